@@ -1,0 +1,247 @@
+/* r3d.h -- C-ABI of the MI355X phonon-transport engine (libr3d_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of Radiative3D: the body of
+ * Model::RunSimulation() (reference model.cpp:602-633), i.e. N independent
+ * calls of ShearDislocation::GenerateEventPhonon() (events.cpp:111-124)
+ * followed by Phonon::Propagate() (phonons.cpp:540-682) and everything those
+ * two call.  The reference has no plugin/FFI interface; the seam is "a fully
+ * built immutable model in, filled seismometer bins + loss counters out".
+ *
+ * Everything crossing the boundary is plain C: POD structs, pointers, sizes.
+ * No C++ types, no torch types, no exceptions, no exit().  A maintainer of the
+ * reference would fill r3d_model_desc from the live objects of its Model
+ * (see INTEGRATION.md for the field-by-field mapping and the stub to add to
+ * model.cpp) and call r3d_run() instead of the for-loop at model.cpp:611-625.
+ *
+ * Units follow the reference: km, s, km/s, arbitrary density.  All reals are
+ * fp64 (reference typedefs.hpp:90, Real = double).
+ */
+#ifndef R3D_H_
+#define R3D_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- ray types (reference raytype.hpp:12-20) --------------------------- */
+enum { R3D_RAY_P = 0, R3D_RAY_S = 1 };
+
+/* ---- cell kinds (reference media.hpp: RCUCylinder :312, Tetra :400,
+ *      SphereShell :467).  A model is homogeneous in kind
+ *      (model.cpp:378-411). ---------------------------------------------- */
+enum { R3D_CELL_CYLINDER = 0, R3D_CELL_TETRA = 1, R3D_CELL_SPHERESHELL = 2 };
+
+/* ---- face flags (reference media_cellface.hpp:120-142) ----------------- */
+enum {
+  R3D_FACE_COLLECT = 1u, /* mCollect   : report to seismometers on arrival  */
+  R3D_FACE_REFLECT = 2u, /* mReflect   : free surface, full R/T, no transmit*/
+  R3D_FACE_ADJOIN  = 4u, /* mAdjoin    : has a neighbour cell               */
+  R3D_FACE_DISCON  = 8u  /* mGridDiscon: first-order discontinuity -> R/T   */
+};
+
+/* One bounding face of a cell.
+ *  plane faces  (PlaneFace,   media_cellface.hpp:273-276): normal + point
+ *  sphere faces (SphereFace,  media_cellface.hpp:375-378): signed radius
+ *               (+R outward-normal top face, -R inward-normal bottom face)
+ *  cylinder wall(CylinderFace,media_cellface.hpp:326-327): radius, no
+ *               neighbour, no flags (the shared static loss face,
+ *               media.cpp:124-125).                                         */
+typedef struct r3d_face {
+  double   normal[3];
+  double   point[3];
+  double   radius;
+  int32_t  neighbor;   /* index of the cell across the face, -1 if none     */
+  uint32_t flags;
+} r3d_face;
+
+/* One medium cell.  Which members are meaningful depends on the model's
+ * cell kind:
+ *  CYLINDER   : vel_c = mVelTop, rho_c = mDensity, q = mQ; faces 0=top plane,
+ *               1=bottom plane, 2=cylinder wall      (media.hpp:312-331)
+ *  TETRA      : vel_grad/vel_c = mVelGrad/mVel0, rho_grad/rho_c, q = mQ;
+ *               faces 0..3 = FACE_A..FACE_D            (media.hpp:400-408)
+ *  SPHERESHELL: v(r) = vel_a r^2 + vel_c, rho(r) = rho_a r^2 + rho_c,
+ *               zero_rad2 = mZeroRadius2; faces 0=top, 1=bottom
+ *                                                       (media.hpp:467-478) */
+typedef struct r3d_cell {
+  double   vel_c[2];
+  double   vel_a[2];
+  double   vel_grad[2][3];
+  double   rho_c;
+  double   rho_a;
+  double   rho_grad[3];
+  double   q[2];
+  double   zero_rad2[2];
+  int32_t  scatterer;   /* index into r3d_model_desc.scatterers             */
+  int32_t  n_faces;     /* 3 / 4 / 2                                        */
+  r3d_face faces[4];
+} r3d_cell;
+
+/* Scatterer (reference scatterers.hpp:157,181 + sources.hpp:130-135).
+ * cdf[k] are the INTEGRATED (cumulative, un-normalised) distributions over
+ * the take-off-angle set for GPP, GPS, GSP, GSS (probability.cpp:21-35);
+ * whole_cdf[in] is the 4-entry cumulative conversion table for an incoming
+ * P (in=0) or S (in=1) phonon (scatterers.cpp:172-184).                     */
+typedef struct r3d_scatterer {
+  double        mfp[2];
+  double        whole_cdf[2][4];
+  const double* cdf[4];      /* each n_toa long                             */
+  const double* spol;        /* n_toa, S->S polarisation (scatparams.cpp:114)*/
+} r3d_scatterer;
+
+/* Event source (reference events.hpp:57-61, sources.hpp:130-135):
+ * cumulative P / SH / SV radiation patterns over the TOA set.              */
+typedef struct r3d_source {
+  double        loc[3];
+  int32_t       cell;
+  int32_t       pad_;
+  double        whole_cdf[3];
+  const double* cdf[3];      /* each n_toa long                             */
+} r3d_source;
+
+/* Seismometer (reference dataout.hpp:102-129, ctor dataout.cpp:42-71).     */
+typedef struct r3d_seismometer {
+  double loc[3];
+  double axes[3][3];   /* X1, X2, X3 unit vectors                           */
+  double r_in[2];      /* inner gather radius by ray type (0 = disc)        */
+  double r_out[2];     /* outer gather radius by ray type                   */
+  double area[2];      /* pi (r_out^2 - r_in^2)                             */
+} r3d_seismometer;
+
+/* Scalar run parameters = the class statics the hot path reads
+ * (phonons.cpp:31-36, media.cpp:32, dataout.cpp:33-34,
+ *  scatterers.hpp:114, ecs.hpp:242-257).                                   */
+typedef struct r3d_params {
+  double   ttl;            /* Phonon::cm_ttl                                */
+  double   frequency;      /* MediumCell::cmPhononFreq (Hz)                 */
+  double   time_per_bin;   /* Seismometer::cmTimePerBin                     */
+  uint32_t n_bins;         /* Seismometer::cmNumBins                        */
+  uint32_t no_deflect;     /* Scatterer::cm_NoDeflect_b                     */
+  double   min_theta;      /* Phonon::cm_min_theta                          */
+  double   max_theta;      /* Phonon::cm_max_theta                          */
+  double   slow_concern;   /* Phonon::cm_slow_concern                       */
+  uint64_t loop_concern;   /* Phonon::cm_loop_concern                       */
+  double   earth_center[3];/* ECS earth centre (sphere-shell models)        */
+} r3d_params;
+
+/* The whole immutable model, as read by the hot path.                      */
+typedef struct r3d_model_desc {
+  int32_t                cell_kind;
+  int32_t                n_cells;
+  const r3d_cell*        cells;
+  int32_t                n_scatterers;
+  int32_t                n_seismometers;
+  const r3d_scatterer*   scatterers;
+  const r3d_seismometer* seismometers;
+  uint64_t               n_toa;
+  const double*          toa;        /* n_toa x (theta, phi)                 */
+  r3d_source             source;
+  r3d_params             params;
+} r3d_model_desc;
+
+/* Invalid-phonon reason slots (reference dataout.hpp:229-237, bit order).  */
+enum {
+  R3D_INV_PATH_NAN = 0, R3D_INV_TIME_NAN, R3D_INV_PATH_NEGATIVE,
+  R3D_INV_TIME_NEGATIVE, R3D_INV_STUCK, R3D_INV_SLOW, R3D_INV_LOOP_EXCEED,
+  R3D_INV_NUM
+};
+
+/* Event counters (diagnostic; one increment where the reference would emit
+ * the corresponding report line, dataout.cpp:526-617).                     */
+enum {
+  R3D_EV_GENERATED = 0, /* GEN */
+  R3D_EV_ITERATIONS,    /* loop iterations of Phonon::Propagate             */
+  R3D_EV_SCATTER,       /* SCT */
+  R3D_EV_COLLECT,       /* COL (collection-face arrivals)                   */
+  R3D_EV_CATCH,         /* seismometer bin increments                       */
+  R3D_EV_REFLECT,       /* REF (free surface + interface reflections)       */
+  R3D_EV_TRANSFER,      /* CEL */
+  R3D_EV_RTSOLVE,       /* Refraction_FullRT calls                          */
+  R3D_EV_NUM
+};
+
+#define R3D_N_ENERGY 5  /* X, Y, Z, P, S  (BinRecord, dataout.hpp:77-93)    */
+#define R3D_N_COUNT  2  /* n_P, n_S                                         */
+
+/* Result block.  `energy` and `counts` are caller-allocated and are
+ * ACCUMULATED into (so shards can be chained); the scalar counters are
+ * likewise added to.
+ *   energy[(s*n_bins + b)*5 + c],  counts[(s*n_bins + b)*2 + t]            */
+typedef struct r3d_result {
+  double*   energy;
+  uint64_t* counts;
+  uint64_t  n_lost;      /* DataReporter::mNumLost    (dataout.cpp:591-598) */
+  uint64_t  n_timeout;   /* mNumTimeout               (dataout.cpp:600-607) */
+  uint64_t  n_invalid;   /* mNumInvalid               (dataout.cpp:611-617) */
+  uint64_t  invalid_reasons[R3D_INV_NUM];
+  uint64_t  events[R3D_EV_NUM];
+} r3d_result;
+
+/* Optional per-history final record, for parity tests (the reference's LST /
+ * TMO / INV report lines carry the same fields, dataout.cpp:484-520).      */
+typedef struct r3d_final {
+  double   time, path, amp;
+  double   loc[3];
+  double   dir[3];
+  uint32_t moves;
+  uint8_t  fate;        /* 1 lost, 2 timeout, 3 invalid                     */
+  uint8_t  type;        /* ray type at the end                              */
+  uint16_t n_catch;     /* seismometer catches along the way                */
+} r3d_final;
+
+typedef struct r3d_engine r3d_engine;   /* opaque: tables resident in HBM   */
+
+/* Copy the model into HBM on `device` and build the engine's own device
+ * layout.  Returns NULL on error (see r3d_last_error).  Thread-compatible:
+ * one engine per thread.                                                   */
+r3d_engine* r3d_engine_create(const r3d_model_desc* model, int device);
+void        r3d_engine_destroy(r3d_engine* e);
+
+/* Sizes of the result block for this engine's model.                       */
+size_t r3d_energy_len(const r3d_engine* e);   /* doubles                    */
+size_t r3d_counts_len(const r3d_engine* e);   /* uint64s                    */
+
+/* Run histories [first_id, first_id + n) with RNG key `seed` and ADD the
+ * outcome into *out (host memory).  Replaces model.cpp:611-625.
+ * Returns 0 on success.  Histories are keyed by id, so the union of any
+ * partition of an id range gives the same result up to fp64 summation
+ * order.                                                                   */
+int r3d_run(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,
+            r3d_result* out);
+
+/* Device-resident variant for multi-GPU jobs: accumulates into caller-owned
+ * DEVICE buffers (e.g. the data_ptr of a torch tensor that is all-reduced
+ * over RCCL afterwards) on `stream` (a hipStream_t, or NULL for the default
+ * stream).  d_scalars holds 3 + R3D_INV_NUM + R3D_EV_NUM uint64 counters in
+ * the order n_lost, n_timeout, n_invalid, invalid_reasons[], events[].
+ * Asynchronous: returns after enqueueing.  d_finals may be NULL.           */
+int r3d_run_device(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,
+                   double* d_energy, uint64_t* d_counts, uint64_t* d_scalars,
+                   r3d_final* d_finals, void* stream);
+
+/* Like r3d_run, additionally returning the per-history final records
+ * (finals[i] for id first_id + i; caller-allocated, n entries).            */
+int r3d_run_traced(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,
+                   r3d_result* out, r3d_final* finals);
+
+/* Duration in milliseconds of the traversal kernel launches enqueued by the
+ * most recent r3d_run / r3d_run_device call on this engine, measured with
+ * HIP events on the engine's stream (blocks until they have completed).    */
+double r3d_last_kernel_ms(r3d_engine* e);
+
+/* Number of scalar counters r3d_run_device expects.                         */
+#define R3D_N_SCALARS (3 + R3D_INV_NUM + R3D_EV_NUM)
+
+/* Message for the last failing call on this thread.                        */
+const char* r3d_last_error(void);
+
+/* Library version / build string.                                          */
+const char* r3d_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R3D_H_ */

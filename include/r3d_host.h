@@ -1,0 +1,50 @@
+/* r3d_host.h -- C-ABI of the host-side model builder (libr3d_host.so).
+ *
+ * The builder is the C++ restatement of the reference's model construction
+ * (Model::Model, model.cpp:220-501) that produces the flat r3d_model_desc the
+ * engine consumes.  It takes the reference's own command-line tokens
+ * (cmdline.hpp:253-312, as assembled by scripts/do-fundamentals.sh:396-419),
+ * so a test or driver describes a run exactly as a do-*.sh script does.
+ */
+#ifndef R3D_HOST_H_
+#define R3D_HOST_H_
+
+#include "r3d.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct r3dh_model r3dh_model;
+
+/* Build a model from argv-style option tokens (program name NOT included),
+ * e.g. {"--grid-compiled=40", "--model-args=...", "--toa-degree=4", ...}.
+ * Returns NULL on error (r3dh_last_error()).                                */
+r3dh_model* r3dh_model_from_args(int argc, const char* const* argv);
+void        r3dh_model_free(r3dh_model* m);
+
+/* The flat tables; valid until r3dh_model_free.                             */
+const r3d_model_desc* r3dh_model_desc(const r3dh_model* m);
+
+/* Run parameters that are not part of the tables.                           */
+uint64_t r3dh_num_phonons(const r3dh_model* m);   /* --num-phonons           */
+uint64_t r3dh_seed(const r3dh_model* m);          /* --seed (default 0x5EED) */
+
+/* Build log (the "@@ __PHASE__" / "|" lines the reference prints to stdout,
+ * model.cpp:222-498).                                                       */
+const char* r3dh_model_log(const r3dh_model* m);
+
+/* ASCII grid dump, identical in layout to `--dump-grid`
+ * (grid.cpp:376-405).  Valid until the model is freed.                      */
+const char* r3dh_grid_dump(r3dh_model* m);
+
+/* Scatterer summary row i: out[10] = nu, eps, a, kappa, el, gam0,
+ * MFP_P, MFP_S, dipole_P, dipole_S (scatterers.cpp:420-478). Returns 0 ok.  */
+int r3dh_scatterer_info(const r3dh_model* m, int i, double out[10]);
+
+const char* r3dh_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,56 @@
+"""ctypes access to the CPU oracle (oracle/libr3d_oracle.so).
+
+TEST INFRASTRUCTURE: import this only from tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg.  The product (radiative3d_amd/) never does.
+"""
+import ctypes as C
+import os
+
+from radiative3d_amd import _ffi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libr3d_oracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"oracle not built: {path} (run `make oracle`)")
+        L = C.CDLL(path)
+        L.r3d_oracle_run.restype = C.c_int
+        L.r3d_oracle_run.argtypes = [C.POINTER(_ffi.ModelDesc), C.c_uint64, C.c_uint64, C.c_uint64,
+                                     C.POINTER(_ffi.Result), C.POINTER(_ffi.Final)]
+        L.r3d_oracle_rt_probs.argtypes = [C.c_double] * 7 + [C.c_int, C.POINTER(C.c_double)]
+        L.r3d_oracle_philox.argtypes = [C.POINTER(C.c_uint32)] * 3
+        L.r3d_oracle_draw.restype = C.c_double
+        L.r3d_oracle_draw.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+        _lib = L
+    return _lib
+
+
+def run(model, n, first_id=0, seed=0x5EED, result=None, trace=False):
+    """Oracle counterpart of Engine.run (same contract)."""
+    res = result if result is not None else model.new_result()
+    c = res._as_c()
+    finals = (_ffi.Final * n)() if trace else None
+    rc = lib().r3d_oracle_run(model.desc_p, n, first_id, seed, C.byref(c), finals)
+    if rc:
+        raise RuntimeError("oracle run failed")
+    res._from_c(c)
+    return (res, finals) if trace else res
+
+
+def rt_probs(rho1, a1, b1, rho2, a2, b2, sini, intype):
+    out = (C.c_double * 6)()
+    lib().r3d_oracle_rt_probs(rho1, a1, b1, rho2, a2, b2, sini, intype, out)
+    return list(out)
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().r3d_oracle_philox(c, k, o)
+    return list(o)

@@ -1,0 +1,141 @@
+"""ctypes mirror of include/r3d.h and include/r3d_host.h.
+
+Only plain C crosses the boundary; these Structure classes restate the POD
+layouts field for field.  tests/test_abi.py checks sizes against the compiled
+libraries.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBDIR = os.path.join(_HERE, "lib")
+REPO = os.path.dirname(_HERE)
+
+R3D_CELL_CYLINDER, R3D_CELL_TETRA, R3D_CELL_SPHERESHELL = 0, 1, 2
+R3D_FACE_COLLECT, R3D_FACE_REFLECT, R3D_FACE_ADJOIN, R3D_FACE_DISCON = 1, 2, 4, 8
+R3D_INV_NUM = 7
+R3D_EV_NAMES = ("generated", "iterations", "scatter", "collect", "catch", "reflect",
+                "transfer", "rtsolve")
+R3D_EV_NUM = len(R3D_EV_NAMES)
+R3D_N_ENERGY, R3D_N_COUNT = 5, 2
+R3D_N_SCALARS = 3 + R3D_INV_NUM + R3D_EV_NUM
+
+_dp = C.POINTER(C.c_double)
+
+
+class Face(C.Structure):
+    _fields_ = [("normal", C.c_double * 3), ("point", C.c_double * 3), ("radius", C.c_double),
+                ("neighbor", C.c_int32), ("flags", C.c_uint32)]
+
+
+class Cell(C.Structure):
+    _fields_ = [("vel_c", C.c_double * 2), ("vel_a", C.c_double * 2),
+                ("vel_grad", (C.c_double * 3) * 2), ("rho_c", C.c_double), ("rho_a", C.c_double),
+                ("rho_grad", C.c_double * 3), ("q", C.c_double * 2), ("zero_rad2", C.c_double * 2),
+                ("scatterer", C.c_int32), ("n_faces", C.c_int32), ("faces", Face * 4)]
+
+
+class Scatterer(C.Structure):
+    _fields_ = [("mfp", C.c_double * 2), ("whole_cdf", (C.c_double * 4) * 2), ("cdf", _dp * 4),
+                ("spol", _dp)]
+
+
+class Source(C.Structure):
+    _fields_ = [("loc", C.c_double * 3), ("cell", C.c_int32), ("pad_", C.c_int32),
+                ("whole_cdf", C.c_double * 3), ("cdf", _dp * 3)]
+
+
+class Seismometer(C.Structure):
+    _fields_ = [("loc", C.c_double * 3), ("axes", (C.c_double * 3) * 3), ("r_in", C.c_double * 2),
+                ("r_out", C.c_double * 2), ("area", C.c_double * 2)]
+
+
+class Params(C.Structure):
+    _fields_ = [("ttl", C.c_double), ("frequency", C.c_double), ("time_per_bin", C.c_double),
+                ("n_bins", C.c_uint32), ("no_deflect", C.c_uint32), ("min_theta", C.c_double),
+                ("max_theta", C.c_double), ("slow_concern", C.c_double),
+                ("loop_concern", C.c_uint64), ("earth_center", C.c_double * 3)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("cell_kind", C.c_int32), ("n_cells", C.c_int32), ("cells", C.POINTER(Cell)),
+                ("n_scatterers", C.c_int32), ("n_seismometers", C.c_int32),
+                ("scatterers", C.POINTER(Scatterer)), ("seismometers", C.POINTER(Seismometer)),
+                ("n_toa", C.c_uint64), ("toa", _dp), ("source", Source), ("params", Params)]
+
+
+class Result(C.Structure):
+    _fields_ = [("energy", _dp), ("counts", C.POINTER(C.c_uint64)), ("n_lost", C.c_uint64),
+                ("n_timeout", C.c_uint64), ("n_invalid", C.c_uint64),
+                ("invalid_reasons", C.c_uint64 * R3D_INV_NUM), ("events", C.c_uint64 * R3D_EV_NUM)]
+
+
+class Final(C.Structure):
+    _fields_ = [("time", C.c_double), ("path", C.c_double), ("amp", C.c_double),
+                ("loc", C.c_double * 3), ("dir", C.c_double * 3), ("moves", C.c_uint32),
+                ("fate", C.c_uint8), ("type", C.c_uint8), ("n_catch", C.c_uint16)]
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"native library missing: {path} -- build it with `make` (or "
+            f"`python -c 'import __graft_entry__ as g; g.build()'`); there is no fallback path")
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+_host = None
+_hip = None
+
+
+def host_lib():
+    """libr3d_host.so: the C++ model builder."""
+    global _host
+    if _host is None:
+        L = _load(os.path.join(LIBDIR, "libr3d_host.so"))
+        L.r3dh_model_from_args.restype = C.c_void_p
+        L.r3dh_model_from_args.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+        L.r3dh_model_free.argtypes = [C.c_void_p]
+        L.r3dh_model_desc.restype = C.POINTER(ModelDesc)
+        L.r3dh_model_desc.argtypes = [C.c_void_p]
+        L.r3dh_num_phonons.restype = C.c_uint64
+        L.r3dh_num_phonons.argtypes = [C.c_void_p]
+        L.r3dh_seed.restype = C.c_uint64
+        L.r3dh_seed.argtypes = [C.c_void_p]
+        L.r3dh_model_log.restype = C.c_char_p
+        L.r3dh_model_log.argtypes = [C.c_void_p]
+        L.r3dh_grid_dump.restype = C.c_char_p
+        L.r3dh_grid_dump.argtypes = [C.c_void_p]
+        L.r3dh_scatterer_info.restype = C.c_int
+        L.r3dh_scatterer_info.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.r3dh_last_error.restype = C.c_char_p
+        _host = L
+    return _host
+
+
+def hip_lib():
+    """libr3d_hip.so: the HIP engine.  Fails loudly when it was not built."""
+    global _hip
+    if _hip is None:
+        L = _load(os.path.join(LIBDIR, "libr3d_hip.so"))
+        L.r3d_engine_create.restype = C.c_void_p
+        L.r3d_engine_create.argtypes = [C.POINTER(ModelDesc), C.c_int]
+        L.r3d_engine_destroy.argtypes = [C.c_void_p]
+        L.r3d_energy_len.restype = C.c_size_t
+        L.r3d_energy_len.argtypes = [C.c_void_p]
+        L.r3d_counts_len.restype = C.c_size_t
+        L.r3d_counts_len.argtypes = [C.c_void_p]
+        L.r3d_run.restype = C.c_int
+        L.r3d_run.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(Result)]
+        L.r3d_run_traced.restype = C.c_int
+        L.r3d_run_traced.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                     C.POINTER(Result), C.POINTER(Final)]
+        L.r3d_run_device.restype = C.c_int
+        L.r3d_run_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.r3d_last_kernel_ms.restype = C.c_double
+        L.r3d_last_kernel_ms.argtypes = [C.c_void_p]
+        L.r3d_last_error.restype = C.c_char_p
+        L.r3d_version.restype = C.c_char_p
+        _hip = L
+    return _hip

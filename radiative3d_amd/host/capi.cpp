@@ -1,0 +1,76 @@
+// capi.cpp -- C-ABI of the host model builder (include/r3d_host.h).
+// Exceptions never cross the boundary: they become a NULL / non-zero return
+// plus a thread-local message.
+#include <sstream>
+
+#include "../../include/r3d_host.h"
+#include "cmdline.hpp"
+
+namespace {
+thread_local std::string g_error;
+}
+
+struct r3dh_model {
+  ModelParams params;
+  MissionParams mission;
+  std::ostringstream log;
+  std::unique_ptr<Model> model;
+  std::string grid_dump;
+};
+
+extern "C" {
+
+r3dh_model* r3dh_model_from_args(int argc, const char* const* argv) {
+  try {
+    auto h = std::make_unique<r3dh_model>();
+    std::vector<std::string> tokens(argv, argv + argc);
+    ParseCommandLine(tokens, h->params, h->mission);
+    h->model = std::make_unique<Model>(h->params, &h->log);
+    return h.release();
+  } catch (const std::exception& e) {
+    g_error = e.what();
+  } catch (...) {
+    g_error = "unknown error";
+  }
+  return nullptr;
+}
+
+void r3dh_model_free(r3dh_model* m) { delete m; }
+
+const r3d_model_desc* r3dh_model_desc(const r3dh_model* m) { return m ? &m->model->Desc() : nullptr; }
+
+uint64_t r3dh_num_phonons(const r3dh_model* m) { return m ? (uint64_t)m->params.NumPhonons : 0; }
+uint64_t r3dh_seed(const r3dh_model* m) { return m ? (uint64_t)m->mission.Seed : 0; }
+
+const char* r3dh_model_log(const r3dh_model* m) {
+  static thread_local std::string s;
+  s = m ? m->log.str() : "";
+  return s.c_str();
+}
+
+const char* r3dh_grid_dump(r3dh_model* m) {
+  if (!m) return "";
+  try {
+    // The dump goes through the global coordinate system, which still holds
+    // this model's mapping only if no other model was built since.
+    std::ostringstream os;
+    m->model->GetGridRef().DumpGridToAscii(os);
+    m->grid_dump = os.str();
+  } catch (const std::exception& e) {
+    g_error = e.what();
+    m->grid_dump.clear();
+  }
+  return m->grid_dump.c_str();
+}
+
+int r3dh_scatterer_info(const r3dh_model* m, int i, double out[10]) {
+  if (!m || i < 0 || i >= (int)m->model->Scatterers().size()) return 1;
+  const ScattererInfo& s = m->model->Scatterers()[i];
+  const double v[10] = {s.nu, s.eps, s.a, s.kappa, s.el, s.gam0, s.mfp[0], s.mfp[1], s.dipole[0], s.dipole[1]};
+  for (int k = 0; k < 10; k++) out[k] = v[k];
+  return 0;
+}
+
+const char* r3dh_last_error(void) { return g_error.c_str(); }
+
+}  // extern "C"

@@ -1,0 +1,297 @@
+// models_builtin.cpp -- compiled-in Earth-model definitions.
+//
+// Grid::ConstructGridManual(selection, args) is the hook through which the
+// reference selects a model (reference user.cpp:59-134).  The reference keeps
+// one hand-written function per model in user_*_inc.cpp; those files remain
+// the user's and still compile against this library's grid.hpp.  What is
+// built in here are table-driven definitions of the four benchmark models
+// named by BASELINE.json, with the same selection codes, argument lists and
+// node values as the reference's functions:
+//
+//   40      halfspace, two layers          (user_Halfspace_inc.cpp:28-183)
+//   1..4    Lop Nor layered crust+mantle   (user_LopNorCyl_inc.cpp:30-400)
+//   5..7    North Sea crust pinch, tetra   (user_NSCP_inc.cpp:13-206)
+//   16      whole-Earth spherical shells   (user_SphereEarth_inc.cpp:13-86)
+//
+// Where the reference prints to stderr and calls exit(1) on a bad argument
+// count, these throw Runtime.
+#include <algorithm>
+#include <iostream>
+
+#include "grid.hpp"
+
+namespace {
+
+using Elastic::HetSpec;
+using Elastic::HSneak;
+using Elastic::Q;
+using Elastic::QmQk;
+using Elastic::VpVs;
+
+const Real kInf = std::numeric_limits<Real>::infinity();
+
+[[noreturn]] void bad_arg_count() {
+  throw Runtime("Error: wrong number of model args passed to compiled-in "
+                "grid-building function.");
+}
+
+// One (nu, eps, a, kappa, Qs) group as it appears in --model-args.
+struct Neakq {
+  Real nu, eps, a, k, q;
+  HetSpec hs() const { return HSneak(nu, eps, a, k); }
+  Q qq() const { return QmQk(q); }
+};
+Neakq neakq_at(const std::vector<Real>& v, size_t o) {
+  return {v.at(o), v.at(o + 1), v.at(o + 2), v.at(o + 3), v.at(o + 4)};
+}
+
+// A layered ("cylinder") grid is 3 plumb lines x nk sheets; attributes live
+// on the first plumb line only (model.cpp:647-724 reads Node(0,0,k)).
+void place_sheet(Grid& g, Index k, const Real xy[3][2], const Real z[3]) {
+  for (Index p = 0; p < 3; p++) g.WNode(p, 0, k).SetLocation(xy[p][0], xy[p][1], z[p]);
+}
+
+// ---------------------------------------------------------------- 40 ------
+void build_halfspace(Grid& g, const std::vector<Real>& a) {
+  Neakq top{0.8, 0.05, 0.50, 0.5, kInf}, bot{0.8, 0.04, 1.0, 0.5, kInf};
+  Real tv[4] = {6.40, 3.63, 2.83, -21.5};  // Vp, Vs, rho, z_bottom
+  Real bv[4] = {6.40, 3.63, 2.83, -100.0};
+  switch (a.size()) {
+    case 0:
+      break;
+    case 18:
+      for (int i = 0; i < 4; i++) tv[i] = a[10 + i], bv[i] = a[14 + i];
+      [[fallthrough]];
+    case 10:
+      top = neakq_at(a, 0), bot = neakq_at(a, 5);
+      break;
+    default:
+      bad_arg_count();
+  }
+  g.SetSize(3, 1, 3);
+  g.SetIndexBase(0);
+  const Real xy[3][2] = {{0, 0}, {100, 0}, {0, 100}};
+  const Real depth[3] = {0.0, tv[3], bv[3]};
+  for (Index k = 0; k < 3; k++) {
+    const Real z[3] = {depth[k], depth[k], depth[k]};
+    place_sheet(g, k, xy, z);
+  }
+  // The interface gets two attribute sets (=> full R/T) only when the layers
+  // actually differ elastically.
+  bool contrast = !(tv[0] == bv[0] && tv[1] == bv[1] && tv[2] == bv[2]);
+  g.WNode(0, 0, 0).SetAttributes(VpVs(tv[0], tv[1]), tv[2], top.qq(), top.hs());
+  if (contrast) g.WNode(0, 0, 1).SetAttributes(VpVs(tv[0], tv[1]), tv[2], top.qq(), top.hs());
+  g.WNode(0, 0, 1).SetAttributes(VpVs(bv[0], bv[1]), bv[2], bot.qq(), bot.hs());
+  g.WNode(0, 0, 2).SetAttributes(VpVs(bv[0], bv[1]), bv[2], bot.qq(), bot.hs());
+}
+
+// --------------------------------------------------------------- 1..4 -----
+void build_lopnor(Grid& g, const std::vector<Real>& a) {
+  Neakq sedi{0.8, 0.06, 0.25, 0.5, kInf}, crust{0.8, 0.05, 0.50, 0.5, kInf},
+      mant{0.8, 0.04, 1.0, 0.5, kInf};
+  Neakq* grp[3] = {&sedi, &crust, &mant};
+  size_t per = 0;  // values per group: nu,eps,a[,k[,Q]]
+  switch (a.size()) {
+    case 0: break;
+    case 9: per = 3; break;
+    case 12: per = 4; break;
+    case 15: per = 5; break;
+    default: bad_arg_count();
+  }
+  for (size_t r = 0; r < 3 && per; r++) {
+    const Real* v = &a[r * per];
+    grp[r]->nu = v[0], grp[r]->eps = v[1], grp[r]->a = v[2];
+    if (per > 3) grp[r]->k = v[3];
+    if (per > 4) grp[r]->q = v[4];
+  }
+
+  g.SetSize(3, 1, 22);
+  g.SetIndexBase(0);
+  // Plumb lines under Lop Nor, station MAK, station WUS; the five crustal
+  // sheets are tilted, the mantle sheets are level.
+  const Real xy[3][2] = {{492.31, -263.65}, {-102.27, 430.84}, {-390.04, -167.18}};
+  const Real crust_z[5][3] = {{1.050, 0.600, 1.457},
+                              {0.563, 0.118, 0.963},
+                              {-18.901, -16.743, -18.812},
+                              {-38.365, -33.122, -38.587},
+                              {-47.610, -43.720, -47.980}};
+  const Real mantle_z[17] = {-80.0,  -120.0, -165.0, -210.0, -260.0, -310.0,
+                             -360.0, -410.0, -460.0, -510.0, -560.0, -610.0,
+                             -660.0, -710.0, -760.0, -809.5, -859.0};
+  for (Index k = 0; k < 5; k++) place_sheet(g, k, xy, crust_z[k]);
+  for (Index k = 0; k < 17; k++) {
+    const Real z[3] = {mantle_z[k], mantle_z[k], mantle_z[k]};
+    place_sheet(g, k + 5, xy, z);
+  }
+
+  // {sheet, region(0 sedi,1 crust,2 mantle), Vp, Vs, rho}; a sheet listed
+  // twice is a first-order discontinuity (above, then below).
+  struct Row { Index k; int region; Real vp, vs, rho; };
+  static const Row rows[] = {
+      {0, 0, 2.50, 1.20, 2.10},       {1, 1, 2.50, 1.20, 2.10},
+      {1, 1, 6.13, 3.53, 2.75},       {2, 1, 6.40, 3.63, 2.83},
+      {3, 1, 7.23, 4.00, 3.10},       {4, 1, 7.23, 4.00, 3.10},
+      {4, 2, 8.07, 4.63, 3.35},       {5, 2, 8.040, 4.480, 3.502},
+      {5, 2, 8.045, 4.490, 3.502},    {6, 2, 8.0505, 4.5000, 3.4268},
+      {7, 2, 8.1750, 4.5090, 3.3711}, {8, 2, 8.3007, 4.5184, 3.3243},
+      {9, 2, 8.4822, 4.6094, 3.3663}, {10, 2, 8.6650, 4.6964, 3.4110},
+      {11, 2, 8.8476, 4.7832, 3.4577}, {12, 2, 9.0302, 4.8702, 3.5068},
+      {12, 2, 9.3601, 5.0806, 3.9317}, {13, 2, 9.5280, 5.1864, 3.9273},
+      {14, 2, 9.6962, 5.2922, 3.9233}, {15, 2, 9.8640, 5.3989, 3.9218},
+      {16, 2, 10.0320, 5.5047, 3.9206}, {17, 2, 10.2000, 5.6104, 3.9201},
+      {17, 2, 10.7909, 5.9607, 4.2387}, {18, 2, 10.9222, 6.0898, 4.2986},
+      {19, 2, 11.0553, 6.2100, 4.3565}, {20, 2, 11.1355, 6.2424, 4.4118},
+      {21, 2, 11.2228, 6.2799, 4.4650}};
+  for (const Row& r : rows)
+    g.WNode(0, 0, r.k).SetAttributes(VpVs(r.vp, r.vs), r.rho, grp[r.region]->qq(),
+                                     grp[r.region]->hs());
+}
+
+// --------------------------------------------------------------- 5..7 -----
+void build_crustpinch(Grid& g, const std::vector<Real>& a) {
+  // Layer groups: sediments, crust, pinched crust, Moho transition, mantle.
+  Neakq dflt{0.8, 0.01, 4.00, 0.8, 200};
+  Neakq sedi = dflt, crust = dflt, pinch = dflt, moho = dflt, mant = dflt;
+  Real sedi_thick = 2.0, crust_thick = 30.0, moho_thick = 10.0;
+  Real pinch_frac = 0.70;  // pinched crust thickness / normal thickness
+  Real depth_frac = 0.50;  // 0 top-aligned, 0.5 common midline, 1 bottom-aligned
+  Real sedi_frac = 1.0, moho_frac = 1.0;
+  switch (a.size()) {
+    case 0:
+      break;
+    case 32:
+      pinch_frac = a[28], depth_frac = a[29], sedi_frac = a[30], moho_frac = a[31];
+      [[fallthrough]];
+    case 28:
+      sedi_thick = a[25], crust_thick = a[26], moho_thick = a[27];
+      [[fallthrough]];
+    case 25:
+      sedi = neakq_at(a, 0), crust = neakq_at(a, 5), pinch = neakq_at(a, 10);
+      moho = neakq_at(a, 15), mant = neakq_at(a, 20);
+      break;
+    default:
+      bad_arg_count();
+  }
+
+  const Count nR = 14, nAz = 6, nZ = 8;
+  const Real azi_far[nAz] = {45.0, 56.25, 78.75, 101.25, 123.75, 135.0};
+  const Real azi_near[nAz] = {5.0, 39.00, 73.00, 107.00, 141.00, 175.0};
+  const Real range[nR] = {-120, -60, 60, 120, 220, 310, 370, 420, 470, 530, 650, 770, 890, 1020};
+
+  Real z_norm[nZ] = {0.0,
+                     -sedi_thick,
+                     -(sedi_thick + crust_thick),
+                     -(sedi_thick + crust_thick + moho_thick),
+                     -80, -120, -210, -360};
+  Real pinch_thick = pinch_frac * crust_thick;
+  Real pinch_top = -sedi_thick - (crust_thick - pinch_thick) * depth_frac;
+  Real sedi_fill = std::max(sedi_frac * (-sedi_thick - pinch_top), Real(0));
+  Real z_pinch[nZ];
+  z_pinch[0] = pinch_top + (sedi_thick + sedi_fill);
+  z_pinch[1] = pinch_top;
+  z_pinch[2] = pinch_top - pinch_thick;
+  z_pinch[3] = z_pinch[2] - moho_frac * moho_thick;
+  for (Count k = 4; k < nZ; k++) z_pinch[k] = z_norm[k];
+
+  g.SetSize(nR, nAz, nZ);
+  g.SetIndexBase(0);
+  g.SetMapping(Grid::GC_RAE, Grid::GC_CURVED);
+
+  for (Index ja = 0; ja < nAz; ja++) {
+    for (Index k = 0; k < nZ; k++)
+      for (Index ir = 0; ir < nR; ir++) {
+        // Behind the origin (negative range) the azimuth fan is mirrored;
+        // the two columns nearest the origin use the wide close-range fan.
+        Real az = (ir == 0)   ? azi_far[nAz - 1 - ja]
+                  : (ir == 1) ? azi_near[nAz - 1 - ja]
+                  : (ir == 2) ? azi_near[ja]
+                              : azi_far[ja];
+        bool pinched_col = (ir >= 6 && ir <= 8);
+        g.WNode(ir, ja, k).SetLocation(range[ir], az, pinched_col ? z_pinch[k] : z_norm[k]);
+      }
+    for (Index ir = 0; ir < nR; ir++) {
+      const Neakq& cr = (ir >= 6 && ir < 8) ? pinch : crust;
+      struct Row { Index k; const Neakq* grp; Real vp, vs, rho; };
+      const Row rows[] = {{0, &sedi, 4.50, 2.60, 2.20},  {1, &sedi, 4.52, 2.61, 2.21},
+                          {1, &cr, 6.20, 3.58, 2.80},    {2, &cr, 6.24, 3.60, 2.82},
+                          {2, &moho, 7.70, 4.44, 3.39},  {3, &mant, 8.00, 4.46, 3.40},
+                          {4, &mant, 8.040, 4.48, 3.50}, {4, &mant, 8.045, 4.49, 3.50},
+                          {5, &mant, 8.051, 4.50, 3.43}, {6, &mant, 8.301, 4.52, 3.32},
+                          {7, &mant, 8.848, 4.78, 3.46}};
+      for (const Row& r : rows)
+        g.WNode(ir, ja, r.k).SetAttributes(VpVs(r.vp, r.vs), r.rho, r.grp->qq(), r.grp->hs());
+    }
+  }
+}
+
+// ---------------------------------------------------------------- 16 ------
+void build_sphere_earth(Grid& g, const std::vector<Real>&) {
+  const Real q = 2000;
+  const HetSpec hs_std = HSneak(0.8, 0.005, 4.00, 0.8);
+  const HetSpec hs_outer_core = HSneak(0.8, 0.005, 8.00, 0.8);
+  const Q q_crust = QmQk(0.8 * q), q_mantle = QmQk(q), q_outer_core = QmQk(1, 20 * q),
+          q_inner_core = QmQk(q);
+
+  const Real depth[16] = {0,     -100.0,  -410.0,  -660.0,  -958.0,  -1354.0, -2047.0, -2789.0,
+                          -2891.0, -3594.0, -4298.0, -4852.0, -5153.0, -5661.0, -6066.0, -6371.0};
+  g.SetSize(1, 1, 16);
+  g.SetIndexBase(0);
+  g.SetMapping(Grid::GC_RAE, Grid::GC_SPHERICAL);
+  for (Index k = 0; k < 16; k++) g.WNode(0, 0, k).SetLocation(0, 0, depth[k]);
+
+  // region: 0 crust, 1 mantle, 2 outer core (liquid: Vs = 1e-5), 3 inner core
+  struct Row { Index k; int region; Real vp, vs, rho; };
+  static const Row rows[] = {
+      {0, 0, 5.80, 3.20, 2.60},    {1, 0, 6.80, 3.90, 2.92},    {1, 1, 8.04, 4.48, 3.64},
+      {2, 1, 9.03, 4.87, 3.51},    {2, 1, 9.36, 5.08, 3.93},    {3, 1, 10.20, 5.61, 3.92},
+      {3, 1, 10.79, 5.96, 4.24},   {4, 1, 11.39, 6.35, 5.60},   {5, 1, 11.99, 6.60, 4.57},
+      {6, 1, 12.85, 6.94, 5.13},   {7, 1, 13.65, 7.26, 5.72},   {8, 1, 13.66, 7.28, 5.77},
+      {8, 2, 8.00, 1e-5, 9.91},    {9, 2, 9.08, 1e-5, 10.9},    {10, 2, 9.79, 1e-5, 11.6},
+      {11, 2, 10.17, 1e-5, 12.0},  {12, 2, 10.29, 1e-5, 12.1},  {12, 3, 11.04, 3.50, 12.7},
+      {13, 3, 11.18, 3.61, 12.9},  {14, 3, 11.25, 3.66, 13.0},  {15, 3, 11.26, 3.67, 13.0}};
+  const Q* qs[4] = {&q_crust, &q_mantle, &q_outer_core, &q_inner_core};
+  for (const Row& r : rows)
+    g.WNode(0, 0, r.k).SetAttributes(VpVs(r.vp, r.vs), r.rho, *qs[r.region],
+                                     r.region == 2 ? hs_outer_core : hs_std);
+}
+
+}  // namespace
+
+// Weak so that a program linking the reference's own user.cpp (which defines
+// this same member) overrides the built-in dispatcher.
+__attribute__((weak)) void Grid::ConstructGridManual(int Selection,
+                                                     const std::vector<Real>& args) {
+  const char* head = "|  ConstructGridManual: ";
+  if (Selection == 0) {
+    Selection = 5;
+    std::cout << head << "Changing selection 0 (no selection) to selection " << Selection
+              << ".\n";
+  }
+  switch (Selection) {
+    case 1: case 2: case 3: case 4:
+      if (args.size() >= 20)
+        throw Runtime("Lop Nor Moho variant is not among the built-in models; "
+                      "link the user model file that defines it.");
+      std::cout << head << "Selected Lop Nor Baseline Model (Layered).\n";
+      build_lopnor(*this, args);
+      break;
+    case 5: case 6: case 7:
+      std::cout << head << "Selected North Sea Crust Pinch Model (Tetra WCG).\n";
+      build_crustpinch(*this, args);
+      break;
+    case 16:
+      std::cout << head << "Selected Spherical Earth Model (Spherical).\n";
+      build_sphere_earth(*this, args);
+      break;
+    case 40:
+      std::cout << head << "Selected Halfspace Model (Layered).\n";
+      build_halfspace(*this, args);
+      break;
+    default: {
+      std::cout << head << "Model selection code not known.\n";
+      TextStream err;
+      err << "Unknown compiled grid selection ID " << Selection << ".";
+      throw Runtime(err.str());
+    }
+  }
+}

@@ -1,0 +1,187 @@
+"""Host-side Python mirror of the reference's run interface for the hot path.
+
+``Model(args)`` takes the reference's own command-line tokens (the ones a
+do-*.sh script assembles, scripts/do-fundamentals.sh:396-419) and builds the
+flat tables through the C++ builder (libr3d_host.so).  ``Engine(model)`` puts
+them in HBM and ``Engine.run(n, first_id, seed)`` is the drop-in for the body
+of ``Model::RunSimulation()`` (reference model.cpp:602-633): N histories of
+GenerateEventPhonon + Propagate, returning filled seismometer bins and the
+loss counters.
+
+There is no CPU fallback here: without libr3d_hip.so (or without a GPU)
+``Engine`` raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+
+
+class Result:
+    """Seismometer bins + counters of a run (reference BinRecord,
+    dataout.hpp:77-93, and DataReporter counters, dataout.cpp:591-617)."""
+
+    def __init__(self, n_seis, n_bins):
+        self.n_seis, self.n_bins = n_seis, n_bins
+        self.energy = np.zeros((n_seis, n_bins, _ffi.R3D_N_ENERGY), dtype=np.float64)
+        self.counts = np.zeros((n_seis, n_bins, _ffi.R3D_N_COUNT), dtype=np.uint64)
+        self.n_lost = self.n_timeout = self.n_invalid = 0
+        self.invalid_reasons = np.zeros(_ffi.R3D_INV_NUM, dtype=np.uint64)
+        self.events = dict.fromkeys(_ffi.R3D_EV_NAMES, 0)
+
+    # -- C view -------------------------------------------------------------
+    def _as_c(self):
+        r = _ffi.Result()
+        r.energy = self.energy.ctypes.data_as(C.POINTER(C.c_double))
+        r.counts = self.counts.ctypes.data_as(C.POINTER(C.c_uint64))
+        r.n_lost, r.n_timeout, r.n_invalid = self.n_lost, self.n_timeout, self.n_invalid
+        for i in range(_ffi.R3D_INV_NUM):
+            r.invalid_reasons[i] = int(self.invalid_reasons[i])
+        for i, k in enumerate(_ffi.R3D_EV_NAMES):
+            r.events[i] = self.events[k]
+        return r
+
+    def _from_c(self, r):
+        self.n_lost, self.n_timeout, self.n_invalid = int(r.n_lost), int(r.n_timeout), int(r.n_invalid)
+        for i in range(_ffi.R3D_INV_NUM):
+            self.invalid_reasons[i] = r.invalid_reasons[i]
+        for i, k in enumerate(_ffi.R3D_EV_NAMES):
+            self.events[k] = int(r.events[i])
+
+    @property
+    def diag_invalid(self):
+        """7-bit OR of the invalid reasons (DataReporter::mDiagInvalid)."""
+        return sum(1 << i for i in range(_ffi.R3D_INV_NUM) if self.invalid_reasons[i])
+
+    def scalars(self):
+        return np.array([self.n_lost, self.n_timeout, self.n_invalid, *self.invalid_reasons,
+                         *[self.events[k] for k in _ffi.R3D_EV_NAMES]], dtype=np.uint64)
+
+    def set_scalars(self, v):
+        v = [int(x) for x in v]
+        self.n_lost, self.n_timeout, self.n_invalid = v[0:3]
+        self.invalid_reasons[:] = v[3:3 + _ffi.R3D_INV_NUM]
+        for i, k in enumerate(_ffi.R3D_EV_NAMES):
+            self.events[k] = v[3 + _ffi.R3D_INV_NUM + i]
+
+
+class Model:
+    """A built, immutable Earth model + source + seismometers."""
+
+    def __init__(self, args):
+        if isinstance(args, str):
+            args = args.split()
+        self._lib = _ffi.host_lib()
+        self.args = list(args)
+        argv = (C.c_char_p * len(args))(*[a.encode() for a in args])
+        self._h = self._lib.r3dh_model_from_args(len(args), argv)
+        if not self._h:
+            raise RuntimeError("model build failed: " + self._lib.r3dh_last_error().decode())
+        self.desc_p = self._lib.r3dh_model_desc(self._h)
+        self.desc = self.desc_p.contents
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.r3dh_model_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- facts about the model ------------------------------------------------
+    @property
+    def n_cells(self):
+        return self.desc.n_cells
+
+    @property
+    def n_scatterers(self):
+        return self.desc.n_scatterers
+
+    @property
+    def n_seismometers(self):
+        return self.desc.n_seismometers
+
+    @property
+    def n_bins(self):
+        return self.desc.params.n_bins
+
+    @property
+    def n_toa(self):
+        return self.desc.n_toa
+
+    @property
+    def num_phonons(self):
+        return int(self._lib.r3dh_num_phonons(self._h))
+
+    @property
+    def seed(self):
+        return int(self._lib.r3dh_seed(self._h))
+
+    @property
+    def log(self):
+        return self._lib.r3dh_model_log(self._h).decode()
+
+    def grid_dump(self):
+        return self._lib.r3dh_grid_dump(self._h).decode()
+
+    def scatterer_info(self, i):
+        out = (C.c_double * 10)()
+        if self._lib.r3dh_scatterer_info(self._h, i, out):
+            raise IndexError(i)
+        keys = ("nu", "eps", "a", "kappa", "el", "gam0", "mfp_p", "mfp_s", "dipole_p", "dipole_s")
+        return dict(zip(keys, out))
+
+    def new_result(self):
+        return Result(self.n_seismometers, self.n_bins)
+
+
+class Engine:
+    """The model resident in HBM + the HIP traversal kernels (libr3d_hip.so)."""
+
+    def __init__(self, model, device=0):
+        self._lib = _ffi.hip_lib()
+        self.model = model
+        self._e = self._lib.r3d_engine_create(model.desc_p, device)
+        if not self._e:
+            raise RuntimeError("r3d_engine_create failed: " + self._lib.r3d_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_e", None):
+            self._lib.r3d_engine_destroy(self._e)
+            self._e = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, n, first_id=0, seed=0x5EED, result=None, trace=False):
+        """Run histories [first_id, first_id+n); accumulate into `result`."""
+        res = result if result is not None else self.model.new_result()
+        c = res._as_c()
+        finals = None
+        if trace:
+            finals = (_ffi.Final * n)()
+            rc = self._lib.r3d_run_traced(self._e, n, first_id, seed, C.byref(c), finals)
+        else:
+            rc = self._lib.r3d_run(self._e, n, first_id, seed, C.byref(c))
+        if rc:
+            raise RuntimeError("r3d_run failed: " + self._lib.r3d_last_error().decode())
+        res._from_c(c)
+        return (res, finals) if trace else res
+
+    def run_device(self, n, first_id, seed, d_energy, d_counts, d_scalars, stream=None):
+        """Asynchronous, device-resident accumulate (pointers are raw device
+        addresses, e.g. tensor.data_ptr())."""
+        rc = self._lib.r3d_run_device(self._e, n, first_id, seed, d_energy, d_counts, d_scalars,
+                                      None, stream)
+        if rc:
+            raise RuntimeError("r3d_run_device failed: " + self._lib.r3d_last_error().decode())
+
+    def last_kernel_ms(self):
+        return float(self._lib.r3d_last_kernel_ms(self._e))
