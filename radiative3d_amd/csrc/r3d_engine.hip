@@ -1,0 +1,479 @@
+// r3d_engine.hip -- the MI355X (gfx950) phonon-transport engine: persistent
+// traversal kernel + the C-ABI of include/r3d.h.
+//
+// Kernel design (one phonon per work-item, 64-wide wavefronts):
+//   * persistent grid: a few workgroups per CU; each WAVE pulls chunks of
+//     history ids from one global counter (one atomic per 256 histories) and
+//     deals them to its lanes with a ballot + prefix-popcount, so a lane whose
+//     history ended is refilled at the next iteration and the wave stays full
+//     until the id range is exhausted;
+//   * every iteration all live lanes run the same sequence: boundary search ->
+//     free-path draw -> advance; only the event handling after it (scatter /
+//     collect / reflect-transmit / bend) diverges;
+//   * small read-only tables (cells of layered and spherical models, the
+//     scatterer heads, the seismometer scan records) are staged in LDS once
+//     per workgroup; tetra cells (0.6 MB for the crust-pinch model), CDFs
+//     (GBs at TOA degree 9) and bins stay in HBM / L2;
+//   * bins are accumulated with native fp64 / u64 global atomics;
+//   * RNG is counter-based Philox keyed by history id (r3d_rng.h): results are
+//     independent of lane, wave, launch geometry and GPU count.
+//
+// The product has no CPU path: without a HIP device every entry point fails
+// with an error message.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/r3d.h"
+#include "r3d_pack.h"
+#include "r3d_step.h"
+
+namespace r3d {
+
+constexpr int kBlock = 256;          // 4 waves
+constexpr unsigned kChunk = 256;     // history ids a wave claims per global atomic
+
+// --------------------------------------------------------------- the kernel --
+template <int KIND, bool LDS_CELLS, bool TRACE>
+__global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
+  using Cell = typename CellOf<KIND>::type;
+  extern __shared__ __align__(16) unsigned char smem[];
+
+  // ---- stage the small tables in LDS ----
+  {
+    auto copy_words = [&](void* dst, const void* src, size_t bytes) {
+      unsigned long long* d = reinterpret_cast<unsigned long long*>(dst);
+      const unsigned long long* s = reinterpret_cast<const unsigned long long*>(src);
+      for (size_t i = threadIdx.x; i < bytes / 8; i += kBlock) d[i] = s[i];
+    };
+    if (LDS_CELLS) copy_words(smem + a.lds_cells_off, a.cells, (size_t)a.n_cells * sizeof(Cell));
+    copy_words(smem + a.lds_scat_off, a.scat_head, (size_t)a.n_scat * sizeof(ScatHead));
+    copy_words(smem + a.lds_seis_off, a.seis_scan, (size_t)a.n_seis * sizeof(SeisScan));
+    __syncthreads();
+  }
+  Tables<KIND> T;
+  T.cells = LDS_CELLS ? reinterpret_cast<const Cell*>(smem + a.lds_cells_off)
+                      : reinterpret_cast<const Cell*>(a.cells);
+  T.scat_head = reinterpret_cast<const ScatHead*>(smem + a.lds_scat_off);
+  T.seis_scan = reinterpret_cast<const SeisScan*>(smem + a.lds_seis_off);
+
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned long long lane_lt = (1ull << lane) - 1ull;
+
+  Phonon p;
+  Rng rng;
+  LaneStats st = {0, 0, 0, 0, 0, 0, 0};
+  uint32_t n_gen = 0, n_lost = 0, n_timeout = 0;
+  uint32_t inv[R3D_INV_NUM] = {0, 0, 0, 0, 0, 0, 0};
+  uint64_t my_id = 0;
+  uint32_t catch_at_start = 0;
+  bool alive = false;
+  unsigned long long w_next = 0, w_end = 0;  // wave-uniform: ids this wave still owns
+  bool drained = false;                      // wave-uniform: the global counter ran out
+
+  for (;;) {
+    // ---- refill dead lanes from the wave's id range ----
+    unsigned long long need = __ballot(!alive);
+    while (need != 0ull && !drained) {
+      if (w_next == w_end) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(a.next, (unsigned long long)kChunk);
+        base = __shfl(base, 0);
+        if (base >= a.n) {
+          drained = true;
+          break;
+        }
+        w_next = base;
+        w_end = (base + kChunk < a.n) ? base + kChunk : a.n;
+      }
+      const unsigned want = (unsigned)__popcll(need);
+      const unsigned long long avail = w_end - w_next;
+      const unsigned take = (avail < want) ? (unsigned)avail : want;
+      const unsigned rank = (unsigned)__popcll(need & lane_lt);
+      if (!alive && rank < take) {
+        my_id = a.first_id + w_next + rank;
+        rng_init(rng, a.seed, my_id);
+        spray(a, p, rng);
+        alive = true;
+        n_gen++;
+        if (TRACE) catch_at_start = st.n_catch;
+      }
+      w_next += take;
+      need = __ballot(!alive);
+    }
+    if (!__any(alive)) break;  // every lane idle and nothing left to hand out
+
+    // ---- one propagation iteration for every live lane ----
+    if (alive) {
+      int reason = 0;
+      const int fate = step<KIND>(a, T, p, rng, st, &reason);
+      if (fate != FATE_ALIVE) {
+        alive = false;
+        if (fate == FATE_LOST) n_lost++;
+        else if (fate == FATE_TIMEOUT) n_timeout++;
+        else {
+#pragma unroll
+          for (int r = 0; r < R3D_INV_NUM; r++) inv[r] += (r == reason);
+        }
+        if (TRACE) {
+          r3d_final* f = reinterpret_cast<r3d_final*>(a.finals) + (my_id - a.first_id);
+          f->time = p.t, f->path = p.path, f->amp = p.amp;
+          f->loc[0] = p.loc.x, f->loc[1] = p.loc.y, f->loc[2] = p.loc.z;
+          f->dir[0] = p.dir.x, f->dir[1] = p.dir.y, f->dir[2] = p.dir.z;
+          f->moves = p.moves;
+          f->fate = (uint8_t)fate;
+          f->type = (uint8_t)p.type;
+          uint32_t nc = st.n_catch - catch_at_start;
+          f->n_catch = (uint16_t)(nc > 65535u ? 65535u : nc);
+        }
+      }
+    }
+  }
+
+  // ---- flush the per-lane tallies: wave reduction, one atomic per counter ----
+  auto flush = [&](uint32_t v, int slot) {
+    unsigned long long s = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane == 0 && s) atomicAdd(a.scalars + slot, s);
+  };
+  flush(n_lost, 0);
+  flush(n_timeout, 1);
+  uint32_t n_inv = 0;
+#pragma unroll
+  for (int r = 0; r < R3D_INV_NUM; r++) n_inv += inv[r];
+  flush(n_inv, 2);
+#pragma unroll
+  for (int r = 0; r < R3D_INV_NUM; r++) flush(inv[r], 3 + r);
+  const int ev0 = 3 + R3D_INV_NUM;
+  flush(n_gen, ev0 + R3D_EV_GENERATED);
+  flush(st.iterations, ev0 + R3D_EV_ITERATIONS);
+  flush(st.scatter, ev0 + R3D_EV_SCATTER);
+  flush(st.collect, ev0 + R3D_EV_COLLECT);
+  flush(st.n_catch, ev0 + R3D_EV_CATCH);
+  flush(st.reflect, ev0 + R3D_EV_REFLECT);
+  flush(st.transfer, ev0 + R3D_EV_TRANSFER);
+  flush(st.rtsolve, ev0 + R3D_EV_RTSOLVE);
+}
+
+// ------------------------------------------------------------------- engine --
+thread_local std::string g_error;
+
+#define R3D_HIP_OK(call)                                                              \
+  do {                                                                                \
+    hipError_t err__ = (call);                                                        \
+    if (err__ != hipSuccess) {                                                        \
+      g_error = std::string(#call) + ": " + hipGetErrorString(err__);                 \
+      return fail_value;                                                              \
+    }                                                                                 \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t upload(const void* src, size_t n) {
+    bytes = n;
+    hipError_t e = hipMalloc(&p, n ? n : 8);
+    if (e != hipSuccess) return e;
+    if (n) e = hipMemcpy(p, src, n, hipMemcpyHostToDevice);
+    return e;
+  }
+  hipError_t alloc_zero(size_t n) {
+    bytes = n;
+    hipError_t e = hipMalloc(&p, n ? n : 8);
+    if (e != hipSuccess) return e;
+    return hipMemset(p, 0, n ? n : 8);
+  }
+};
+
+}  // namespace r3d
+
+using namespace r3d;
+
+struct r3d_engine {
+  int device = 0;
+  int kind = 0;
+  bool lds_cells = false;
+  int n_seis = 0;
+  uint32_t n_bins = 0;
+  KArgs args{};
+  size_t lds_bytes = 0;
+  int grid_blocks = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  std::vector<std::unique_ptr<DevBuf>> bufs;
+  DevBuf d_energy, d_counts, d_scalars, d_next;
+
+  DevBuf* keep(std::unique_ptr<DevBuf> b) {
+    bufs.push_back(std::move(b));
+    return bufs.back().get();
+  }
+  ~r3d_engine() {
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace {
+
+template <class T>
+const T* upload_vec(r3d_engine* e, const std::vector<T>& v, hipError_t* err) {
+  auto b = std::make_unique<DevBuf>();
+  hipError_t r = b->upload(v.data(), v.size() * sizeof(T));
+  if (r != hipSuccess) *err = r;
+  return reinterpret_cast<const T*>(e->keep(std::move(b))->p);
+}
+const double* upload_doubles(r3d_engine* e, const double* src, size_t n, hipError_t* err) {
+  auto b = std::make_unique<DevBuf>();
+  hipError_t r = b->upload(src, n * sizeof(double));
+  if (r != hipSuccess) *err = r;
+  return reinterpret_cast<const double*>(e->keep(std::move(b))->p);
+}
+
+template <int KIND, bool LDS_CELLS>
+hipError_t launch(r3d_engine* e, const KArgs& a, bool trace, hipStream_t s) {
+  if (trace)
+    hipLaunchKernelGGL((propagate_kernel<KIND, LDS_CELLS, true>), dim3(e->grid_blocks), dim3(kBlock),
+                       e->lds_bytes, s, a);
+  else
+    hipLaunchKernelGGL((propagate_kernel<KIND, LDS_CELLS, false>), dim3(e->grid_blocks), dim3(kBlock),
+                       e->lds_bytes, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_any(r3d_engine* e, const KArgs& a, bool trace, hipStream_t s) {
+  switch (e->kind) {
+    case R3D_CELL_CYLINDER:
+      return e->lds_cells ? launch<CELL_CYL, true>(e, a, trace, s) : launch<CELL_CYL, false>(e, a, trace, s);
+    case R3D_CELL_TETRA:
+      return e->lds_cells ? launch<CELL_TET, true>(e, a, trace, s) : launch<CELL_TET, false>(e, a, trace, s);
+    default:
+      return e->lds_cells ? launch<CELL_SPH, true>(e, a, trace, s) : launch<CELL_SPH, false>(e, a, trace, s);
+  }
+}
+
+template <int KIND, bool LDS_CELLS>
+hipError_t set_lds_attr(size_t bytes) {
+  hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_kernel<KIND, LDS_CELLS, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (r != hipSuccess) return r;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_kernel<KIND, LDS_CELLS, true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+bool check_model(const r3d_model_desc* m) {
+  if (!m) return g_error = "null model", false;
+  if (m->cell_kind < 0 || m->cell_kind > 2) return g_error = "unknown cell kind", false;
+  if (m->n_cells <= 0 || !m->cells) return g_error = "model has no cells", false;
+  if (m->n_scatterers <= 0 || !m->scatterers) return g_error = "model has no scatterers", false;
+  if (m->n_toa == 0 || !m->toa) return g_error = "model has no take-off angles", false;
+  if (m->params.n_bins == 0) return g_error = "zero time bins", false;
+  if (m->source.cell < 0 || m->source.cell >= m->n_cells) return g_error = "source cell out of range", false;
+  const int want_faces = m->cell_kind == R3D_CELL_CYLINDER ? 3 : m->cell_kind == R3D_CELL_TETRA ? 4 : 2;
+  for (int i = 0; i < m->n_cells; i++) {
+    const r3d_cell& c = m->cells[i];
+    if (c.n_faces != want_faces) return g_error = "cell face count does not match cell kind", false;
+    if (c.scatterer < 0 || c.scatterer >= m->n_scatterers) return g_error = "cell scatterer out of range", false;
+    for (int f = 0; f < c.n_faces; f++) {
+      const r3d_face& F = c.faces[f];
+      if ((F.flags & R3D_FACE_ADJOIN) && (F.neighbor < 0 || F.neighbor >= m->n_cells))
+        return g_error = "face neighbour out of range", false;
+    }
+  }
+  for (int s = 0; s < m->n_scatterers; s++)
+    for (int k = 0; k < 4; k++)
+      if (!m->scatterers[s].cdf[k] || !m->scatterers[s].spol) return g_error = "scatterer table missing", false;
+  for (int k = 0; k < 3; k++)
+    if (!m->source.cdf[k]) return g_error = "source table missing", false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* r3d_last_error(void) { return g_error.c_str(); }
+const char* r3d_version(void) { return "radiative3d_amd engine r1 (gfx950, fp64)"; }
+
+r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
+  r3d_engine* const fail_value = nullptr;
+  if (!check_model(m)) return nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    g_error = "no HIP device available: the engine has no CPU path";
+    return nullptr;
+  }
+  if (device < 0 || device >= ndev) {
+    g_error = "device index out of range";
+    return nullptr;
+  }
+  R3D_HIP_OK(hipSetDevice(device));
+  auto e = std::make_unique<r3d_engine>();
+  e->device = device;
+  e->kind = m->cell_kind;
+  e->n_seis = m->n_seismometers;
+  e->n_bins = m->params.n_bins;
+  KArgs& a = e->args;
+  PackedModel pm;
+  pack_model(*m, pm);
+  a = pm.args;
+  const size_t cell_bytes = pm.cell_bytes();
+  hipError_t err = hipSuccess;
+  // ---- move every table into HBM and point the launch arguments at it ----
+  switch (m->cell_kind) {
+    case R3D_CELL_CYLINDER: a.cells = upload_vec(e.get(), pm.cyl, &err); break;
+    case R3D_CELL_TETRA:
+      a.cells = upload_vec(e.get(), pm.tet, &err);
+      a.rho = upload_vec(e.get(), pm.rho, &err);
+      break;
+    default: a.cells = upload_vec(e.get(), pm.sph, &err);
+  }
+  for (int s = 0; s < m->n_scatterers; s++) {
+    for (int k = 0; k < 4; k++) pm.scat_ptrs[s].cdf[k] = upload_doubles(e.get(), m->scatterers[s].cdf[k], m->n_toa, &err);
+    pm.scat_ptrs[s].spol = upload_doubles(e.get(), m->scatterers[s].spol, m->n_toa, &err);
+  }
+  a.scat_head = upload_vec(e.get(), pm.scat_head, &err);
+  a.scat_ptrs = upload_vec(e.get(), pm.scat_ptrs, &err);
+  a.toa_xyz = upload_vec(e.get(), pm.toa_xyz, &err);
+  for (int k = 0; k < 3; k++) a.src_cdf[k] = upload_doubles(e.get(), m->source.cdf[k], m->n_toa, &err);
+  a.seis_scan = upload_vec(e.get(), pm.seis_scan, &err);
+  a.seis_hit = upload_vec(e.get(), pm.seis_hit, &err);
+  a.grid.start = upload_vec(e.get(), pm.grid_start, &err);
+  a.grid.items = upload_vec(e.get(), pm.grid_items, &err);
+  if (err != hipSuccess) {
+    g_error = std::string("uploading model tables: ") + hipGetErrorString(err);
+    return nullptr;
+  }
+
+  // ---- LDS carve-up and launch geometry ----
+  auto align16 = [](size_t x) { return (x + 15) & ~size_t(15); };
+  size_t off = 0;
+  e->lds_cells = cell_bytes <= 48 * 1024;
+  a.lds_cells_off = 0xFFFFFFFFu;
+  if (e->lds_cells) a.lds_cells_off = (uint32_t)off, off = align16(off + cell_bytes);
+  a.lds_scat_off = (uint32_t)off, off = align16(off + (size_t)m->n_scatterers * sizeof(ScatHead));
+  a.lds_seis_off = (uint32_t)off, off = align16(off + (size_t)std::max(1, m->n_seismometers) * sizeof(SeisScan));
+  e->lds_bytes = off;
+  if (e->lds_bytes > 160 * 1024) {
+    g_error = "model's scan tables exceed the 160 KB of LDS per CU";
+    return nullptr;
+  }
+  hipDeviceProp_t prop;
+  R3D_HIP_OK(hipGetDeviceProperties(&prop, device));
+  if (e->lds_bytes > 64 * 1024) {
+    hipError_t r;
+    switch (e->kind) {
+      case R3D_CELL_CYLINDER: r = e->lds_cells ? set_lds_attr<CELL_CYL, true>(e->lds_bytes) : set_lds_attr<CELL_CYL, false>(e->lds_bytes); break;
+      case R3D_CELL_TETRA: r = e->lds_cells ? set_lds_attr<CELL_TET, true>(e->lds_bytes) : set_lds_attr<CELL_TET, false>(e->lds_bytes); break;
+      default: r = e->lds_cells ? set_lds_attr<CELL_SPH, true>(e->lds_bytes) : set_lds_attr<CELL_SPH, false>(e->lds_bytes);
+    }
+    R3D_HIP_OK(r);
+  }
+  // persistent grid: as many workgroups per CU as LDS allows, up to 4
+  int per_cu = (int)std::min<size_t>(4, std::max<size_t>(1, (160 * 1024) / std::max<size_t>(e->lds_bytes, 1)));
+  e->grid_blocks = prop.multiProcessorCount * per_cu;
+
+  // ---- result scratch, work counter, stream, events ----
+  R3D_HIP_OK(e->d_energy.alloc_zero((size_t)std::max(1, e->n_seis) * e->n_bins * R3D_N_ENERGY * sizeof(double)));
+  R3D_HIP_OK(e->d_counts.alloc_zero((size_t)std::max(1, e->n_seis) * e->n_bins * R3D_N_COUNT * sizeof(uint64_t)));
+  R3D_HIP_OK(e->d_scalars.alloc_zero(R3D_N_SCALARS * sizeof(uint64_t)));
+  R3D_HIP_OK(e->d_next.alloc_zero(sizeof(unsigned long long)));
+  R3D_HIP_OK(hipStreamCreate(&e->stream));
+  R3D_HIP_OK(hipEventCreate(&e->ev0));
+  R3D_HIP_OK(hipEventCreate(&e->ev1));
+  return e.release();
+}
+
+void r3d_engine_destroy(r3d_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  delete e;
+}
+
+size_t r3d_energy_len(const r3d_engine* e) { return e ? (size_t)e->n_seis * e->n_bins * R3D_N_ENERGY : 0; }
+size_t r3d_counts_len(const r3d_engine* e) { return e ? (size_t)e->n_seis * e->n_bins * R3D_N_COUNT : 0; }
+
+int r3d_run_device(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, double* d_energy,
+                   uint64_t* d_counts, uint64_t* d_scalars, r3d_final* d_finals, void* stream) {
+  const int fail_value = 1;
+  if (!e) return g_error = "null engine", 1;
+  if (!d_energy || !d_counts || !d_scalars) return g_error = "null result buffer", 1;
+  R3D_HIP_OK(hipSetDevice(e->device));
+  hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : e->stream;
+  KArgs a = e->args;
+  a.n = n, a.first_id = first_id, a.seed = seed;
+  a.next = reinterpret_cast<unsigned long long*>(e->d_next.p);
+  a.energy = d_energy;
+  a.counts = reinterpret_cast<unsigned long long*>(d_counts);
+  a.scalars = reinterpret_cast<unsigned long long*>(d_scalars);
+  a.finals = d_finals;
+  R3D_HIP_OK(hipMemsetAsync(e->d_next.p, 0, sizeof(unsigned long long), s));
+  R3D_HIP_OK(hipEventRecord(e->ev0, s));
+  if (n > 0) R3D_HIP_OK(launch_any(e, a, d_finals != nullptr, s));
+  R3D_HIP_OK(hipEventRecord(e->ev1, s));
+  e->timed = true;
+  return 0;
+}
+
+static int run_host(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, r3d_result* out,
+                    r3d_final* finals) {
+  const int fail_value = 1;
+  if (!e) return g_error = "null engine", 1;
+  if (!out || !out->energy || !out->counts) return g_error = "null result", 1;
+  R3D_HIP_OK(hipSetDevice(e->device));
+  R3D_HIP_OK(hipMemsetAsync(e->d_energy.p, 0, e->d_energy.bytes, e->stream));
+  R3D_HIP_OK(hipMemsetAsync(e->d_counts.p, 0, e->d_counts.bytes, e->stream));
+  R3D_HIP_OK(hipMemsetAsync(e->d_scalars.p, 0, e->d_scalars.bytes, e->stream));
+  DevBuf d_finals;
+  if (finals) R3D_HIP_OK(d_finals.alloc_zero(n * sizeof(r3d_final)));
+  if (r3d_run_device(e, n, first_id, seed, reinterpret_cast<double*>(e->d_energy.p),
+                     reinterpret_cast<uint64_t*>(e->d_counts.p), reinterpret_cast<uint64_t*>(e->d_scalars.p),
+                     finals ? reinterpret_cast<r3d_final*>(d_finals.p) : nullptr, nullptr))
+    return 1;
+  R3D_HIP_OK(hipStreamSynchronize(e->stream));
+  const size_t ne = r3d_energy_len(e), nc = r3d_counts_len(e);
+  std::vector<double> he(ne);
+  std::vector<uint64_t> hc(nc);
+  uint64_t hs[R3D_N_SCALARS];
+  if (ne) R3D_HIP_OK(hipMemcpy(he.data(), e->d_energy.p, ne * sizeof(double), hipMemcpyDeviceToHost));
+  if (nc) R3D_HIP_OK(hipMemcpy(hc.data(), e->d_counts.p, nc * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  R3D_HIP_OK(hipMemcpy(hs, e->d_scalars.p, sizeof hs, hipMemcpyDeviceToHost));
+  if (finals) R3D_HIP_OK(hipMemcpy(finals, d_finals.p, n * sizeof(r3d_final), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < ne; i++) out->energy[i] += he[i];
+  for (size_t i = 0; i < nc; i++) out->counts[i] += hc[i];
+  out->n_lost += hs[0], out->n_timeout += hs[1], out->n_invalid += hs[2];
+  for (int r = 0; r < R3D_INV_NUM; r++) out->invalid_reasons[r] += hs[3 + r];
+  for (int k = 0; k < R3D_EV_NUM; k++) out->events[k] += hs[3 + R3D_INV_NUM + k];
+  return 0;
+}
+
+int r3d_run(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, r3d_result* out) {
+  return run_host(e, n, first_id, seed, out, nullptr);
+}
+
+int r3d_run_traced(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, r3d_result* out,
+                   r3d_final* finals) {
+  if (!finals) return g_error = "null finals", 1;
+  return run_host(e, n, first_id, seed, out, finals);
+}
+
+double r3d_last_kernel_ms(r3d_engine* e) {
+  if (!e || !e->timed) return -1.0;
+  if (hipEventSynchronize(e->ev1) != hipSuccess) return -1.0;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, e->ev0, e->ev1) != hipSuccess) return -1.0;
+  return (double)ms;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+// r3d_math.h -- fp64 vector / complex helpers for the traversal kernels.
+//
+// Directions are carried as unit vectors (the reference carries (theta, phi)
+// pairs and converts to xyz on every use, geom_r3.cpp:36-40 -- 9 % of its CPU
+// time per SURVEY.md); the spherical unit vectors theta^, phi^ that the
+// reference gets from trigonometry (geom_r3.cpp:85-126, :212-233) are formed
+// here algebraically from the direction cosines.
+#ifndef R3D_MATH_H_
+#define R3D_MATH_H_
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define R3D_HD __host__ __device__ __forceinline__
+#else
+#define R3D_HD inline
+#endif
+
+namespace r3d {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kPi90 = kPi * 0.5;
+constexpr double kPi360 = kPi * 2.0;
+
+R3D_HD double pos_inf() { return __builtin_inf(); }
+
+struct V3 {
+  double x, y, z;
+};
+R3D_HD V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+R3D_HD V3 v3(const double* a) { return V3{a[0], a[1], a[2]}; }
+R3D_HD V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+R3D_HD V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+R3D_HD V3 operator*(double s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+R3D_HD V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+R3D_HD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+R3D_HD V3 cross(V3 a, V3 b) {
+  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+R3D_HD double mag2(V3 a) { return dot(a, a); }
+R3D_HD double mag(V3 a) { return sqrt(mag2(a)); }
+R3D_HD bool is_zero(V3 a) { return a.x == 0 && a.y == 0 && a.z == 0; }
+R3D_HD V3 unit(V3 a) {
+  double s = 1.0 / mag(a);
+  return s * a;
+}
+R3D_HD V3 unit_else(V3 a, V3 fallback) {  // reference geom_r3.hpp:127-132
+  double m = mag(a);
+  if (m == 0) return fallback;
+  return (1.0 / m) * a;
+}
+
+// The reference stores a direction as theta = acos(z), phi = atan2(y, x) and
+// regenerates (sin th cos ph, sin th sin ph, cos th) from them.  This is that
+// round trip without the trigonometry: z is kept, the horizontal part is
+// rescaled to sqrt(1 - z^2).  `v` must already be (very nearly) unit length.
+R3D_HD V3 through_angles(V3 v) {
+  double h2 = v.x * v.x + v.y * v.y;
+  double st = sqrt(fmax(0.0, 1.0 - v.z * v.z));
+  if (h2 == 0) return v3(st, 0.0, v.z);  // atan2(0,0) = 0
+  double s = st / sqrt(h2);
+  return v3(s * v.x, s * v.y, v.z);
+}
+
+// theta^ and phi^ at unit direction d (reference OrthoAxes E1, E2,
+// geom_r3.cpp:222-224).
+R3D_HD void sph_basis(V3 d, V3& th_hat, V3& ph_hat) {
+  double st = sqrt(d.x * d.x + d.y * d.y);
+  double cp = 1.0, sp = 0.0;
+  if (st != 0) cp = d.x / st, sp = d.y / st;
+  th_hat = v3(d.z * cp, d.z * sp, -st);
+  ph_hat = v3(-sp, cp, 0.0);
+}
+
+// Unit vector perpendicular to `self`, in the plane of self and other, on
+// other's side (reference geom_r3.cpp:146-171).
+R3D_HD V3 in_plane_unit_perp(V3 self, V3 other) {
+  V3 mp = cross(self, other);
+  if (is_zero(mp)) {
+    mp = cross(self, v3(1, 0, 0));
+    if (is_zero(mp)) mp = cross(self, v3(0, 1, 0));
+  }
+  mp = unit(mp);
+  return unit(cross(mp, self));
+}
+
+// ---- complex numbers (the reference's Complex = std::complex<Real>,
+//      complex.hpp:39-56) ---------------------------------------------------
+struct Cx {
+  double re, im;
+};
+R3D_HD Cx cx(double re, double im = 0.0) { return Cx{re, im}; }
+R3D_HD Cx operator+(Cx a, Cx b) { return cx(a.re + b.re, a.im + b.im); }
+R3D_HD Cx operator-(Cx a, Cx b) { return cx(a.re - b.re, a.im - b.im); }
+R3D_HD Cx operator-(Cx a) { return cx(-a.re, -a.im); }
+R3D_HD Cx operator*(Cx a, Cx b) { return cx(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+R3D_HD Cx operator*(double s, Cx a) { return cx(s * a.re, s * a.im); }
+R3D_HD Cx operator*(Cx a, double s) { return cx(s * a.re, s * a.im); }
+R3D_HD Cx operator/(Cx a, double s) { return cx(a.re / s, a.im / s); }
+R3D_HD Cx operator+(double s, Cx a) { return cx(s + a.re, a.im); }
+R3D_HD Cx operator-(double s, Cx a) { return cx(s - a.re, -a.im); }
+R3D_HD Cx operator/(Cx a, Cx b) {
+  double den = b.re * b.re + b.im * b.im;
+  return cx((a.re * b.re + a.im * b.im) / den, (a.im * b.re - a.re * b.im) / den);
+}
+R3D_HD double norm(Cx a) { return a.re * a.re + a.im * a.im; }  // squared modulus
+// sqrt of the real number s as a complex number (principal branch):
+// post-critical cosines come out purely imaginary (rtcoef.cpp:312-318).
+R3D_HD Cx sqrt_real(double s) { return s >= 0 ? cx(sqrt(s), 0.0) : cx(0.0, sqrt(-s)); }
+
+}  // namespace r3d
+#endif

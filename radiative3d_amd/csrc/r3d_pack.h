@@ -1,0 +1,255 @@
+// r3d_pack.h -- host-side repacking of the C-ABI model (include/r3d.h) into
+// the engine's own table layout (r3d_tables.h).  Pure C++ (no HIP): the
+// engine uploads the packed vectors to HBM; the test-only CPU emulation of the
+// kernel (tests/emul) points the kernel arguments at them directly.
+#ifndef R3D_PACK_H_
+#define R3D_PACK_H_
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/r3d.h"
+#include "r3d_tables.h"
+
+namespace r3d {
+
+struct PackedModel {
+  std::vector<CellCyl> cyl;
+  std::vector<CellTet> tet;
+  std::vector<CellSph> sph;
+  std::vector<RhoLin> rho;
+  std::vector<ScatHead> scat_head;
+  std::vector<ScatPtrs> scat_ptrs;   // filled with the HOST pointers of the model
+  std::vector<double> toa_xyz;
+  std::vector<SeisScan> seis_scan;
+  std::vector<SeisHit> seis_hit;
+  std::vector<uint32_t> grid_start, grid_items;
+  KArgs args;                        // pointers refer to the vectors above / the model
+  size_t cell_bytes() const {
+    return cyl.size() * sizeof(CellCyl) + tet.size() * sizeof(CellTet) + sph.size() * sizeof(CellSph);
+  }
+};
+
+inline uint32_t pack_flags(const r3d_cell& c) {
+  uint32_t f = 0;
+  for (int i = 0; i < c.n_faces && i < 4; i++) f |= (c.faces[i].flags & 0xFFu) << (8 * i);
+  return f;
+}
+inline double dot3(const double a[3], const double b[3]) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+
+// Uniform hash over the seismometers' gather spheres.  Cell edge ~ twice the
+// median outer radius, grown until the grid has at most ~2M cells.  Insertion
+// is conservative (bounding box of the sphere plus a rounding margin), so the
+// candidates of a cell are a superset of the seismometers that can catch a
+// phonon arriving anywhere inside it.
+inline void build_seis_grid(const r3d_model_desc& m, SeisGrid& g, std::vector<uint32_t>& start,
+                            std::vector<uint32_t>& items) {
+  const int n = m.n_seismometers;
+  g.n_cells = 0;
+  g.dim[0] = g.dim[1] = g.dim[2] = 0;
+  g.inv_h = 0;
+  g.origin[0] = g.origin[1] = g.origin[2] = 0;
+  start.assign(2, 0);
+  items.assign(1, 0);
+  if (n == 0) return;
+  std::vector<double> rad(n);
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int s = 0; s < n; s++) {
+    const r3d_seismometer& S = m.seismometers[s];
+    rad[s] = std::max(S.r_out[0], S.r_out[1]);
+    for (int k = 0; k < 3; k++) {
+      lo[k] = std::min(lo[k], S.loc[k] - rad[s]);
+      hi[k] = std::max(hi[k], S.loc[k] + rad[s]);
+    }
+  }
+  std::vector<double> sorted = rad;
+  std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+  double h = std::max(2.0 * sorted[n / 2], 1e-6);
+  int d[3];
+  auto dims_for = [&](double hh) {
+    double cells = 1;
+    for (int k = 0; k < 3; k++) {
+      d[k] = std::max(1, (int)std::ceil((hi[k] - lo[k]) / hh) + 1);
+      cells *= d[k];
+    }
+    return cells;
+  };
+  while (dims_for(h) > 2.0e6) h *= 1.5;
+  for (int k = 0; k < 3; k++) g.origin[k] = lo[k], g.dim[k] = d[k];
+  g.inv_h = 1.0 / h;
+  g.n_cells = d[0] * d[1] * d[2];
+  std::vector<std::vector<uint32_t>> buckets(g.n_cells);
+  for (int s = 0; s < n; s++) {
+    const r3d_seismometer& S = m.seismometers[s];
+    int a0[3], a1[3];
+    for (int k = 0; k < 3; k++) {
+      double r = rad[s] * (1 + 1e-9) + 1e-9 * h;
+      a0[k] = std::max(0, (int)std::floor((S.loc[k] - r - lo[k]) * g.inv_h) - 0);
+      a1[k] = std::min(d[k] - 1, (int)std::floor((S.loc[k] + r - lo[k]) * g.inv_h));
+    }
+    for (int z = a0[2]; z <= a1[2]; z++)
+      for (int y = a0[1]; y <= a1[1]; y++)
+        for (int x = a0[0]; x <= a1[0]; x++)
+          buckets[((size_t)z * d[1] + y) * d[0] + x].push_back((uint32_t)s);
+  }
+  start.assign(g.n_cells + 1, 0);
+  for (int c = 0; c < g.n_cells; c++) start[c + 1] = start[c] + (uint32_t)buckets[c].size();
+  items.clear();
+  items.reserve(start.back() + 1);
+  for (auto& b : buckets) items.insert(items.end(), b.begin(), b.end());
+  if (items.empty()) items.push_back(0);
+}
+
+inline void pack_model(const r3d_model_desc& m, PackedModel& pm) {
+  KArgs& a = pm.args;
+  std::memset(&a, 0, sizeof a);
+  const r3d_params& par = m.params;
+  const double kPiF = -3.14159265358979323846 * par.frequency;
+
+  // ---- cells ----
+  if (m.cell_kind == R3D_CELL_CYLINDER) {
+    pm.cyl.resize(m.n_cells);
+    for (int i = 0; i < m.n_cells; i++) {
+      const r3d_cell& c = m.cells[i];
+      CellCyl& d = pm.cyl[i];
+      std::memset(&d, 0, sizeof d);
+      for (int t = 0; t < 2; t++) d.v[t] = c.vel_c[t], d.att[t] = kPiF / c.q[t];
+      d.rho = c.rho_c;
+      for (int f = 0; f < 2; f++) {
+        for (int k = 0; k < 3; k++) d.n[f][k] = c.faces[f].normal[k];
+        d.d[f] = dot3(c.faces[f].normal, c.faces[f].point);
+        d.nbr[f] = (c.faces[f].flags & R3D_FACE_ADJOIN) ? c.faces[f].neighbor : -1;
+      }
+      d.flags = pack_flags(c);
+      d.scat = c.scatterer;
+    }
+    a.cyl_radius2 = m.cells[0].faces[2].radius * m.cells[0].faces[2].radius;
+    a.cells = pm.cyl.data();
+  } else if (m.cell_kind == R3D_CELL_TETRA) {
+    pm.tet.resize(m.n_cells);
+    pm.rho.resize(m.n_cells);
+    for (int i = 0; i < m.n_cells; i++) {
+      const r3d_cell& c = m.cells[i];
+      CellTet& d = pm.tet[i];
+      std::memset(&d, 0, sizeof d);
+      for (int t = 0; t < 2; t++) {
+        for (int k = 0; k < 3; k++) d.g[t][k] = c.vel_grad[t][k];
+        d.v0[t] = c.vel_c[t];
+        d.inv_gmag[t] = 1.0 / std::sqrt(dot3(c.vel_grad[t], c.vel_grad[t]));
+        d.att[t] = kPiF / c.q[t];
+      }
+      for (int f = 0; f < 4; f++) {
+        for (int k = 0; k < 3; k++) d.n[f][k] = c.faces[f].normal[k];
+        d.d[f] = dot3(c.faces[f].normal, c.faces[f].point);
+        d.nbr[f] = (c.faces[f].flags & R3D_FACE_ADJOIN) ? c.faces[f].neighbor : -1;
+      }
+      d.flags = pack_flags(c);
+      d.scat = c.scatterer;
+      for (int k = 0; k < 3; k++) pm.rho[i].g[k] = c.rho_grad[k];
+      pm.rho[i].c = c.rho_c;
+    }
+    a.cells = pm.tet.data();
+    a.rho = pm.rho.data();
+  } else {
+    pm.sph.resize(m.n_cells);
+    for (int i = 0; i < m.n_cells; i++) {
+      const r3d_cell& c = m.cells[i];
+      CellSph& d = pm.sph[i];
+      std::memset(&d, 0, sizeof d);
+      for (int t = 0; t < 2; t++) {
+        d.a[t] = c.vel_a[t], d.c[t] = c.vel_c[t], d.zero_rad2[t] = c.zero_rad2[t];
+        d.att[t] = kPiF / c.q[t];
+      }
+      d.rho_a = c.rho_a, d.rho_c = c.rho_c;
+      for (int f = 0; f < 2; f++) {
+        d.radius[f] = c.faces[f].radius;
+        d.nbr[f] = (c.faces[f].flags & R3D_FACE_ADJOIN) ? c.faces[f].neighbor : -1;
+      }
+      d.flags = pack_flags(c);
+      d.scat = c.scatterer;
+    }
+    a.cells = pm.sph.data();
+  }
+  a.n_cells = m.n_cells;
+
+  // ---- scatterers ----
+  pm.scat_head.resize(m.n_scatterers);
+  pm.scat_ptrs.resize(m.n_scatterers);
+  for (int s = 0; s < m.n_scatterers; s++) {
+    const r3d_scatterer& S = m.scatterers[s];
+    for (int t = 0; t < 2; t++) {
+      pm.scat_head[s].mfp[t] = S.mfp[t];
+      for (int k = 0; k < 4; k++) pm.scat_head[s].whole[t][k] = S.whole_cdf[t][k];
+    }
+    for (int k = 0; k < 4; k++) pm.scat_ptrs[s].cdf[k] = S.cdf[k];
+    pm.scat_ptrs[s].spol = S.spol;
+  }
+  a.scat_head = pm.scat_head.data();
+  a.scat_ptrs = pm.scat_ptrs.data();
+  a.n_scat = m.n_scatterers;
+
+  // ---- take-off directions as unit vectors; theta nudged away from the poles
+  //      as Phonon::nudge_if_singular does (phonons.hpp:335-344) ----
+  pm.toa_xyz.resize(m.n_toa * 3);
+  for (uint64_t k = 0; k < m.n_toa; k++) {
+    double th = m.toa[2 * k], ph = m.toa[2 * k + 1];
+    if (th < par.min_theta) th = par.min_theta;
+    if (th > par.max_theta) th = par.max_theta;
+    pm.toa_xyz[3 * k] = std::sin(th) * std::cos(ph);
+    pm.toa_xyz[3 * k + 1] = std::sin(th) * std::sin(ph);
+    pm.toa_xyz[3 * k + 2] = std::cos(th);
+  }
+  a.toa_xyz = pm.toa_xyz.data();
+  a.n_toa = m.n_toa;
+  a.nodeflect_dir[0] = std::sin(par.min_theta);
+  a.nodeflect_dir[1] = 0.0;
+  a.nodeflect_dir[2] = std::cos(par.min_theta);
+
+  // ---- source ----
+  for (int k = 0; k < 3; k++) {
+    a.src_cdf[k] = m.source.cdf[k];
+    a.src_whole[k] = m.source.whole_cdf[k];
+    a.src_loc[k] = m.source.loc[k];
+    a.earth_center[k] = par.earth_center[k];
+  }
+  a.src_cell = m.source.cell;
+
+  // ---- seismometers ----
+  const int ns = std::max(1, m.n_seismometers);
+  pm.seis_scan.assign(ns, SeisScan{});
+  pm.seis_hit.assign(ns, SeisHit{});
+  for (int s = 0; s < m.n_seismometers; s++) {
+    const r3d_seismometer& S = m.seismometers[s];
+    for (int k = 0; k < 3; k++) {
+      pm.seis_scan[s].loc[k] = S.loc[k];
+      for (int j = 0; j < 3; j++) pm.seis_hit[s].axes[k][j] = S.axes[k][j];
+    }
+    for (int t = 0; t < 2; t++) {
+      pm.seis_scan[s].r_in[t] = S.r_in[t], pm.seis_scan[s].r_out[t] = S.r_out[t];
+      pm.seis_hit[s].inv_norm[t] = 1.0 / (par.time_per_bin * S.area[t]);
+    }
+  }
+  a.seis_scan = pm.seis_scan.data();
+  a.seis_hit = pm.seis_hit.data();
+  a.n_seis = m.n_seismometers;
+  build_seis_grid(m, a.grid, pm.grid_start, pm.grid_items);
+  a.grid.start = pm.grid_start.data();
+  a.grid.items = pm.grid_items.data();
+
+  // ---- scalars ----
+  a.n_bins = par.n_bins;
+  a.no_deflect = par.no_deflect;
+  a.ttl = par.ttl;
+  a.time_per_bin = par.time_per_bin;
+  a.inv_time_per_bin = 1.0 / par.time_per_bin;
+  a.slow_concern = par.slow_concern;
+  a.loop_concern = par.loop_concern;
+  a.lds_cells_off = 0xFFFFFFFFu;
+}
+
+}  // namespace r3d
+#endif

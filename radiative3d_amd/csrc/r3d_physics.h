@@ -1,0 +1,538 @@
+// r3d_physics.h -- per-history physics of the traversal kernel, one phonon per
+// work-item.  Everything here is straight-line scalar fp64 code on registers
+// plus table reads; wave-level concerns (refill, counters, LDS staging) live
+// in r3d_engine.hip.  Functions are __host__ __device__ so that a test-only
+// host build (tests/emul) can single-step the same code on a CPU.
+//
+// What is computed follows the reference function by function (cited); how it
+// is computed is chosen for the GPU:
+//   * direction = unit vector, polarisation = angle about it; theta^/phi^ by
+//     algebra, not trigonometry (r3d_math.h);
+//   * a boundary search returns only (arc length, face); the single "advance
+//     by length" that follows serves both the boundary and the scatter branch,
+//     so all lanes of a wave run it together (the reference advances inside
+//     GetPathToBoundary and again on scatter, media.cpp:562-565, phonons.cpp:608);
+//   * tetra arcs: the position on the arc is carried as (sin a, cos a), the
+//     travel time uses  ln|tan(a/2+pi/4)| = atanh(sin a)  so one log replaces
+//     two log(tan()) pairs (media.cpp:487-488);
+//   * plane faces are stored as (n, n.p).
+#ifndef R3D_PHYSICS_H_
+#define R3D_PHYSICS_H_
+
+#include "r3d_math.h"
+#include "r3d_rng.h"
+#include "r3d_tables.h"
+
+namespace r3d {
+
+enum { RAY_P = 0, RAY_S = 1 };
+enum { CELL_CYL = 0, CELL_TET = 1, CELL_SPH = 2 };
+enum { FATE_ALIVE = 0, FATE_LOST = 1, FATE_TIMEOUT = 2, FATE_INVALID = 3 };
+
+struct Phonon {            // reference phonons.hpp:69-126
+  double t, path, recent, amp;
+  V3 loc, dir;
+  double pol;
+  int32_t type, cell;
+  uint32_t moves;
+};
+
+struct Exit {              // where the current ray leaves the current cell
+  double len;
+  int face;
+};
+
+R3D_HD uint32_t face_flags(uint32_t packed, int f) { return (packed >> (8 * f)) & 0xFFu; }
+
+// Particle-motion direction (reference Phonon::DirectionOfMotion,
+// phonons.cpp:201-211): along the ray for P, else the S1 axis of the
+// (theta, phi, pol) frame.
+R3D_HD V3 direction_of_motion(const Phonon& p) {
+  if (p.type == RAY_P) return p.dir;
+  V3 th, ph;
+  sph_basis(p.dir, th, ph);
+  double s, c;
+  sincos(p.pol, &s, &c);
+  return c * th + s * ph;
+}
+// Polarisation angle of particle motion `pdom` about direction d
+// (phonons.cpp:389-391, :462-465).
+R3D_HD double pol_angle(V3 pdom, V3 d) {
+  V3 th, ph;
+  sph_basis(d, th, ph);
+  return atan2(dot(pdom, ph), dot(pdom, th));
+}
+
+// ===================================================================== CYL ==
+R3D_HD double plane_exit(const double n[3], double d, V3 loc, V3 dir) {
+  // reference PlaneFace::LinearRayDistToExit, media_cellface.cpp:262-324
+  double d_sh = d - (n[0] * loc.x + n[1] * loc.y + n[2] * loc.z);
+  double d_fact = n[0] * dir.x + n[1] * dir.y + n[2] * dir.z;
+  if (d_fact < 0) return pos_inf();
+  if (d_fact == 0) return d_sh < 0 ? -pos_inf() : pos_inf();
+  return d_sh / d_fact;
+}
+R3D_HD double cylwall_exit(double rad2, V3 loc, V3 dir) {
+  // reference CylinderFace::LinearRayDistToExit, media_cellface.cpp:531-562
+  double A = dir.x * dir.x + dir.y * dir.y;
+  double C = loc.x * loc.x + loc.y * loc.y - rad2;
+  if (A == 0) return C <= 0 ? pos_inf() : -pos_inf();
+  double B = 2 * (loc.x * dir.x + loc.y * dir.y);
+  double urad = B * B - 4 * A * C;
+  if (urad < 0) return -pos_inf();
+  return (sqrt(urad) - B) / (2 * A);
+}
+// reference RCUCylinder::GetPathToBoundary, media.cpp:236-330.  Face ids:
+// 0 top, 1 bottom, 2 lateral wall (phonon is lost there).
+R3D_HD Exit cyl_exit(const CellCyl& c, double wall_rad2, const Phonon& p) {
+  double dl = cylwall_exit(wall_rad2, p.loc, p.dir);
+  double dt = plane_exit(c.n[0], c.d[0], p.loc, p.dir);
+  double db = plane_exit(c.n[1], c.d[1], p.loc, p.dir);
+  if (dl < 0) dl = 0;
+  if (dt < 0) dt = 0;
+  if (db < 0) db = 0;
+  Exit e{dl, 2};
+  if (dt < e.len) e.len = dt, e.face = 0;
+  if (db < e.len) e.len = db, e.face = 1;
+  return e;
+}
+// reference RCUCylinder::AdvanceLength + Phonon::Move, media.cpp:208-222,
+// phonons.cpp:62-70
+R3D_HD void cyl_advance(const CellCyl& c, Phonon& p, double len) {
+  double time = len / c.v[p.type];
+  p.path += len, p.t += time, p.recent += time;
+  p.loc = p.loc + len * p.dir;
+  p.amp *= exp(c.att[p.type] * time);
+  p.moves += 1;
+}
+
+// ===================================================================== TET ==
+// Frame in which the ray through a linear-velocity cell is a circle about the
+// origin of the (x,z) plane (reference CoordinateTransformation,
+// media.hpp:560-587): rows v1,v2,v3; `trans` is the arc centre in the rotated
+// frame; the phonon sits at angle a0 measured from +z towards +x.
+struct TetArc {
+  V3 v1, v2, v3, trans;
+  double R, a0, s0, c0;   // radius, start angle and its sine / cosine
+};
+R3D_HD TetArc tet_arc(const CellTet& c, const Phonon& p) {
+  TetArc A;
+  const int t = p.type;
+  V3 g = v3(c.g[t]);
+  double vel = dot(p.loc, g) + c.v0[t];
+  V3 w2 = cross(g, p.dir), w1 = cross(w2, g);
+  A.v1 = unit(w1), A.v2 = unit(w2), A.v3 = c.inv_gmag[t] * g;
+  double txp = dot(p.dir, A.v1), tzp = dot(p.dir, A.v3);
+  A.R = 1.0 / ((txp / vel) * mag(g));
+  V3 x0 = v3(dot(A.v1, p.loc), dot(A.v2, p.loc), dot(A.v3, p.loc));
+  A.trans = v3(x0.x + A.R * tzp, x0.y, x0.z - A.R * txp);
+  double px = x0.x - A.trans.x, pz = x0.z - A.trans.z;  // phonon in the centred frame
+  A.a0 = atan2(px, pz);
+  double h = 1.0 / sqrt(px * px + pz * pz);
+  A.s0 = px * h, A.c0 = pz * h;
+  return A;
+}
+// Entry / exit / bisector angles of one plane against the arc circle
+// (reference PlaneFace::GetCircArcDistToFace, media_cellface.cpp:333-426).
+struct Gcad {
+  double entry, exit, half;
+  bool continuous;
+};
+R3D_HD Gcad tet_face_arc(const double n[3], double dplane, const TetArc& A) {
+  const double inf = pos_inf();
+  V3 nn = v3(n);
+  V3 rn = v3(dot(nn, A.v1), dot(nn, A.v2), dot(nn, A.v3));
+  double rho = sqrt(rn.x * rn.x + rn.z * rn.z);
+  double D = (dplane - dot(rn, A.trans)) / rho;   // centre-to-trace distance along the in-plane normal
+  double ir = 1.0 / rho;
+  double bis = atan2(rn.x * ir, rn.z * ir);
+  double en = 0, ex = 0;
+  bool cont = true;
+  const double ratio = D / A.R;
+  if (ratio < 1 && ratio > -1) {
+    double q = acos(ratio);
+    if (bis > -kPi90 && bis < kPi90) {
+      en = bis + q, ex = bis - q, cont = false;
+    } else if (bis <= -kPi90) {
+      en = bis + q, ex = bis - q + kPi360;
+    } else if (bis >= kPi90) {
+      en = bis + q - kPi360, ex = bis - q;
+    } else {
+      en = ex = bis;  // NaN bisector: the reference exit(1)s here; let it propagate
+    }
+  }
+  if (bis >= kPi90 || bis <= -kPi90) bis = inf;
+  if (en >= kPi90) en = inf;
+  if (en <= -kPi90) en = -inf;
+  if (ex >= kPi90) ex = inf;
+  if (ex <= -kPi90) ex = -inf;
+  if (ratio >= 1) en = -inf, ex = inf;
+  if (ratio <= -1) en = inf, ex = -inf, bis = -inf, cont = false;
+  return Gcad{en, ex, bis, cont};
+}
+R3D_HD bool gcad_inside(const Gcad& g, double th) {  // media_cellface.cpp:767-782
+  const double slack = 0.0000000001;
+  if (g.continuous) return th <= g.exit && th >= (g.entry - slack);
+  return (th >= -kPi90 && th <= g.exit) || (th >= (g.entry - slack) && th <= kPi90);
+}
+// reference Tetra::GetPathToBoundary, media.cpp:518-567 (search part)
+R3D_HD Exit tet_exit(const CellTet& c, const TetArc& A) {
+  Gcad rv[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) rv[i] = tet_face_arc(c.n[i], c.d[i], A);
+  Exit e{pos_inf(), 0};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    double x = rv[i].exit;
+    bool proper = gcad_inside(rv[(i + 1) & 3], x) && gcad_inside(rv[(i + 2) & 3], x) &&
+                  gcad_inside(rv[(i + 3) & 3], x);
+    if (proper) {
+      double nl = (x - A.a0) * A.R;
+      if (nl < 0 && (A.a0 > rv[i].half)) nl = e.len;  // dismissed exit
+      if (nl < e.len) e.len = nl, e.face = i;
+    }
+  }
+  return e;
+}
+// reference Tetra::AdvanceLength (media.cpp:442-499) + Phonon::Move
+R3D_HD void tet_advance(const CellTet& c, const TetArc& A, Phonon& p, double len) {
+  const int t = p.type;
+  double a1 = A.a0 + len / A.R;
+  double s1, c1;
+  sincos(a1, &s1, &c1);
+  V3 q = v3(A.R * s1 + A.trans.x, A.trans.y, A.R * c1 + A.trans.z);  // new position, rotated frame
+  V3 nl = q.x * A.v1 + q.y * A.v2 + q.z * A.v3;                       // back-rotate (S^T)
+  V3 nd = c1 * A.v1 + (-s1) * A.v3;                                   // tangent (cos a, 0, -sin a)
+  // time = (ln|tan(a1/2+pi/4)| - ln|tan(a0/2+pi/4)|) / |g|,  ln|tan(a/2+pi/4)| = atanh(sin a)
+  double time = 0.5 * c.inv_gmag[t] * log(((1.0 + s1) * (1.0 - A.s0)) / ((1.0 - s1) * (1.0 + A.s0)));
+  p.path += len, p.t += time, p.recent += time;
+  p.loc = nl;
+  p.dir = through_angles(unit(nd));
+  p.amp *= exp(c.att[t] * time);
+  p.moves += 1;
+}
+
+// ===================================================================== SPH ==
+R3D_HD double sph_linear_exit(double radius, V3 loc, V3 dir) {
+  // reference SphereFace::LinearRayDistToExit, media_cellface.cpp:664-684
+  bool outward = radius > 0;
+  double midpt = -dot(loc, dir);
+  double urad = radius * radius + midpt * midpt - mag2(loc);
+  if (urad <= 0) return outward ? -pos_inf() : pos_inf();
+  double sq = sqrt(urad);
+  if (outward) return midpt + sq;
+  if (midpt <= 0) return pos_inf();
+  return midpt - sq;
+}
+// Ray arc in a v = a r^2 + c shell (reference RayArcAttributes +
+// cache_RD2_precompute, raypath.hpp:31-113; SphereShell::GetRayArc_RD2,
+// media.cpp:795-861).
+struct SphArc {
+  double radius, rad2;
+  V3 center, u1, u3;
+  double S2, TwoSQ, CotZetaBy2, timeCoef;
+  double a0;       // angle of the current location from the arc bottom
+  bool straight;   // a == 0: straight rays
+};
+R3D_HD V3 down_at(const double ec[3], V3 loc) {  // ECS.GetDown, ecs.cpp:147-167
+  return -unit_else(loc - v3(ec), v3(0, 1, 0));
+}
+R3D_HD SphArc sph_arc(const CellSph& c, const double ec[3], const Phonon& p) {
+  SphArc A;
+  const int t = p.type;
+  A.straight = (c.a[t] == 0);
+  if (A.straight) {
+    A.radius = pos_inf(), A.rad2 = pos_inf(), A.S2 = 0, A.TwoSQ = 0, A.CotZetaBy2 = 0;
+    A.timeCoef = 0, A.a0 = 0, A.center = v3(0, 0, 0), A.u1 = p.dir, A.u3 = v3(0, 0, 0);
+    return A;
+  }
+  V3 w3 = down_at(ec, p.loc);
+  V3 w2 = unit_else(cross(w3, p.dir), v3(0, 0, 0));
+  V3 w1 = cross(w2, w3);
+  double sini = dot(w1, p.dir);
+  if (sini > 1.0) sini = 1.0;
+  double cosi = dot(w3, p.dir);
+  double r2 = mag2(p.loc);
+  const double G = sini * sqrt(r2) / (c.c[t] + c.a[t] * r2);
+  const double TwoGA = 2. * G * c.a[t];
+  const double urad = 1. - (2. * TwoGA * G * c.c[t]);
+  double bottom = (urad > 1) ? (1. - sqrt(urad)) / TwoGA : 0;
+  A.radius = (c.zero_rad2[t] / bottom - bottom) / 2.0;
+  A.rad2 = A.radius * A.radius;
+  A.center = p.loc + ((A.radius * cosi) * w1 + (-A.radius * sini) * w3);
+  A.u3 = down_at(ec, A.center);
+  A.u1 = cross(w2, A.u3);
+  if (urad <= 1) {  // straight up or down
+    A.center = v3(0, 0, 0);
+    A.u3 = v3(0, 0, 0);
+    A.u1 = p.dir;
+  }
+  A.S2 = mag2(A.center);
+  double S = sqrt(A.S2);
+  A.TwoSQ = 2 * S * A.radius;
+  double cz = (A.S2 + A.radius * A.radius - c.zero_rad2[t]) / A.TwoSQ;
+  double sz = sqrt(1 - cz * cz);
+  A.CotZetaBy2 = (1 + cz) / sz;
+  A.timeCoef = -1 / (c.a[t] * S * sz);
+  V3 cl = p.loc - A.center;
+  A.a0 = atan2(dot(A.u1, cl), dot(A.u3, cl));
+  return A;
+}
+R3D_HD double sph_arc_exit(double radius, const SphArc& A, const Phonon& p) {
+  // reference SphereFace::CircularArcDistToExit, media_cellface.cpp:717-748
+  if (A.S2 == 0) return sph_linear_exit(radius, p.loc, p.dir);
+  bool outward = radius > 0;
+  double cosq = (A.S2 + A.rad2 - radius * radius) / A.TwoSQ;
+  if (cosq > 1.0) return outward ? -pos_inf() : pos_inf();
+  double b2e = acos(cosq);
+  if (outward) return (b2e - A.a0) * A.radius;
+  if (A.a0 >= 0) return pos_inf();
+  return (-b2e - A.a0) * A.radius;
+}
+// reference SphereShell::GetPathToBoundary, media.cpp:668-757 (search part)
+R3D_HD Exit sph_exit(const CellSph& c, const SphArc& A, const Phonon& p) {
+  double dt, db;
+  if (A.straight) {
+    dt = sph_linear_exit(c.radius[0], p.loc, p.dir);
+    db = sph_linear_exit(c.radius[1], p.loc, p.dir);
+  } else {
+    dt = sph_arc_exit(c.radius[0], A, p);
+    db = sph_arc_exit(c.radius[1], A, p);
+  }
+  Exit e;
+  e.face = (dt < db) ? 0 : 1;
+  e.len = e.face == 0 ? dt : db;
+  if (e.len < 0) e.len = 0;
+  return e;
+}
+// reference SphereShell::AdvanceLength_* (media.cpp:877-957) + Phonon::Move
+R3D_HD void sph_advance(const CellSph& c, const SphArc& A, Phonon& p, double len) {
+  const int t = p.type;
+  double time, att_time;
+  if (A.straight || A.radius == pos_inf()) {
+    V3 nl = p.loc + len * p.dir;
+    time = att_time = len / c.c[t];
+    if (!A.straight) {  // vertical ray in a graded shell: analytic time, straight-line attenuation
+      double r0 = mag(p.loc), r1 = mag(nl);
+      double sqnac = sqrt(-c.a[t] * c.c[t]), sqnaoc = sqrt(-c.a[t] / c.c[t]);
+      time = fabs((atanh(sqnaoc * r1) - atanh(sqnaoc * r0)) / sqnac);
+    }
+    p.loc = nl;
+  } else {
+    double a1 = A.a0 + len / A.radius;
+    double s1, c1, s0, c0;
+    sincos(a1, &s1, &c1);
+    sincos(A.a0, &s0, &c0);
+    p.loc = A.center + ((A.radius * s1) * A.u1 + (A.radius * c1) * A.u3);
+    V3 nd = c1 * A.u1 + (-s1) * A.u3;
+    // tan(a/2) = sin a / (1 + cos a)
+    double t0 = A.timeCoef * atanh(A.CotZetaBy2 * (s0 / (1.0 + c0)));
+    double t1 = A.timeCoef * atanh(A.CotZetaBy2 * (s1 / (1.0 + c1)));
+    time = att_time = t1 - t0;
+    p.dir = through_angles(unit(nd));
+  }
+  p.path += len, p.t += time, p.recent += time;
+  p.amp *= exp(c.att[t] * att_time);
+  p.moves += 1;
+}
+
+// ============================================================== interfaces ==
+// Elastic properties either side of an interface, at the crossing point.
+struct Iface {
+  V3 normal;            // outward from the current cell
+  double vR[2], vT[2];  // reflection side (current cell), transmission side
+  double rhoR, rhoT;
+  bool has_neighbor;
+};
+
+enum { R_P, R_SV, R_SH, T_P, T_SV, T_SH, RT_NUM };
+
+// Reflection / transmission at a first-order discontinuity or the free
+// surface: Aki & Richards (1980) eq. 5.40 amplitudes -> energy-flux weights ->
+// random outcome -> new type, direction, polarisation.  Reference
+// Phonon::Refraction_FullRT (phonons.cpp:429-476), CellFace::GetRTBasis
+// (media_cellface.cpp:122-149), RTCoef (rtcoef.cpp:30-588).
+// Returns true if the phonon crossed into the neighbour.
+R3D_HD bool full_rt(Phonon& p, Iface f, Rng& rng) {
+  const V3 fnorm = f.normal;
+  const V3 fpara = in_plane_unit_perp(fnorm, p.dir);
+  const V3 fparash = cross(fnorm, fpara);
+  const double sini = dot(fpara, p.dir);
+  bool no_transmit = false;
+  if (!f.has_neighbor) {  // free surface: vanishing medium on the far side
+    f.rhoT = 0.0, f.vT[0] = f.vT[1] = 1e-12;
+    no_transmit = true;
+  }
+  int intype = 0;  // 0 P, 1 SH, 2 SV
+  if (p.type == RAY_S) {  // ChooseSPolType, rtcoef.cpp:406-422
+    double sh = dot(direction_of_motion(p), fparash);
+    intype = (rng_draw(rng) <= sh * sh) ? 1 : 2;
+  }
+  const double rho1 = f.rhoR, rho2 = f.rhoT;
+  const double a1 = f.vR[0], a2 = f.vT[0], b1 = f.vR[1], b2 = f.vT[1];
+  double sino[RT_NUM], cosre[RT_NUM], prob[RT_NUM];
+#pragma unroll
+  for (int i = 0; i < RT_NUM; i++) sino[i] = 0, cosre[i] = 0, prob[i] = 0;
+  int defchoice;
+  if (intype == 1) {  // GetCoefs_SH, rtcoef.cpp:207-278
+    defchoice = R_SH;
+    sino[R_SH] = sini;
+    sino[T_SH] = (b2 / b1) * sini;
+    Cx cj1 = sqrt_real(1.0 - sino[R_SH] * sino[R_SH]);
+    Cx cj2 = sqrt_real(1.0 - sino[T_SH] * sino[T_SH]);
+    Cx a = (rho1 * b1) * cj1, b = (rho2 * b2) * cj2;
+    Cx ar = (a - b) / (a + b), at = (2.0 * a) / (a + b);
+    cosre[R_SH] = cj1.re, cosre[T_SH] = cj2.re;
+    prob[R_SH] = rho1 * b1 * cj1.re * norm(ar);
+    prob[T_SH] = rho2 * b2 * cj2.re * norm(at);
+  } else {  // GetCoefs_PSV, rtcoef.cpp:107-198, :289-393
+    const bool in_p = (intype == 0);
+    defchoice = in_p ? R_P : R_SV;
+    const double pp = sini / (in_p ? a1 : b1);  // horizontal slowness
+    sino[T_P] = a2 * pp, sino[T_SV] = b2 * pp, sino[R_SV] = b1 * pp, sino[R_P] = a1 * pp;
+    const Cx cTP = sqrt_real(1.0 - sino[T_P] * sino[T_P]);
+    const Cx cTS = sqrt_real(1.0 - sino[T_SV] * sino[T_SV]);
+    const Cx cRS = sqrt_real(1.0 - sino[R_SV] * sino[R_SV]);
+    const Cx cRP = sqrt_real(1.0 - sino[R_P] * sino[R_P]);
+    cosre[T_P] = cTP.re, cosre[T_SV] = cTS.re, cosre[R_SV] = cRS.re, cosre[R_P] = cRP.re;
+    const double b1s = b1 * b1, b2s = b2 * b2, psq = pp * pp;
+    const double t1 = rho1 * (1. - 2. * b1s * psq), t2 = rho2 * (1. - 2. * b2s * psq);
+    const double t3 = 2. * rho1 * b1s, t4 = 2. * rho2 * b2s;
+    const double a = t2 - t1, b = t2 + t3 * psq, c = t1 + t4 * psq, d = t4 - t3;
+    const Cx ci1 = cRP / a1, ci2 = cTP / a2, cj1 = cRS / b1, cj2 = cTS / b2;
+    const Cx E = b * ci1 + c * ci2, F = b * cj1 + c * cj2;
+    const Cx G = a - (d * ci1) * cj2, H = a - (d * ci2) * cj1;
+    const Cx D = E * F + (G * H) * psq;
+    Cx aRP, aRS, aTP, aTS, T1, T2;
+    if (in_p) {
+      T1 = b * ci1 - c * ci2;
+      T2 = a + (d * ci1) * cj2;
+      aRP = (T1 * F - (T2 * H) * psq) / D;
+      T1 = (a * b) + ((c * d) * ci2) * cj2;
+      aRS = ((((-2.0) * ci1) * T1) * pp * a1) / (b1 * D);
+      T1 = (2.0 * rho1) * ci1 * a1;
+      aTP = (T1 * F) / (a2 * D);
+      aTS = ((T1 * H) * pp) / (b2 * D);
+    } else {
+      T1 = (a * b) + ((c * d) * ci2) * cj2;
+      aRP = ((((-2.0) * cj1) * T1) * pp * b1) / (a1 * D);
+      T1 = b * cj1 - c * cj2;
+      T2 = a + (d * ci2) * cj1;
+      aRS = -((T1 * E - (T2 * G) * psq) / D);
+      T1 = (2.0 * rho1) * cj1 * b1;
+      aTP = -(((T1 * G) * pp) / (a2 * D));
+      aTS = (T1 * E) / (b2 * D);
+    }
+    prob[R_P] = rho1 * a1 * cRP.re * norm(aRP);
+    prob[R_SV] = rho1 * b1 * cRS.re * norm(aRS);
+    prob[T_P] = rho2 * a2 * cTP.re * norm(aTP);
+    prob[T_SV] = rho2 * b2 * cTS.re * norm(aTS);
+  }
+  // Choose, rtcoef.cpp:436-475
+  double cum[RT_NUM];
+  cum[0] = prob[0];
+#pragma unroll
+  for (int i = 1; i < RT_NUM; i++) cum[i] = cum[i - 1] + prob[i];
+  const double total = cum[RT_NUM - 1];
+  const double ran = rng_draw(rng) * total;
+  int choice = RT_NUM - 1;
+#pragma unroll
+  for (int i = RT_NUM - 2; i >= 0; i--)
+    if (ran <= cum[i]) choice = i;   // ends on the FIRST i with ran <= cum[i]
+  if (total == 0 || (total - total) != 0) choice = defchoice;
+  if (no_transmit && choice >= T_P) choice -= 3;  // T_x -> R_x
+  const bool reflected = choice < T_P;
+  // GetChosenRayDirection, rtcoef.cpp:529-548
+  double comp_para = 0, comp_norm = 0;
+#pragma unroll
+  for (int i = 0; i < RT_NUM; i++)
+    if (i == choice) comp_para = sino[i], comp_norm = cosre[i];
+  if (comp_para > 1.0) comp_para = 1.0;
+  if (reflected) comp_norm = -comp_norm;
+  V3 out = comp_para * fpara + comp_norm * fnorm;
+  p.type = (choice == R_P || choice == T_P) ? RAY_P : RAY_S;
+  V3 nd = through_angles(unit(out));  // mDir.Set(outdir.Theta(), outdir.Phi())
+  if (p.type == RAY_S) {  // GetChosenParticleDOM, rtcoef.cpp:559-588
+    V3 dopm;
+    if (choice == T_SH || choice == R_SH) dopm = fparash;
+    else if (choice == R_SV) dopm = cross(out, fparash);
+    else dopm = cross(fparash, out);
+    p.pol = pol_angle(dopm, nd);
+  }
+  p.dir = nd;
+  return !reflected;
+}
+
+// Snell bending without mode conversion across a weak velocity step
+// (reference Phonon::Refraction_Bend, phonons.cpp:311-405).  Returns true if
+// transmitted.
+R3D_HD bool bend(Phonon& p, V3 fnorm, double veli, double velo) {
+  V3 fpara = in_plane_unit_perp(fnorm, p.dir);
+  V3 fparash = cross(fnorm, fpara);
+  double sini = dot(fpara, p.dir);
+  double sino = (velo / veli) * sini;
+  bool transfer;
+  double coso;
+  if (sino >= 1.0) {
+    transfer = false, sino = sini, coso = -1.0 * dot(fnorm, p.dir);
+  } else {
+    transfer = true, coso = sqrt(1.0 - sino * sino);
+  }
+  V3 out = sino * fpara + coso * fnorm;
+  double polout = 0;
+  if (p.type != RAY_P) {
+    V3 pdomi = direction_of_motion(p);
+    V3 svi = cross(fparash, p.dir), svo = cross(fparash, out);
+    V3 pdomo = dot(pdomi, fparash) * fparash + dot(pdomi, svi) * svo;
+    // outdir.ThetaHat()/PhiHat() normalise through Theta()/Phi()
+    polout = pol_angle(pdomo, through_angles(unit(out)));
+  }
+  p.dir = through_angles(unit(out));
+  p.pol = polout;
+  return transfer;
+}
+
+// ================================================================= scatter ==
+// Inverse-CDF draw: smallest k with r <= cdf[k], r = total * U
+// (reference ProbDist::GetRandomIndex, probability.cpp:104-128).
+R3D_HD uint64_t sample_cdf(const double* __restrict__ cdf, uint64_t n, double u) {
+  uint64_t k1 = 0, k2 = n - 1;
+  const double r = cdf[k2] * u;
+  while (k1 != k2) {
+    uint64_t k = (k1 + k2) >> 1;
+    if (r <= cdf[k]) k2 = k;
+    else k1 = k + 1;
+  }
+  return k2;
+}
+R3D_HD int sample_small(const double* cdf, int n, double u) {
+  const double r = cdf[n - 1] * u;
+  int k = n - 1;
+  for (int i = n - 2; i >= 0; i--)
+    if (r <= cdf[i]) k = i;
+  return k;
+}
+// Rotate (dir, pol) by a deflection given in the phonon's own frame
+// (reference Phonon::Transform, phonons.cpp:116-170; OrthoAxes,
+// geom_r3.cpp:212-286).  rel is the unit deflection vector, rpol the relative
+// polarisation angle.
+R3D_HD void scatter_transform(Phonon& p, V3 rel, double rpol, int new_type) {
+  V3 e1, e2;
+  sph_basis(p.dir, e1, e2);
+  double s, c;
+  sincos(p.pol, &s, &c);
+  const V3 s1 = c * e1 + s * e2, s2 = (-s) * e1 + c * e2, e3 = p.dir;
+  V3 b1, b2;
+  sph_basis(rel, b1, b2);
+  sincos(rpol, &s, &c);
+  const V3 bs1 = c * b1 + s * b2;               // S1 axis of the deflection frame
+  V3 nd = rel.x * s1 + rel.y * s2 + rel.z * e3;  // AA.Express(BB.E3)
+  V3 ns1 = bs1.x * s1 + bs1.y * s2 + bs1.z * e3;
+  nd = through_angles(nd);                       // theta = acos(z), phi = atan2(y, x)
+  p.pol = pol_angle(ns1, nd);
+  p.dir = nd;
+  p.type = new_type;
+}
+
+}  // namespace r3d
+#endif

@@ -1,0 +1,82 @@
+// r3d_rng.h -- counter-based Philox4x32-10 stream of the HIP engine.
+//
+// The reference draws from libc rand() seeded with time(NULL)
+// (model.cpp:235; call sites probability.cpp:111, scatterers.cpp:299,
+// rtcoef.cpp:414,447), which is neither reproducible nor parallel.  The
+// engine keys every history by its id instead:
+//
+//   draw k (k = 0,1,2,...) of history `id` under key `seed` is the 53-bit
+//   uniform in (0,1] made of words [2(k&1), 2(k&1)+1] of
+//   Philox4x32-10(counter = {id_lo, id_hi, k>>1, 0}, key = {seed_lo, seed_hi})
+//
+// so results do not depend on which lane, wave or GPU runs a history.  All of
+// the reference's uniform conventions ([0,1], (0,1], 1-[0,1)) are mapped to
+// (0,1]; they differ from it by at most one part in 2^31.
+#ifndef R3D_RNG_H_
+#define R3D_RNG_H_
+
+#include <stdint.h>
+
+#include "r3d_math.h"
+
+namespace r3d {
+
+struct Rng {
+  uint32_t id_lo, id_hi, key0, key1;
+  uint32_t k;        // next draw index
+  uint32_t w2, w3;   // second half of the current Philox block
+};
+
+R3D_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umulhi(a, b);
+#else
+  return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+R3D_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                 uint32_t k1, uint32_t out[4]) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint32_t hi0 = mulhi32(M0, c0), lo0 = M0 * c0;
+    uint32_t hi1 = mulhi32(M1, c2), lo1 = M1 * c2;
+    c0 = hi1 ^ c1 ^ k0;
+    c1 = lo1;
+    c2 = hi0 ^ c3 ^ k1;
+    c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+
+R3D_HD double u01_from_words(uint32_t hi, uint32_t lo) {
+  uint64_t m = ((uint64_t)(hi >> 5) << 26) | (uint64_t)(lo >> 6);
+  return (double)(m + 1) * (1.0 / 9007199254740992.0);
+}
+
+R3D_HD void rng_init(Rng& g, uint64_t seed, uint64_t id) {
+  g.id_lo = (uint32_t)id, g.id_hi = (uint32_t)(id >> 32);
+  g.key0 = (uint32_t)seed, g.key1 = (uint32_t)(seed >> 32);
+  g.k = 0;
+  g.w2 = g.w3 = 0;
+}
+
+R3D_HD double rng_draw(Rng& g) {
+  double u;
+  if ((g.k & 1u) == 0) {
+    uint32_t w[4];
+    philox4x32_10(g.id_lo, g.id_hi, g.k >> 1, 0u, g.key0, g.key1, w);
+    g.w2 = w[2], g.w3 = w[3];
+    u = u01_from_words(w[0], w[1]);
+  } else {
+    u = u01_from_words(g.w2, g.w3);
+  }
+  g.k++;
+  return u;
+}
+
+}  // namespace r3d
+#endif

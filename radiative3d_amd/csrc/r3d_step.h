@@ -1,0 +1,240 @@
+// r3d_step.h -- one history: the source spray and one iteration of the
+// propagation loop, for one work-item.
+//
+//   spray()  = ShearDislocation::GenerateEventPhonon (reference events.cpp:111-124,
+//              sources.cpp:156-170, phonons.hpp:193-207)
+//   step()   = one pass through the body of Phonon::Propagate
+//              (reference phonons.cpp:540-682)
+//
+// Both are templates over the cell kind (a model is homogeneous in kind, so
+// the choice is made once per launch, not per cell) and over where the small
+// tables live.  They are __host__ __device__: r3d_engine.hip wraps them in
+// the persistent refill kernel; tests/emul wraps them in a plain CPU loop.
+#ifndef R3D_STEP_H_
+#define R3D_STEP_H_
+
+#include "r3d_physics.h"
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define R3D_ADD_F64(ptr, val) unsafeAtomicAdd((ptr), (val))
+#define R3D_ADD_U64(ptr, val) atomicAdd((ptr), (unsigned long long)(val))
+#else
+#define R3D_ADD_F64(ptr, val) (*(ptr) += (val))
+#define R3D_ADD_U64(ptr, val) (*(ptr) += (unsigned long long)(val))
+#endif
+
+namespace r3d {
+
+template <int KIND> struct CellOf;
+template <> struct CellOf<CELL_CYL> { using type = CellCyl; };
+template <> struct CellOf<CELL_TET> { using type = CellTet; };
+template <> struct CellOf<CELL_SPH> { using type = CellSph; };
+
+// Per-lane event tallies (reported through r3d_result.events).
+struct LaneStats {
+  uint32_t iterations, scatter, collect, n_catch, reflect, transfer, rtsolve;
+};
+
+// Where the step finds its tables (pointers may be LDS or HBM).
+template <int KIND>
+struct Tables {
+  const typename CellOf<KIND>::type* cells;
+  const ScatHead* scat_head;
+  const SeisScan* seis_scan;
+};
+
+// ---- per-kind property lookups --------------------------------------------
+R3D_HD double cell_velocity(const CellCyl& c, V3, int t) { return c.v[t]; }
+R3D_HD double cell_velocity(const CellTet& c, V3 p, int t) { return dot(p, v3(c.g[t])) + c.v0[t]; }
+R3D_HD double cell_velocity(const CellSph& c, V3 p, int t) { return c.c[t] + c.a[t] * mag2(p); }
+
+R3D_HD double cell_density(const KArgs&, const CellCyl& c, int, V3) { return c.rho; }
+R3D_HD double cell_density(const KArgs& a, const CellTet&, int idx, V3 p) {
+  const RhoLin r = a.rho[idx];
+  return dot(p, v3(r.g)) + r.c;
+}
+R3D_HD double cell_density(const KArgs&, const CellSph& c, int, V3 p) { return c.rho_c + c.rho_a * mag2(p); }
+
+R3D_HD V3 cell_face_normal(const CellCyl& c, int f, V3) { return v3(c.n[f]); }
+R3D_HD V3 cell_face_normal(const CellTet& c, int f, V3) { return v3(c.n[f]); }
+R3D_HD V3 cell_face_normal(const CellSph& c, int f, V3 loc) {  // media_cellface.cpp:624-627
+  V3 u = unit_else(loc, v3(0, 0, 1));
+  return c.radius[f] > 0 ? u : -u;
+}
+R3D_HD int cell_neighbor(const CellCyl& c, int f) { return f < 2 ? c.nbr[f] : -1; }
+R3D_HD int cell_neighbor(const CellTet& c, int f) { return c.nbr[f]; }
+R3D_HD int cell_neighbor(const CellSph& c, int f) { return c.nbr[f]; }
+
+// ---- source spray ----------------------------------------------------------
+R3D_HD void spray(const KArgs& a, Phonon& p, Rng& rng) {
+  int rt3 = sample_small(a.src_whole, 3, rng_draw(rng));            // 0 P, 1 SH, 2 SV
+  uint64_t k = sample_cdf(a.src_cdf[rt3], a.n_toa, rng_draw(rng));
+  p.t = p.path = p.recent = 0.0;
+  p.amp = 1.0;
+  p.moves = 0;
+  p.dir = v3(a.toa_xyz + 3 * k);
+  p.pol = (rt3 == 1) ? kPi * 0.5 : 0.0;
+  p.type = (rt3 == 0) ? RAY_P : RAY_S;
+  p.loc = v3(a.src_loc);
+  p.cell = a.src_cell;
+}
+
+// ---- seismometers ----------------------------------------------------------
+// reference DataReporter::ReportPhononCollected (dataout.cpp:545-568) +
+// Seismometer::CatchPhonon (dataout.cpp:103-216).  The reference tests every
+// seismometer on every collection event (mPassthrough is hard-wired true);
+// the hash grid narrows that to the seismometers whose gather sphere can
+// contain the arrival point, which gives the identical set of catches.
+template <int KIND>
+R3D_HD void collect(const KArgs& a, const Tables<KIND>& T, const Phonon& p, double vel,
+                    LaneStats& st) {
+  st.collect++;
+  const SeisGrid& g = a.grid;
+  double fx = (p.loc.x - g.origin[0]) * g.inv_h;
+  double fy = (p.loc.y - g.origin[1]) * g.inv_h;
+  double fz = (p.loc.z - g.origin[2]) * g.inv_h;
+  if (!(fx >= 0 && fy >= 0 && fz >= 0 && fx < g.dim[0] && fy < g.dim[1] && fz < g.dim[2])) return;
+  int cellid = ((int)fz * g.dim[1] + (int)fy) * g.dim[0] + (int)fx;
+  uint32_t k0 = g.start[cellid], k1 = g.start[cellid + 1];
+  if (k0 == k1) return;
+  const int t = p.type;
+  V3 dopm = v3(0, 0, 0);
+  bool have_dopm = false;
+  for (uint32_t k = k0; k < k1; k++) {
+    const uint32_t s = g.items[k];
+    const SeisScan& S = T.seis_scan[s];
+    V3 to = v3(S.loc) - p.loc;
+    double dist = mag(to);
+    if (dist > S.r_out[t] || dist < S.r_in[t]) continue;
+    double arv = p.t;
+    if (S.r_in[t] <= 0) arv += dot(to, p.dir) / vel;   // plane-wave arrival-time correction
+    double scaled = arv / a.time_per_bin;
+    if (!(scaled >= 0.0)) continue;
+    double fl = floor(scaled);
+    if (!(fl < (double)a.n_bins)) continue;
+    uint32_t bin = (uint32_t)fl;
+    if (!have_dopm) dopm = direction_of_motion(p), have_dopm = true;
+    const SeisHit& H = a.seis_hit[s];
+    double xf = dot(dopm, v3(H.axes[0])), yf = dot(dopm, v3(H.axes[1])), zf = dot(dopm, v3(H.axes[2]));
+    double energy = (p.amp * p.amp) * H.inv_norm[t];
+    size_t slot = (size_t)s * a.n_bins + bin;
+    double* e = a.energy + slot * 5;
+    R3D_ADD_F64(e + 0, energy * (xf * xf));
+    R3D_ADD_F64(e + 1, energy * (yf * yf));
+    R3D_ADD_F64(e + 2, energy * (zf * zf));
+    R3D_ADD_F64(e + 3 + t, energy);
+    R3D_ADD_U64(a.counts + slot * 2 + t, 1);
+    st.n_catch++;
+  }
+}
+
+// ---- one loop iteration ----------------------------------------------------
+// Returns FATE_ALIVE to continue, else the fate; *reason gets the invalid
+// reason slot (include/r3d.h R3D_INV_*) when FATE_INVALID.
+template <int KIND>
+R3D_HD int step(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng, LaneStats& st,
+                int* reason) {
+  using Cell = typename CellOf<KIND>::type;
+  // phonons.cpp:549-552
+  if (p.t > a.ttl) return FATE_TIMEOUT;
+  // phonons.cpp:554-584: sanity checks every 128th move
+  if ((p.moves & 127u) == 127u) {
+    if (isnan(p.path)) return *reason = 0, FATE_INVALID;
+    if (isnan(p.t)) return *reason = 1, FATE_INVALID;
+    if (p.path < 0) return *reason = 2, FATE_INVALID;
+    if (p.t < 0 || p.recent < 0) return *reason = 3, FATE_INVALID;
+    if (p.recent == 0) return *reason = 4, FATE_INVALID;
+    if (p.recent < a.slow_concern) return *reason = 5, FATE_INVALID;
+    if (p.moves > a.loop_concern) return *reason = 6, FATE_INVALID;
+    p.recent = 0;
+  }
+  st.iterations++;
+  const Cell& c = T.cells[p.cell];
+
+  // --- where does the ray leave the cell? (phonons.cpp:590)
+  Exit e;
+  TetArc tarc;
+  SphArc sarc;
+  if constexpr (KIND == CELL_CYL) {
+    e = cyl_exit(c, a.cyl_radius2, p);
+  } else if constexpr (KIND == CELL_TET) {
+    tarc = tet_arc(c, p);
+    e = tet_exit(c, tarc);
+  } else {
+    sarc = sph_arc(c, a.earth_center, p);
+    e = sph_exit(c, sarc, p);
+  }
+  if (e.len == pos_inf()) return FATE_TIMEOUT;  // phonons.cpp:595-598
+
+  // --- free path to the next scattering event, drawn afresh every iteration
+  //     (scatterers.cpp:297-307, phonons.cpp:601)
+  const ScatHead& sh = T.scat_head[c.scat];
+  const double scatlen = -log(rng_draw(rng)) * sh.mfp[p.type];
+  const bool scatters = scatlen < e.len;
+  const double len = scatters ? scatlen : e.len;
+
+  // --- advance (both branches) and Move (phonons.cpp:608-609, :623)
+  if constexpr (KIND == CELL_CYL) cyl_advance(c, p, len);
+  else if constexpr (KIND == CELL_TET) tet_advance(c, tarc, p, len);
+  else sph_advance(c, sarc, p, len);
+
+  if (scatters) {
+    // Scatterer::GetRandomScatteredRelativePhonon, scatterers.cpp:318-363
+    st.scatter++;
+    if (a.no_deflect) {
+      scatter_transform(p, v3(a.nodeflect_dir), 0.0, p.type);
+    } else {
+      const ScatPtrs sp = a.scat_ptrs[c.scat];
+      int conv = sample_small(sh.whole[p.type], 4, rng_draw(rng));  // GPP GPS GSP GSS
+      uint64_t k = sample_cdf(sp.cdf[conv], a.n_toa, rng_draw(rng));
+      double rpol = (conv == 3) ? sp.spol[k] : 0.0;
+      scatter_transform(p, v3(a.toa_xyz + 3 * k), rpol, (conv & 1) ? RAY_S : RAY_P);
+    }
+    return FATE_ALIVE;
+  }
+
+  // --- at a cell face (phonons.cpp:629-676)
+  const uint32_t fl = face_flags(c.flags, e.face);
+  if (fl & F_COLLECT) collect<KIND>(a, T, p, cell_velocity(c, p.loc, p.type), st);
+  if (fl & (F_REFLECT | F_ADJOIN)) {
+    const int nbr = cell_neighbor(c, e.face);
+    const bool adjoin = (fl & F_ADJOIN) != 0;
+    bool crossed;
+    if ((fl & F_REFLECT) || (fl & F_DISCON)) {
+      Iface f;
+      f.normal = cell_face_normal(c, e.face, p.loc);
+      f.vR[0] = cell_velocity(c, p.loc, 0), f.vR[1] = cell_velocity(c, p.loc, 1);
+      f.rhoR = cell_density(a, c, p.cell, p.loc);
+      f.has_neighbor = adjoin;
+      f.vT[0] = f.vT[1] = f.rhoT = 0;
+      if (adjoin) {
+        const Cell& o = T.cells[nbr];
+        f.vT[0] = cell_velocity(o, p.loc, 0), f.vT[1] = cell_velocity(o, p.loc, 1);
+        f.rhoT = cell_density(a, o, nbr, p.loc);
+      }
+      st.rtsolve++;
+      crossed = full_rt(p, f, rng);
+    } else {
+      // Phonon::Refract without a grid discontinuity (phonons.cpp:243-252):
+      // bend on a fractional velocity step > 1e-5, else plain hand-over.
+      const Cell& o = T.cells[nbr];
+      double v1 = cell_velocity(c, p.loc, 0), v2 = cell_velocity(o, p.loc, 0);
+      double dvp = fabs(2 * (v2 - v1) / (v2 + v1));
+      double w1 = cell_velocity(c, p.loc, 1), w2 = cell_velocity(o, p.loc, 1);
+      double dvs = fabs(2 * (w2 - w1) / (w2 + w1));
+      if ((dvp > dvs ? dvp : dvs) > 0.00001) {
+        crossed = bend(p, cell_face_normal(c, e.face, p.loc), p.type == RAY_P ? v1 : w1,
+                       p.type == RAY_P ? v2 : w2);
+      } else {
+        crossed = true;
+      }
+    }
+    if (crossed) p.cell = nbr, st.transfer++;
+    else st.reflect++;
+    return FATE_ALIVE;
+  }
+  return FATE_LOST;  // phonons.cpp:675
+}
+
+}  // namespace r3d
+#endif

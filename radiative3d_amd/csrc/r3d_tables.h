@@ -1,0 +1,138 @@
+// r3d_tables.h -- the engine's own HBM/LDS data layout.
+//
+// The C-ABI hands over AoS structs that mirror the reference's objects
+// (include/r3d.h).  The engine repacks them once at r3d_engine_create into
+// what the kernels want:
+//   * one fixed-size, 16-B aligned record per cell and per cell kind, holding
+//     only what the traversal reads, with derived constants folded in
+//     (plane offsets n.p, 1/|grad v|, the attenuation exponent -pi f / Q);
+//   * densities (needed only by the R/T solve) in a side array;
+//   * take-off directions as unit vectors instead of (theta, phi);
+//   * seismometers split into a small "scan" record (position + gather radii,
+//     staged in LDS) and a "hit" record (axes, 1/(bin width * area)) fetched
+//     from HBM only on a hit, plus a uniform spatial hash over the scan
+//     records so a surface arrival tests a handful of candidates, not all.
+#ifndef R3D_TABLES_H_
+#define R3D_TABLES_H_
+
+#include <stdint.h>
+
+namespace r3d {
+
+// face flag byte (same bit values as include/r3d.h)
+enum : uint32_t { F_COLLECT = 1u, F_REFLECT = 2u, F_ADJOIN = 4u, F_DISCON = 8u };
+
+// ---- cells -----------------------------------------------------------------
+// Layered cylinder cell (reference RCUCylinder, media.hpp:312-331): uniform
+// velocity, top and bottom planes; the lateral wall radius is a model constant.
+struct alignas(16) CellCyl {
+  double v[2];        // Vp, Vs
+  double att[2];      // -pi f / Q
+  double rho;
+  double n[2][3];     // outward unit normals of top, bottom
+  double d[2];        // plane offsets n . point
+  int32_t nbr[2];
+  uint32_t flags;     // byte f = flags of face f
+  int32_t scat;
+};
+
+// Tetrahedral cell with linear velocity (reference Tetra, media.hpp:400-408).
+struct alignas(16) CellTet {
+  double g[2][3];     // grad Vp, grad Vs
+  double v0[2];       // velocity at the origin
+  double inv_gmag[2]; // 1 / |grad v|
+  double att[2];
+  double n[4][3];
+  double d[4];
+  int32_t nbr[4];
+  uint32_t flags;
+  int32_t scat;
+  double pad_;
+};
+static_assert(sizeof(CellTet) == 256, "CellTet is one 256-byte record");
+
+// Spherical shell, v(r) = a r^2 + c (reference SphereShell, media.hpp:467-478).
+struct alignas(16) CellSph {
+  double a[2], c[2], zero_rad2[2], att[2];
+  double rho_a, rho_c;
+  double radius[2];   // signed: +top (outward normal), -bottom (inward)
+  int32_t nbr[2];
+  uint32_t flags;
+  int32_t scat;
+};
+
+struct RhoLin {       // density side table for tetra cells
+  double g[3], c;
+};
+
+// ---- scatterers ------------------------------------------------------------
+struct ScatHead {     // small per-scatterer record, staged in LDS
+  double mfp[2];
+  double whole[2][4]; // cumulative conversion weights for incoming P / S
+};
+struct ScatPtrs {     // HBM-resident tables of one scatterer
+  const double* cdf[4];
+  const double* spol;
+};
+
+// ---- seismometers ----------------------------------------------------------
+struct SeisScan {     // 56 B, staged in LDS
+  double loc[3];
+  double r_in[2], r_out[2];
+};
+struct SeisHit {      // fetched on a hit
+  double axes[3][3];
+  double inv_norm[2]; // 1 / (time_per_bin * area[type])
+};
+struct SeisGrid {     // uniform hash over seismometer gather spheres
+  double origin[3];
+  double inv_h;
+  int32_t dim[3];
+  int32_t n_cells;
+  const uint32_t* start;   // n_cells + 1 offsets into items
+  const uint32_t* items;   // seismometer indices
+};
+
+// ---- everything a launch needs (passed by value) ---------------------------
+struct KArgs {
+  // model
+  const void* cells;         // CellCyl / CellTet / CellSph array
+  const RhoLin* rho;         // tetra only
+  int32_t n_cells;
+  int32_t n_scat;
+  int32_t n_seis;
+  uint32_t n_bins;
+  const ScatHead* scat_head;
+  const ScatPtrs* scat_ptrs;
+  const SeisScan* seis_scan;
+  const SeisHit* seis_hit;
+  SeisGrid grid;
+  uint64_t n_toa;
+  const double* toa_xyz;     // n_toa x 3, theta already nudged
+  const double* src_cdf[3];
+  double src_whole[3];
+  double src_loc[3];
+  int32_t src_cell;
+  uint32_t no_deflect;
+  // scalars
+  double ttl, time_per_bin, inv_time_per_bin, slow_concern;
+  uint64_t loop_concern;
+  double nodeflect_dir[3];   // unit vector at theta = min_theta, phi = 0
+  double cyl_radius2;        // cylinder models: wall radius squared
+  double earth_center[3];
+  // work
+  uint64_t n, first_id, seed;
+  unsigned long long* next;  // device work counter
+  // results
+  double* energy;
+  unsigned long long* counts;
+  unsigned long long* scalars;
+  void* finals;              // r3d_final[n] or null
+  // LDS carve-up (bytes from the start of dynamic shared memory)
+  uint32_t lds_cells_off;    // 0xFFFFFFFF: cells stay in HBM
+  uint32_t lds_scat_off;
+  uint32_t lds_seis_off;
+};
+
+}  // namespace r3d
+#endif

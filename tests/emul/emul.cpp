@@ -1,0 +1,71 @@
+// emul.cpp -- TEST-ONLY host build of the engine's per-work-item code.
+//
+// Compiles radiative3d_amd/csrc/r3d_step.h (the exact functions the HIP kernel
+// runs per lane) with g++ and drives them one history at a time, so kernel
+// logic can be single-stepped and compared with the oracle in a container
+// that has no GPU.  It is NOT a product path: it is not part of the C-ABI,
+// not shipped in radiative3d_amd/lib, and nothing outside tests/ loads it.
+#include <cstring>
+
+#include "../../include/r3d.h"
+#include "../../radiative3d_amd/csrc/r3d_pack.h"
+#include "../../radiative3d_amd/csrc/r3d_step.h"
+
+using namespace r3d;
+
+template <int KIND>
+static void run_kind(const KArgs& a, uint64_t n, uint64_t first_id, uint64_t seed, r3d_result* out,
+                     r3d_final* finals) {
+  Tables<KIND> T;
+  T.cells = reinterpret_cast<const typename CellOf<KIND>::type*>(a.cells);
+  T.scat_head = a.scat_head;
+  T.seis_scan = a.seis_scan;
+  for (uint64_t i = 0; i < n; i++) {
+    Phonon p;
+    Rng rng;
+    LaneStats st = {0, 0, 0, 0, 0, 0, 0};
+    rng_init(rng, seed, first_id + i);
+    spray(a, p, rng);
+    out->events[R3D_EV_GENERATED]++;
+    int fate, reason = 0;
+    while ((fate = step<KIND>(a, T, p, rng, st, &reason)) == FATE_ALIVE) {
+    }
+    if (fate == FATE_LOST) out->n_lost++;
+    else if (fate == FATE_TIMEOUT) out->n_timeout++;
+    else out->n_invalid++, out->invalid_reasons[reason]++;
+    out->events[R3D_EV_ITERATIONS] += st.iterations;
+    out->events[R3D_EV_SCATTER] += st.scatter;
+    out->events[R3D_EV_COLLECT] += st.collect;
+    out->events[R3D_EV_CATCH] += st.n_catch;
+    out->events[R3D_EV_REFLECT] += st.reflect;
+    out->events[R3D_EV_TRANSFER] += st.transfer;
+    out->events[R3D_EV_RTSOLVE] += st.rtsolve;
+    if (finals) {
+      r3d_final& f = finals[i];
+      std::memset(&f, 0, sizeof f);
+      f.time = p.t, f.path = p.path, f.amp = p.amp;
+      f.loc[0] = p.loc.x, f.loc[1] = p.loc.y, f.loc[2] = p.loc.z;
+      f.dir[0] = p.dir.x, f.dir[1] = p.dir.y, f.dir[2] = p.dir.z;
+      f.moves = p.moves;
+      f.fate = (uint8_t)fate;
+      f.type = (uint8_t)p.type;
+      f.n_catch = (uint16_t)(st.n_catch > 65535u ? 65535u : st.n_catch);
+    }
+  }
+}
+
+extern "C" int r3d_emul_run(const r3d_model_desc* m, uint64_t n, uint64_t first_id, uint64_t seed,
+                            r3d_result* out, r3d_final* finals) {
+  if (!m || !out) return 1;
+  PackedModel pm;
+  pack_model(*m, pm);
+  KArgs a = pm.args;
+  a.energy = out->energy;
+  a.counts = reinterpret_cast<unsigned long long*>(out->counts);
+  switch (m->cell_kind) {
+    case R3D_CELL_CYLINDER: run_kind<CELL_CYL>(a, n, first_id, seed, out, finals); break;
+    case R3D_CELL_TETRA: run_kind<CELL_TET>(a, n, first_id, seed, out, finals); break;
+    default: run_kind<CELL_SPH>(a, n, first_id, seed, out, finals);
+  }
+  return 0;
+}

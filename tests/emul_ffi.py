@@ -1,0 +1,38 @@
+"""ctypes access to the TEST-ONLY host build of the kernel's per-lane code
+(tests/emul/libr3d_emul.so).  See tests/emul/emul.cpp."""
+import ctypes as C
+import os
+import subprocess
+
+from radiative3d_amd import _ffi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(_HERE, "emul", "libr3d_emul.so")
+        src = os.path.join(_HERE, "emul", "emul.cpp")
+        deps = [src] + [os.path.join(_ffi.REPO, "radiative3d_amd", "csrc", f)
+                        for f in os.listdir(os.path.join(_ffi.REPO, "radiative3d_amd", "csrc"))
+                        if f.endswith(".h")]
+        if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", so, src])
+        L = C.CDLL(so)
+        L.r3d_emul_run.restype = C.c_int
+        L.r3d_emul_run.argtypes = [C.POINTER(_ffi.ModelDesc), C.c_uint64, C.c_uint64, C.c_uint64,
+                                   C.POINTER(_ffi.Result), C.POINTER(_ffi.Final)]
+        _lib = L
+    return _lib
+
+
+def run(model, n, first_id=0, seed=0x5EED, result=None, trace=False):
+    res = result if result is not None else model.new_result()
+    c = res._as_c()
+    finals = (_ffi.Final * n)() if trace else None
+    if lib().r3d_emul_run(model.desc_p, n, first_id, seed, C.byref(c), finals):
+        raise RuntimeError("emul run failed")
+    res._from_c(c)
+    return (res, finals) if trace else res
