@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- phonon-histories/s of the HIP engine on the reference's headline
+configuration (BASELINE.json configs[1]: NSCP crust-pinch, do-crustpinch.sh
+arguments, TOA degree 9, 1e7 histories per step), one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path (GenerateEventPhonon + Propagate) over a
+fresh batch of 1e7 history ids per GPU; tables are resident in HBM before the
+timed region; the per-receiver bins stay in HBM and are summed over ranks with
+one RCCL all-reduce per buffer inside the timed region (weak scaling: every
+rank runs the same count).  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes_per_history(ev, n_toa, n_seis, cell_kind):
+    """must-touch bytes per history from per-history event counts."""
+    probes = 2 + math.ceil(math.log2(n_toa))
+    b_cell = {0: 150, 1: 340, 2: 120}[cell_kind]
+    return (probes * 8 + 16
+            + ev["iterations"] * b_cell
+            + ev["transfer"] * 64
+            + ev["rtsolve"] * 112
+            + ev["scatter"] * (probes * 8 + 8 + 16)
+            + ev["collect"] * n_seis * 48
+            + ev["catch"] * 56
+            + 104)
+
+
+def usable_cores(cap=16):
+    """Host cores this process may really use: affinity, cgroup CPU quota, and the
+    GPU box's per-GPU share (16) as an upper bound."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(model, budget_s=12.0):
+    """The oracle (CPU port of the reference's algorithm) on this box's host
+    cores: one thread per core, each on its own id range, bounded to ~budget_s."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle_ffi
+    cores = usable_cores()
+    t = time.perf_counter()
+    oracle_ffi.run(model, 2000, first_id=1 << 50)
+    per_core_rate = 2000 / (time.perf_counter() - t)
+    per_thread = max(2000, int(per_core_rate * budget_s))
+
+    def work(i):
+        oracle_ffi.run(model, per_thread, first_id=(1 << 50) + (i + 1) * per_thread)
+
+    t = time.perf_counter()
+    with ThreadPoolExecutor(cores) as pool:   # ctypes releases the GIL during the call
+        list(pool.map(work, range(cores)))
+    dt = time.perf_counter() - t
+    return {"value": cores * per_thread / dt, "unit": "histories/s", "cores": cores, "kind": "port",
+            "sample": f"{cores * per_thread} histories of the same workload "
+                      f"({per_thread} per thread x {cores} threads, {dt:.1f} s), oracle/r3d_oracle.cpp"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--histories", type=int, default=10_000_000, help="histories per GPU per step")
+    ap.add_argument("--toa-degree", type=int, default=9)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from radiative3d_amd import Engine, Model
+    from radiative3d_amd.parallel import DeviceResult
+    from tests.configs import crustpinch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    # ---- build the model (host) and put it in HBM: not timed --------------
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    t0 = time.perf_counter()
+    model = Model(crustpinch(args.toa_degree))
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    engine = Engine(model, device=local_rank)
+    t_upload = time.perf_counter() - t0
+    note(f"model built in {t_build:.1f} s, tables in HBM after {t_upload:.1f} s")
+    result = DeviceResult(model, device)
+    stream = torch.cuda.current_stream(device)
+    n = args.histories
+    seed = 0x5EED
+
+    step_res = DeviceResult(model, device)
+
+    def step(i):
+        # every step and every rank gets its own disjoint id range; a step ends with the
+        # whole-job bins of that step (summed over ranks) added to the running total
+        first = (i * world + rank) * n
+        step_res.zero_()
+        engine.run_device(n, first, seed, *step_res.pointers(), stream=stream.cuda_stream)
+        step_res.allreduce_()     # no-op at world == 1
+        result.add_(step_res)
+        return engine
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    result.zero_()
+    sync()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+        kernel_ms.append(None)
+    sync()
+    elapsed = time.perf_counter() - t0
+    # per-launch kernel durations from HIP events on the launch stream: measured in a
+    # second, untimed pass so that reading the events does not serialise the timed loop
+    for i in range(args.steps):
+        step(args.warmup + args.steps + i)
+        kernel_ms[i] = engine.last_kernel_ms()
+    sync()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    note(f"timed {args.steps} steps in {elapsed:.3f} s")
+    if rank == 0:
+        res = result.to_result()
+        total = res.events["generated"]            # histories summed over ranks and passes
+        ev = {k: v / total for k, v in res.events.items()}
+        b_hist = algorithmic_bytes_per_history(ev, model.n_toa, model.n_seismometers, model.desc.cell_kind)
+        avg_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = n * b_hist / (avg_ms * 1e-3) / 1e9
+        value = args.steps * n * world / elapsed
+        line = {
+            "metric": "phonon-histories/sec", "value": value, "unit": "histories/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "NSCP crust-pinch (do-crustpinch.sh arguments), "
+                                   f"TOA degree {args.toa_degree}, {n} histories per GPU per step, "
+                                   "480 seismometers x 300 bins",
+                       "histories_per_gpu_per_step": n, "toa_degree": args.toa_degree,
+                       "cells": model.n_cells, "scatterers": model.n_scatterers,
+                       "parallelism": f"history-id shards x{world}, one all-reduce of the bins per step"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "propagate_kernel<tetra>", "kernel_ms_avg": avg_ms,
+                         "algorithmic_bytes_per_history": b_hist,
+                         "events_per_history": {k: round(v, 4) for k, v in ev.items()}},
+            "host": {"model_build_s": round(t_build, 2), "table_upload_s": round(t_upload, 2)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            note("timing the CPU baseline (oracle) ...")
+            line["cpu_baseline"] = cpu_baseline(model)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -26,8 +26,26 @@ def lib():
         L.r3d_oracle_philox.argtypes = [C.POINTER(C.c_uint32)] * 3
         L.r3d_oracle_draw.restype = C.c_double
         L.r3d_oracle_draw.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32]
+        L.r3d_oracle_advance.argtypes = [C.POINTER(_ffi.ModelDesc), C.c_int, C.c_int, C.POINTER(C.c_double),
+                                         C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double)]
+        L.r3d_oracle_boundary.argtypes = [C.POINTER(_ffi.ModelDesc), C.c_int, C.c_int, C.POINTER(C.c_double),
+                                          C.c_double, C.c_double, C.POINTER(C.c_double)]
         _lib = L
     return _lib
+
+
+def advance(model, cell, rtype, loc, theta, phi, length):
+    """-> dict(loc, theta, phi, time, atten) after moving `length` along the ray."""
+    out = (C.c_double * 8)()
+    lib().r3d_oracle_advance(model.desc_p, cell, rtype, (C.c_double * 3)(*loc), theta, phi, length, out)
+    return dict(loc=list(out[0:3]), theta=out[3], phi=out[4], time=out[5], atten=out[6])
+
+
+def boundary(model, cell, rtype, loc, theta, phi):
+    """-> dict(loc, theta, phi, time, length, face) at the cell boundary."""
+    out = (C.c_double * 8)()
+    lib().r3d_oracle_boundary(model.desc_p, cell, rtype, (C.c_double * 3)(*loc), theta, phi, out)
+    return dict(loc=list(out[0:3]), theta=out[3], phi=out[4], time=out[5], length=out[6], face=int(out[7]))
 
 
 def run(model, n, first_id=0, seed=0x5EED, result=None, trace=False):

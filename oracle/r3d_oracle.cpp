@@ -976,6 +976,28 @@ void r3d_oracle_rt_probs(double rho1, double a1, double b1, double rho2, double 
   for (int i = 0; i < 6; i++) probs[i] = r.prob[i];
 }
 
+// Known-answer hooks for tests: one leg of ray geometry in a given cell.
+//   r3d_oracle_advance: move `len` along the ray from (loc, theta, phi)
+//       -> out[8] = new loc(3), new theta, new phi, travel time, attenuation, 0
+//   r3d_oracle_boundary: MediumCell::GetPathToBoundary
+//       -> out[8] = exit loc(3), theta, phi, time, path length, face id
+void r3d_oracle_advance(const r3d_model_desc* m, int cell, int type, const double loc[3],
+                        double theta, double phi, double len, double out[8]) {
+  Phonon p;
+  p.loc = mk(loc), p.theta = theta, p.phi = phi, p.type = type, p.cell = cell;
+  TravelRec r = advance_length(*m, m->cells[cell], p, len);
+  out[0] = r.loc.x, out[1] = r.loc.y, out[2] = r.loc.z, out[3] = r.theta, out[4] = r.phi;
+  out[5] = r.time, out[6] = r.atten, out[7] = 0;
+}
+void r3d_oracle_boundary(const r3d_model_desc* m, int cell, int type, const double loc[3],
+                         double theta, double phi, double out[8]) {
+  Phonon p;
+  p.loc = mk(loc), p.theta = theta, p.phi = phi, p.type = type, p.cell = cell;
+  TravelRec r = path_to_boundary(*m, m->cells[cell], p);
+  out[0] = r.loc.x, out[1] = r.loc.y, out[2] = r.loc.z, out[3] = r.theta, out[4] = r.phi;
+  out[5] = r.time, out[6] = r.len, out[7] = r.face;
+}
+
 void r3d_oracle_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   oracle_philox4x32_10(ctr, key, out);
 }

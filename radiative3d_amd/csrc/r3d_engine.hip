@@ -404,13 +404,12 @@ void r3d_engine_destroy(r3d_engine* e) {
 size_t r3d_energy_len(const r3d_engine* e) { return e ? (size_t)e->n_seis * e->n_bins * R3D_N_ENERGY : 0; }
 size_t r3d_counts_len(const r3d_engine* e) { return e ? (size_t)e->n_seis * e->n_bins * R3D_N_COUNT : 0; }
 
-int r3d_run_device(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, double* d_energy,
-                   uint64_t* d_counts, uint64_t* d_scalars, r3d_final* d_finals, void* stream) {
+static int enqueue(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, double* d_energy,
+                   uint64_t* d_counts, uint64_t* d_scalars, r3d_final* d_finals, hipStream_t s) {
   const int fail_value = 1;
   if (!e) return g_error = "null engine", 1;
   if (!d_energy || !d_counts || !d_scalars) return g_error = "null result buffer", 1;
   R3D_HIP_OK(hipSetDevice(e->device));
-  hipStream_t s = stream ? reinterpret_cast<hipStream_t>(stream) : e->stream;
   KArgs a = e->args;
   a.n = n, a.first_id = first_id, a.seed = seed;
   a.next = reinterpret_cast<unsigned long long*>(e->d_next.p);
@@ -426,6 +425,14 @@ int r3d_run_device(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, 
   return 0;
 }
 
+int r3d_run_device(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, double* d_energy,
+                   uint64_t* d_counts, uint64_t* d_scalars, r3d_final* d_finals, void* stream) {
+  // NULL means HIP's default (null) stream, which is also what torch's
+  // default stream is, so later work queued there is ordered after the kernel.
+  return enqueue(e, n, first_id, seed, d_energy, d_counts, d_scalars, d_finals,
+                 reinterpret_cast<hipStream_t>(stream));
+}
+
 static int run_host(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, r3d_result* out,
                     r3d_final* finals) {
   const int fail_value = 1;
@@ -437,9 +444,9 @@ static int run_host(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,
   R3D_HIP_OK(hipMemsetAsync(e->d_scalars.p, 0, e->d_scalars.bytes, e->stream));
   DevBuf d_finals;
   if (finals) R3D_HIP_OK(d_finals.alloc_zero(n * sizeof(r3d_final)));
-  if (r3d_run_device(e, n, first_id, seed, reinterpret_cast<double*>(e->d_energy.p),
-                     reinterpret_cast<uint64_t*>(e->d_counts.p), reinterpret_cast<uint64_t*>(e->d_scalars.p),
-                     finals ? reinterpret_cast<r3d_final*>(d_finals.p) : nullptr, nullptr))
+  if (enqueue(e, n, first_id, seed, reinterpret_cast<double*>(e->d_energy.p),
+              reinterpret_cast<uint64_t*>(e->d_counts.p), reinterpret_cast<uint64_t*>(e->d_scalars.p),
+              finals ? reinterpret_cast<r3d_final*>(d_finals.p) : nullptr, e->stream))
     return 1;
   R3D_HIP_OK(hipStreamSynchronize(e->stream));
   const size_t ne = r3d_energy_len(e), nc = r3d_counts_len(e);

@@ -1,0 +1,84 @@
+"""The C-ABI libraries load and export every entry point include/*.h declares;
+the ctypes mirrors have the layouts the C compiler gives the structs.  No
+compute calls here: these run without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from radiative3d_amd import _ffi
+
+INCLUDE = os.path.join(_ffi.REPO, "include")
+
+
+def declared_functions(header):
+    text = open(os.path.join(INCLUDE, header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#define[^\n]*", "", text)
+    return sorted(set(re.findall(r"\b(r3dh?_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_engine_library_exports_every_declared_symbol():
+    names = declared_functions("r3d.h")
+    assert {"r3d_engine_create", "r3d_run", "r3d_run_device", "r3d_run_traced",
+            "r3d_engine_destroy", "r3d_last_error"} <= set(names)
+    lib = C.CDLL(os.path.join(_ffi.LIBDIR, "libr3d_hip.so"))
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_host_library_exports_every_declared_symbol():
+    names = declared_functions("r3d_host.h")
+    lib = C.CDLL(os.path.join(_ffi.LIBDIR, "libr3d_host.so"))
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert names and not missing, missing
+
+
+def test_ctypes_mirror_matches_c_layout():
+    prog = r'''
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "r3d.h"
+    int main(void) {
+      printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(r3d_face), sizeof(r3d_cell),
+             sizeof(r3d_scatterer), sizeof(r3d_source), sizeof(r3d_seismometer), sizeof(r3d_params),
+             sizeof(r3d_model_desc), sizeof(r3d_result), sizeof(r3d_final));
+      printf("%zu %zu %zu %d\n", offsetof(r3d_cell, faces), offsetof(r3d_model_desc, source),
+             offsetof(r3d_result, events), R3D_N_SCALARS);
+      return 0;
+    }'''
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "s.c")
+        open(src, "w").write(prog)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", INCLUDE, "-o", exe, src])
+        out = subprocess.check_output([exe]).decode().split()
+    sizes = [int(x) for x in out]
+    want = [C.sizeof(t) for t in (_ffi.Face, _ffi.Cell, _ffi.Scatterer, _ffi.Source, _ffi.Seismometer,
+                                  _ffi.Params, _ffi.ModelDesc, _ffi.Result, _ffi.Final)]
+    assert sizes[:9] == want
+    assert sizes[9:12] == [_ffi.Cell.faces.offset, _ffi.ModelDesc.source.offset, _ffi.Result.events.offset]
+    assert sizes[12] == _ffi.R3D_N_SCALARS
+
+
+def test_engine_fails_loudly_without_a_gpu(models):
+    """No silent CPU fallback: on a box without a HIP device the product path
+    raises (on the GPU box this test is a no-op)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from radiative3d_amd import Engine
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU path"):
+        Engine(models("halfspace", 3))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(_ffi.REPO, "radiative3d_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
+                text = open(os.path.join(root, f), errors="ignore").read()
+                assert "oracle_ffi" not in text and "r3d_oracle" not in text and "libr3d_oracle" not in text, f
