@@ -1,0 +1,77 @@
+"""The reference's own model-definition files (user.cpp + user_*_inc.cpp) must
+work unchanged against this library's grid.hpp (north_star).
+Runs only where the reference checkout is present (not on the GPU box).  The
+user files are compiled from where they lie into pytest's temp dir; nothing is
+copied into the repo."""
+import ctypes as C
+import glob
+import os
+import subprocess
+
+import pytest
+
+from radiative3d_amd import _ffi
+from tests.configs import CONFIGS
+
+REF = "/root/reference"
+HOST = os.path.join(_ffi.REPO, "radiative3d_amd", "host")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "user.cpp")),
+                                reason="reference checkout not present")
+
+
+@pytest.fixture(scope="module")
+def user_lib(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("userlib") / "libr3d_host_user.so")
+    srcs = [f for f in glob.glob(os.path.join(HOST, "*.cpp"))]
+    # user.cpp says #include "grid.hpp": feed it on stdin so that the quote-include
+    # resolves through -I to THIS repo's grid.hpp, and the user_*_inc.cpp files
+    # through the second -I to the reference directory.
+    cmd = ["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-pthread", "-I", HOST, "-I", REF,
+           "-o", out, "-x", "c++", "-", "-x", "none"] + srcs
+    with open(os.path.join(REF, "user.cpp")) as f:
+        subprocess.check_call(cmd, stdin=f, cwd=str(tmp_path_factory.getbasetemp()))
+    L = C.CDLL(out)
+    L.r3dh_model_from_args.restype = C.c_void_p
+    L.r3dh_model_from_args.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+    L.r3dh_model_desc.restype = C.POINTER(_ffi.ModelDesc)
+    L.r3dh_model_desc.argtypes = [C.c_void_p]
+    L.r3dh_grid_dump.restype = C.c_char_p
+    L.r3dh_grid_dump.argtypes = [C.c_void_p]
+    L.r3dh_model_free.argtypes = [C.c_void_p]
+    L.r3dh_last_error.restype = C.c_char_p
+    return L
+
+
+def build(lib, args):
+    argv = (C.c_char_p * len(args))(*[a.encode() for a in args])
+    h = lib.r3dh_model_from_args(len(args), argv)
+    assert h, lib.r3dh_last_error().decode()
+    return h
+
+
+@pytest.mark.parametrize("name", ["halfspace", "crustpinch", "lopnor", "sphere"])
+def test_builtin_models_equal_the_users_definitions(user_lib, name):
+    """Same do-script arguments through the reference's user_*_inc.cpp and through
+    the built-in table-driven definitions: identical grids and identical cell tables."""
+    args = CONFIGS[name](2)
+    builtin = _ffi.host_lib()
+    hu, hb = build(user_lib, args), build(builtin, args)
+    assert user_lib.r3dh_grid_dump(hu) == builtin.r3dh_grid_dump(hb)
+    du, db = user_lib.r3dh_model_desc(hu).contents, builtin.r3dh_model_desc(hb).contents
+    assert (du.n_cells, du.n_scatterers, du.cell_kind) == (db.n_cells, db.n_scatterers, db.cell_kind)
+    size = C.sizeof(_ffi.Cell) * du.n_cells
+    assert C.string_at(du.cells, size) == C.string_at(db.cells, size)
+    user_lib.r3dh_model_free(hu), builtin.r3dh_model_free(hb)
+
+
+@pytest.mark.parametrize("args,cells", [
+    (["--grid-compiled=8", "--toa-degree=1"], None),             # crust upthrust (tetra)
+    (["--grid-compiled=30", "--toa-degree=1"], None),            # toy sphere
+    (["--grid-compiled=21", "--toa-degree=1", "--range=1200"], None),  # Lop Nor Moho alt 2
+])
+def test_other_user_models_build(user_lib, args, cells):
+    h = build(user_lib, args)
+    d = user_lib.r3dh_model_desc(h).contents
+    assert d.n_cells > 0 and d.n_scatterers > 0
+    user_lib.r3dh_model_free(h)
