@@ -117,7 +117,8 @@ def hip_lib():
     """libr3d_hip.so: the HIP engine.  Fails loudly when it was not built."""
     global _hip
     if _hip is None:
-        L = _load(os.path.join(LIBDIR, "libr3d_hip.so"))
+        # R3D_HIP_LIB: developer override used by tools/ to time experimental builds
+        L = _load(os.environ.get("R3D_HIP_LIB") or os.path.join(LIBDIR, "libr3d_hip.so"))
         L.r3d_engine_create.restype = C.c_void_p
         L.r3d_engine_create.argtypes = [C.POINTER(ModelDesc), C.c_int]
         L.r3d_engine_destroy.argtypes = [C.c_void_p]

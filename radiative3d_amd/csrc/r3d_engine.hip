@@ -38,10 +38,89 @@ namespace r3d {
 
 constexpr int kBlock = 256;          // 4 waves
 constexpr unsigned kChunk = 256;     // history ids a wave claims per global atomic
+#ifndef R3D_REFILL_MIN
+#define R3D_REFILL_MIN 8
+#endif
+constexpr unsigned kRefillMin = R3D_REFILL_MIN;
+#ifndef R3D_WAVES_PER_SIMD
+#define R3D_WAVES_PER_SIMD 1   // register budget 512 / N per lane (second __launch_bounds__ argument)
+#endif  // idle lanes that trigger a refill
+
+// ---------------------------------------------------- wave-level helpers ----
+__device__ __forceinline__ double bcast(double v, int src) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ V3 bcast(V3 v, int src) { return v3(bcast(v.x, src), bcast(v.y, src), bcast(v.z, src)); }
+
+// Seismometer collection for the arrival held by lane `src`, executed by the
+// whole wave: same tests and same bin updates as collect() in r3d_step.h
+// (reference dataout.cpp:103-216, :545-568), with the candidate receivers of
+// the arrival's hash cell spread over the 64 lanes.
+template <int KIND>
+__device__ __forceinline__ void collect_wave(const KArgs& a, const Tables<KIND>& T, const Phonon& p,
+                                             double vel_lane, int src_lane, unsigned lane, LaneStats& st) {
+  const int src = __builtin_amdgcn_readfirstlane(src_lane);
+  const V3 loc = bcast(p.loc, src), dir = bcast(p.dir, src);
+  const double t = bcast(p.t, src), amp = bcast(p.amp, src), pol = bcast(p.pol, src);
+  const double vel = bcast(vel_lane, src);
+  const int type = __builtin_amdgcn_readlane(p.type, src);
+  if ((int)lane == src) st.collect++;
+  const SeisGrid& g = a.grid;
+  const double fx = (loc.x - g.origin[0]) * g.inv_h;
+  const double fy = (loc.y - g.origin[1]) * g.inv_h;
+  const double fz = (loc.z - g.origin[2]) * g.inv_h;
+  if (!(fx >= 0 && fy >= 0 && fz >= 0 && fx < g.dim[0] && fy < g.dim[1] && fz < g.dim[2])) return;
+  const int cellid = ((int)fz * g.dim[1] + (int)fy) * g.dim[0] + (int)fx;
+  const uint32_t k0 = g.start[cellid], k1 = g.start[cellid + 1];
+  if (k0 == k1) return;
+  V3 dopm = dir;  // Phonon::DirectionOfMotion of the broadcast phonon
+  if (type != RAY_P) {
+    V3 th, ph;
+    sph_basis(dir, th, ph);
+    double s, c;
+    sincos(pol, &s, &c);
+    dopm = c * th + s * ph;
+  }
+  uint32_t hits = 0;
+  for (uint32_t kb = k0; kb < k1; kb += 64u) {
+    const uint32_t k = kb + lane;
+    bool hit = false;
+    if (k < k1) {
+      const uint32_t s = g.items[k];
+      const SeisScan& S = T.seis_scan[s];
+      const V3 to = v3(S.loc) - loc;
+      const double dist = mag(to);
+      if (!(dist > S.r_out[type] || dist < S.r_in[type])) {
+        double arv = t;
+        if (S.r_in[type] <= 0) arv += dot(to, dir) / vel;
+        const double scaled = arv / a.time_per_bin;
+        const double fl = floor(scaled);
+        if (scaled >= 0.0 && fl < (double)a.n_bins) {
+          const uint32_t bin = (uint32_t)fl;
+          const SeisHit& H = a.seis_hit[s];
+          const double xf = dot(dopm, v3(H.axes[0])), yf = dot(dopm, v3(H.axes[1])), zf = dot(dopm, v3(H.axes[2]));
+          const double energy = (amp * amp) * H.inv_norm[type];
+          const size_t slot = (size_t)s * a.n_bins + bin;
+          double* e = a.energy + slot * 5;
+          unsafeAtomicAdd(e + 0, energy * (xf * xf));
+          unsafeAtomicAdd(e + 1, energy * (yf * yf));
+          unsafeAtomicAdd(e + 2, energy * (zf * zf));
+          unsafeAtomicAdd(e + 3 + type, energy);
+          atomicAdd(a.counts + slot * 2 + type, 1ull);
+          hit = true;
+        }
+      }
+    }
+    hits += (uint32_t)__popcll(__ballot(hit));
+  }
+  if ((int)lane == src) st.n_catch += hits;
+}
 
 // --------------------------------------------------------------- the kernel --
 template <int KIND, bool LDS_CELLS, bool TRACE>
-__global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
+__global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(const KArgs a) {
   using Cell = typename CellOf<KIND>::type;
   extern __shared__ __align__(16) unsigned char smem[];
 
@@ -79,8 +158,11 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
 
   for (;;) {
     // ---- refill dead lanes from the wave's id range ----
+    // (a refill costs a dependent table search, so wait until kRefillMin lanes are idle
+    //  -- or none is left running -- and serve them together)
     unsigned long long need = __ballot(!alive);
-    while (need != 0ull && !drained) {
+    const bool refill_now = (unsigned)__popcll(need) >= kRefillMin || need == ~0ull;
+    while (refill_now && need != 0ull && !drained) {
       if (w_next == w_end) {
         unsigned long long base = 0;
         if (lane == 0) base = atomicAdd(a.next, (unsigned long long)kChunk);
@@ -109,29 +191,43 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
     }
     if (!__any(alive)) break;  // every lane idle and nothing left to hand out
 
-    // ---- one propagation iteration for every live lane ----
-    if (alive) {
-      int reason = 0;
-      const int fate = step<KIND>(a, T, p, rng, st, &reason);
-      if (fate != FATE_ALIVE) {
-        alive = false;
-        if (fate == FATE_LOST) n_lost++;
-        else if (fate == FATE_TIMEOUT) n_timeout++;
-        else {
+    // ---- first half of the iteration for every live lane: search, draw, advance ----
+    Pending ev;
+    ev.vel = 0.0, ev.face = -1, ev.flags = 0u;
+    int fate = FATE_ALIVE, reason = 0;
+    if (alive) fate = step_move<KIND>(a, T, p, rng, st, &reason, ev);
+    const bool moved = alive && fate == FATE_ALIVE;
+
+    // ---- seismometers: the wave serves its arriving lanes one at a time, all 64
+    //      lanes testing candidate receivers in parallel ----
+    unsigned long long arrivals = __ballot(moved && (ev.flags & F_COLLECT));
+    while (arrivals) {
+      const int src = __ffsll((long long)arrivals) - 1;
+      arrivals &= arrivals - 1ull;
+      collect_wave<KIND>(a, T, p, ev.vel, src, lane, st);
+    }
+
+    // ---- second half: scatter / reflect-transmit / bend / hand-over ----
+    if (moved) fate = step_event<KIND>(a, T, p, rng, st, ev);
+
+    if (alive && fate != FATE_ALIVE) {
+      alive = false;
+      if (fate == FATE_LOST) n_lost++;
+      else if (fate == FATE_TIMEOUT) n_timeout++;
+      else {
 #pragma unroll
-          for (int r = 0; r < R3D_INV_NUM; r++) inv[r] += (r == reason);
-        }
-        if (TRACE) {
-          r3d_final* f = reinterpret_cast<r3d_final*>(a.finals) + (my_id - a.first_id);
-          f->time = p.t, f->path = p.path, f->amp = p.amp;
-          f->loc[0] = p.loc.x, f->loc[1] = p.loc.y, f->loc[2] = p.loc.z;
-          f->dir[0] = p.dir.x, f->dir[1] = p.dir.y, f->dir[2] = p.dir.z;
-          f->moves = p.moves;
-          f->fate = (uint8_t)fate;
-          f->type = (uint8_t)p.type;
-          uint32_t nc = st.n_catch - catch_at_start;
-          f->n_catch = (uint16_t)(nc > 65535u ? 65535u : nc);
-        }
+        for (int r = 0; r < R3D_INV_NUM; r++) inv[r] += (r == reason);
+      }
+      if (TRACE) {
+        r3d_final* f = reinterpret_cast<r3d_final*>(a.finals) + (my_id - a.first_id);
+        f->time = p.t, f->path = p.path, f->amp = p.amp;
+        f->loc[0] = p.loc.x, f->loc[1] = p.loc.y, f->loc[2] = p.loc.z;
+        f->dir[0] = p.dir.x, f->dir[1] = p.dir.y, f->dir[2] = p.dir.z;
+        f->moves = p.moves;
+        f->fate = (uint8_t)fate;
+        f->type = (uint8_t)p.type;
+        uint32_t nc = st.n_catch - catch_at_start;
+        f->n_catch = (uint16_t)(nc > 65535u ? 65535u : nc);
       }
     }
   }
@@ -340,13 +436,19 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
     default: a.cells = upload_vec(e.get(), pm.sph, &err);
   }
   for (int s = 0; s < m->n_scatterers; s++) {
-    for (int k = 0; k < 4; k++) pm.scat_ptrs[s].cdf[k] = upload_doubles(e.get(), m->scatterers[s].cdf[k], m->n_toa, &err);
+    for (int k = 0; k < 4; k++) {
+      pm.scat_ptrs[s].cdf[k] = upload_doubles(e.get(), m->scatterers[s].cdf[k], m->n_toa, &err);
+      pm.scat_ptrs[s].guide[k] = upload_vec(e.get(), pm.scat_guide[s * 4 + k], &err);
+    }
     pm.scat_ptrs[s].spol = upload_doubles(e.get(), m->scatterers[s].spol, m->n_toa, &err);
   }
   a.scat_head = upload_vec(e.get(), pm.scat_head, &err);
   a.scat_ptrs = upload_vec(e.get(), pm.scat_ptrs, &err);
   a.toa_xyz = upload_vec(e.get(), pm.toa_xyz, &err);
-  for (int k = 0; k < 3; k++) a.src_cdf[k] = upload_doubles(e.get(), m->source.cdf[k], m->n_toa, &err);
+  for (int k = 0; k < 3; k++) {
+    a.src_cdf[k] = upload_doubles(e.get(), m->source.cdf[k], m->n_toa, &err);
+    a.src_guide[k] = upload_vec(e.get(), pm.src_guide[k], &err);
+  }
   a.seis_scan = upload_vec(e.get(), pm.seis_scan, &err);
   a.seis_hit = upload_vec(e.get(), pm.seis_hit, &err);
   a.grid.start = upload_vec(e.get(), pm.grid_start, &err);

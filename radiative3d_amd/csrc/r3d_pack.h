@@ -26,6 +26,8 @@ struct PackedModel {
   std::vector<SeisScan> seis_scan;
   std::vector<SeisHit> seis_hit;
   std::vector<uint32_t> grid_start, grid_items;
+  std::vector<std::vector<uint32_t>> src_guide;    // [3]
+  std::vector<std::vector<uint32_t>> scat_guide;   // [n_scat * 4]
   KArgs args;                        // pointers refer to the vectors above / the model
   size_t cell_bytes() const {
     return cyl.size() * sizeof(CellCyl) + tet.size() * sizeof(CellTet) + sph.size() * sizeof(CellSph);
@@ -104,6 +106,27 @@ inline void build_seis_grid(const r3d_model_desc& m, SeisGrid& g, std::vector<ui
   if (items.empty()) items.push_back(0);
 }
 
+// Search guide of a cumulative table: guide[j] = smallest k with
+// total * (j / G) <= cdf[k], j = 0..G.  A draw u in [j/G, (j+1)/G) has its
+// answer inside [guide[j], guide[j+1]], so the bisection starts from a bracket
+// of ~n/G entries instead of n, and returns the identical index.
+inline void build_guide(const double* cdf, uint64_t n, uint32_t bits, std::vector<uint32_t>& g) {
+  const uint64_t G = 1ull << bits;
+  g.resize(G + 1);
+  const double total = cdf[n - 1];
+  uint64_t k = 0;
+  for (uint64_t j = 0; j <= G; j++) {
+    const double r = total * ((double)j / (double)G);
+    while (k < n - 1 && !(r <= cdf[k])) k++;
+    g[j] = (uint32_t)k;
+  }
+}
+inline uint32_t guide_bits_for(uint64_t n_toa) {
+  uint32_t bits = 4;
+  while (bits < 16 && (1ull << (bits + 5)) < n_toa) bits++;   // ~32 entries per bracket, at most 2^16
+  return bits;
+}
+
 inline void pack_model(const r3d_model_desc& m, PackedModel& pm) {
   KArgs& a = pm.args;
   std::memset(&a, 0, sizeof a);
@@ -177,6 +200,9 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm) {
   a.n_cells = m.n_cells;
 
   // ---- scatterers ----
+  a.guide_bits = guide_bits_for(m.n_toa);
+  pm.scat_guide.assign((size_t)m.n_scatterers * 4, {});
+  pm.src_guide.assign(3, {});
   pm.scat_head.resize(m.n_scatterers);
   pm.scat_ptrs.resize(m.n_scatterers);
   for (int s = 0; s < m.n_scatterers; s++) {
@@ -185,7 +211,12 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm) {
       pm.scat_head[s].mfp[t] = S.mfp[t];
       for (int k = 0; k < 4; k++) pm.scat_head[s].whole[t][k] = S.whole_cdf[t][k];
     }
-    for (int k = 0; k < 4; k++) pm.scat_ptrs[s].cdf[k] = S.cdf[k];
+    for (int k = 0; k < 4; k++) {
+      pm.scat_ptrs[s].cdf[k] = S.cdf[k];
+      pm.scat_head[s].total[k] = S.cdf[k][m.n_toa - 1];
+      build_guide(S.cdf[k], m.n_toa, a.guide_bits, pm.scat_guide[s * 4 + k]);
+      pm.scat_ptrs[s].guide[k] = pm.scat_guide[s * 4 + k].data();
+    }
     pm.scat_ptrs[s].spol = S.spol;
   }
   a.scat_head = pm.scat_head.data();
@@ -212,6 +243,9 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm) {
   // ---- source ----
   for (int k = 0; k < 3; k++) {
     a.src_cdf[k] = m.source.cdf[k];
+    a.src_total[k] = m.source.cdf[k][m.n_toa - 1];
+    build_guide(m.source.cdf[k], m.n_toa, a.guide_bits, pm.src_guide[k]);
+    a.src_guide[k] = pm.src_guide[k].data();
     a.src_whole[k] = m.source.whole_cdf[k];
     a.src_loc[k] = m.source.loc[k];
     a.earth_center[k] = par.earth_center[k];

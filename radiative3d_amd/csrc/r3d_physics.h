@@ -353,6 +353,15 @@ enum { R_P, R_SV, R_SH, T_P, T_SV, T_SH, RT_NUM };
 // Phonon::Refraction_FullRT (phonons.cpp:429-476), CellFace::GetRTBasis
 // (media_cellface.cpp:122-149), RTCoef (rtcoef.cpp:30-588).
 // Returns true if the phonon crossed into the neighbour.
+//
+// The outcome is chosen from weights w_k = rho_k v_k Re(cos_k) |A_k|^2.  Every
+// amplitude is a numerator over the same determinant (D for P-SV, a+b for SH),
+// and the chooser (rtcoef.cpp:436-475) only compares u * sum(w) with partial
+// sums, so the common 1/|D|^2 is dropped: the weights here are |D|^2 times the
+// reference's, which selects the same outcome with ~4 reciprocals instead of
+// ~20 fp64 divisions.  A vanishing or non-finite determinant gives the
+// reference a NaN total and hence its default choice; that case is tested
+// explicitly.
 R3D_HD bool full_rt(Phonon& p, Iface f, Rng& rng) {
   const V3 fnorm = f.normal;
   const V3 fpara = in_plane_unit_perp(fnorm, p.dir);
@@ -370,83 +379,84 @@ R3D_HD bool full_rt(Phonon& p, Iface f, Rng& rng) {
   }
   const double rho1 = f.rhoR, rho2 = f.rhoT;
   const double a1 = f.vR[0], a2 = f.vT[0], b1 = f.vR[1], b2 = f.vT[1];
-  double sino[RT_NUM], cosre[RT_NUM], prob[RT_NUM];
-#pragma unroll
-  for (int i = 0; i < RT_NUM; i++) sino[i] = 0, cosre[i] = 0, prob[i] = 0;
+  // outcome order R_P, R_SV, R_SH, T_P, T_SV, T_SH (rtcoef.hpp:79-87)
+  double w[RT_NUM] = {0, 0, 0, 0, 0, 0};
+  double sn[RT_NUM] = {0, 0, 0, 0, 0, 0};   // sine of each outgoing angle
+  double cr[RT_NUM] = {0, 0, 0, 0, 0, 0};   // real part of each outgoing cosine
+  double det2;                              // |determinant|^2
   int defchoice;
   if (intype == 1) {  // GetCoefs_SH, rtcoef.cpp:207-278
     defchoice = R_SH;
-    sino[R_SH] = sini;
-    sino[T_SH] = (b2 / b1) * sini;
-    Cx cj1 = sqrt_real(1.0 - sino[R_SH] * sino[R_SH]);
-    Cx cj2 = sqrt_real(1.0 - sino[T_SH] * sino[T_SH]);
-    Cx a = (rho1 * b1) * cj1, b = (rho2 * b2) * cj2;
-    Cx ar = (a - b) / (a + b), at = (2.0 * a) / (a + b);
-    cosre[R_SH] = cj1.re, cosre[T_SH] = cj2.re;
-    prob[R_SH] = rho1 * b1 * cj1.re * norm(ar);
-    prob[T_SH] = rho2 * b2 * cj2.re * norm(at);
+    sn[R_SH] = sini;
+    sn[T_SH] = (b2 / b1) * sini;
+    const Cx cj1 = sqrt_real(1.0 - sn[R_SH] * sn[R_SH]);
+    const Cx cj2 = sqrt_real(1.0 - sn[T_SH] * sn[T_SH]);
+    const Cx a = (rho1 * b1) * cj1, b = (rho2 * b2) * cj2;
+    cr[R_SH] = cj1.re, cr[T_SH] = cj2.re;
+    det2 = norm(a + b);
+    w[R_SH] = rho1 * b1 * cj1.re * norm(a - b);
+    w[T_SH] = rho2 * b2 * cj2.re * (4.0 * norm(a));
   } else {  // GetCoefs_PSV, rtcoef.cpp:107-198, :289-393
     const bool in_p = (intype == 0);
     defchoice = in_p ? R_P : R_SV;
-    const double pp = sini / (in_p ? a1 : b1);  // horizontal slowness
-    sino[T_P] = a2 * pp, sino[T_SV] = b2 * pp, sino[R_SV] = b1 * pp, sino[R_P] = a1 * pp;
-    const Cx cTP = sqrt_real(1.0 - sino[T_P] * sino[T_P]);
-    const Cx cTS = sqrt_real(1.0 - sino[T_SV] * sino[T_SV]);
-    const Cx cRS = sqrt_real(1.0 - sino[R_SV] * sino[R_SV]);
-    const Cx cRP = sqrt_real(1.0 - sino[R_P] * sino[R_P]);
-    cosre[T_P] = cTP.re, cosre[T_SV] = cTS.re, cosre[R_SV] = cRS.re, cosre[R_P] = cRP.re;
+    const double ia1 = 1.0 / a1, ia2 = 1.0 / a2, ib1 = 1.0 / b1, ib2 = 1.0 / b2;
+    const double pp = sini * (in_p ? ia1 : ib1);  // horizontal slowness
+    sn[T_P] = a2 * pp, sn[T_SV] = b2 * pp, sn[R_SV] = b1 * pp, sn[R_P] = a1 * pp;
+    const Cx cTP = sqrt_real(1.0 - sn[T_P] * sn[T_P]);
+    const Cx cTS = sqrt_real(1.0 - sn[T_SV] * sn[T_SV]);
+    const Cx cRS = sqrt_real(1.0 - sn[R_SV] * sn[R_SV]);
+    const Cx cRP = sqrt_real(1.0 - sn[R_P] * sn[R_P]);
+    cr[T_P] = cTP.re, cr[T_SV] = cTS.re, cr[R_SV] = cRS.re, cr[R_P] = cRP.re;
     const double b1s = b1 * b1, b2s = b2 * b2, psq = pp * pp;
     const double t1 = rho1 * (1. - 2. * b1s * psq), t2 = rho2 * (1. - 2. * b2s * psq);
     const double t3 = 2. * rho1 * b1s, t4 = 2. * rho2 * b2s;
     const double a = t2 - t1, b = t2 + t3 * psq, c = t1 + t4 * psq, d = t4 - t3;
-    const Cx ci1 = cRP / a1, ci2 = cTP / a2, cj1 = cRS / b1, cj2 = cTS / b2;
+    const Cx ci1 = ia1 * cRP, ci2 = ia2 * cTP, cj1 = ib1 * cRS, cj2 = ib2 * cTS;
     const Cx E = b * ci1 + c * ci2, F = b * cj1 + c * cj2;
     const Cx G = a - (d * ci1) * cj2, H = a - (d * ci2) * cj1;
     const Cx D = E * F + (G * H) * psq;
-    Cx aRP, aRS, aTP, aTS, T1, T2;
+    det2 = norm(D);
+    Cx nRP, nRS, nTP, nTS;   // amplitude numerators (times the velocity ratio factors below)
     if (in_p) {
-      T1 = b * ci1 - c * ci2;
-      T2 = a + (d * ci1) * cj2;
-      aRP = (T1 * F - (T2 * H) * psq) / D;
-      T1 = (a * b) + ((c * d) * ci2) * cj2;
-      aRS = ((((-2.0) * ci1) * T1) * pp * a1) / (b1 * D);
-      T1 = (2.0 * rho1) * ci1 * a1;
-      aTP = (T1 * F) / (a2 * D);
-      aTS = ((T1 * H) * pp) / (b2 * D);
+      nRP = (b * ci1 - c * ci2) * F - ((a + (d * ci1) * cj2) * H) * psq;
+      nRS = ((-2.0 * pp * a1) * ci1) * ((a * b) + ((c * d) * ci2) * cj2);
+      const Cx T1 = (2.0 * rho1 * a1) * ci1;
+      nTP = T1 * F;
+      nTS = (T1 * H) * pp;
     } else {
-      T1 = (a * b) + ((c * d) * ci2) * cj2;
-      aRP = ((((-2.0) * cj1) * T1) * pp * b1) / (a1 * D);
-      T1 = b * cj1 - c * cj2;
-      T2 = a + (d * ci2) * cj1;
-      aRS = -((T1 * E - (T2 * G) * psq) / D);
-      T1 = (2.0 * rho1) * cj1 * b1;
-      aTP = -(((T1 * G) * pp) / (a2 * D));
-      aTS = (T1 * E) / (b2 * D);
+      nRP = ((-2.0 * pp * b1) * cj1) * ((a * b) + ((c * d) * ci2) * cj2);
+      nRS = (b * cj1 - c * cj2) * E - ((a + (d * ci2) * cj1) * G) * psq;
+      const Cx T1 = (2.0 * rho1 * b1) * cj1;
+      nTP = (T1 * G) * pp;
+      nTS = T1 * E;
     }
-    prob[R_P] = rho1 * a1 * cRP.re * norm(aRP);
-    prob[R_SV] = rho1 * b1 * cRS.re * norm(aRS);
-    prob[T_P] = rho2 * a2 * cTP.re * norm(aTP);
-    prob[T_SV] = rho2 * b2 * cTS.re * norm(aTS);
+    // |A|^2 |D|^2: R_P and R_SV numerators carry 1/b1 resp. 1/a1 when the type converts,
+    // the transmitted ones 1/a2, 1/b2 (rtcoef.cpp:150-186)
+    const double sRP = in_p ? 1.0 : ia1 * ia1, sRS = in_p ? ib1 * ib1 : 1.0;
+    w[R_P] = rho1 * a1 * cRP.re * (norm(nRP) * sRP);
+    w[R_SV] = rho1 * b1 * cRS.re * (norm(nRS) * sRS);
+    w[T_P] = rho2 * a2 * cTP.re * (norm(nTP) * (ia2 * ia2));
+    w[T_SV] = rho2 * b2 * cTS.re * (norm(nTS) * (ib2 * ib2));
   }
   // Choose, rtcoef.cpp:436-475
   double cum[RT_NUM];
-  cum[0] = prob[0];
+  cum[0] = w[0];
 #pragma unroll
-  for (int i = 1; i < RT_NUM; i++) cum[i] = cum[i - 1] + prob[i];
+  for (int i = 1; i < RT_NUM; i++) cum[i] = cum[i - 1] + w[i];
   const double total = cum[RT_NUM - 1];
   const double ran = rng_draw(rng) * total;
   int choice = RT_NUM - 1;
 #pragma unroll
   for (int i = RT_NUM - 2; i >= 0; i--)
     if (ran <= cum[i]) choice = i;   // ends on the FIRST i with ran <= cum[i]
-  if (total == 0 || (total - total) != 0) choice = defchoice;
+  if (total == 0 || (total - total) != 0 || !(det2 > 0) || (det2 - det2) != 0) choice = defchoice;
   if (no_transmit && choice >= T_P) choice -= 3;  // T_x -> R_x
   const bool reflected = choice < T_P;
   // GetChosenRayDirection, rtcoef.cpp:529-548
   double comp_para = 0, comp_norm = 0;
 #pragma unroll
   for (int i = 0; i < RT_NUM; i++)
-    if (i == choice) comp_para = sino[i], comp_norm = cosre[i];
+    if (i == choice) comp_para = sn[i], comp_norm = cr[i];
   if (comp_para > 1.0) comp_para = 1.0;
   if (reflected) comp_norm = -comp_norm;
   V3 out = comp_para * fpara + comp_norm * fnorm;
@@ -498,6 +508,22 @@ R3D_HD bool bend(Phonon& p, V3 fnorm, double veli, double velo) {
 R3D_HD uint64_t sample_cdf(const double* __restrict__ cdf, uint64_t n, double u) {
   uint64_t k1 = 0, k2 = n - 1;
   const double r = cdf[k2] * u;
+  while (k1 != k2) {
+    uint64_t k = (k1 + k2) >> 1;
+    if (r <= cdf[k]) k2 = k;
+    else k1 = k + 1;
+  }
+  return k2;
+}
+// The same draw with a search guide (r3d_pack.h build_guide): identical result,
+// ~5 probes into one or two cache lines instead of ceil(log2 n) dependent probes
+// scattered over the whole table.
+R3D_HD uint64_t sample_cdf_guided(const double* __restrict__ cdf, const uint32_t* __restrict__ guide,
+                                  uint32_t bits, double total, double u) {
+  const double r = total * u;
+  uint32_t j = (uint32_t)(u * (double)(1u << bits));
+  if (j > (1u << bits) - 1u) j = (1u << bits) - 1u;
+  uint64_t k1 = guide[j], k2 = guide[j + 1];
   while (k1 != k2) {
     uint64_t k = (k1 + k2) >> 1;
     if (r <= cdf[k]) k2 = k;

@@ -68,7 +68,12 @@ R3D_HD int cell_neighbor(const CellSph& c, int f) { return c.nbr[f]; }
 // ---- source spray ----------------------------------------------------------
 R3D_HD void spray(const KArgs& a, Phonon& p, Rng& rng) {
   int rt3 = sample_small(a.src_whole, 3, rng_draw(rng));            // 0 P, 1 SH, 2 SV
-  uint64_t k = sample_cdf(a.src_cdf[rt3], a.n_toa, rng_draw(rng));
+#ifdef R3D_ABLATE_SPRAY_SEARCH
+  uint64_t k = (uint64_t)(rng_draw(rng) * (double)(a.n_toa - 1));
+#else
+  uint64_t k = sample_cdf_guided(a.src_cdf[rt3], a.src_guide[rt3], a.guide_bits, a.src_total[rt3],
+                                 rng_draw(rng));
+#endif
   p.t = p.path = p.recent = 0.0;
   p.amp = 1.0;
   p.moves = 0;
@@ -128,12 +133,21 @@ R3D_HD void collect(const KArgs& a, const Tables<KIND>& T, const Phonon& p, doub
   }
 }
 
-// ---- one loop iteration ----------------------------------------------------
-// Returns FATE_ALIVE to continue, else the fate; *reason gets the invalid
-// reason slot (include/r3d.h R3D_INV_*) when FATE_INVALID.
+// ---- one loop iteration, in two halves --------------------------------------
+// What the first half leaves for the second.
+struct Pending {
+  double vel;        // phonon's velocity at the arrival point (for the seismometers)
+  int32_t face;      // face reached, or -1 if the phonon scattered inside the cell
+  uint32_t flags;    // that face's flags
+};
+
+// First half (phonons.cpp:549-623): termination checks, boundary search,
+// free-path draw, advance + Move.  Returns FATE_ALIVE to continue with
+// step_event(), else the fate; *reason gets the invalid-reason slot
+// (include/r3d.h R3D_INV_*) when FATE_INVALID.
 template <int KIND>
-R3D_HD int step(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng, LaneStats& st,
-                int* reason) {
+R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng, LaneStats& st,
+                     int* reason, Pending& ev) {
   using Cell = typename CellOf<KIND>::type;
   // phonons.cpp:549-552
   if (p.t > a.ttl) return FATE_TIMEOUT;
@@ -168,8 +182,7 @@ R3D_HD int step(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng, Lane
 
   // --- free path to the next scattering event, drawn afresh every iteration
   //     (scatterers.cpp:297-307, phonons.cpp:601)
-  const ScatHead& sh = T.scat_head[c.scat];
-  const double scatlen = -log(rng_draw(rng)) * sh.mfp[p.type];
+  const double scatlen = -log(rng_draw(rng)) * T.scat_head[c.scat].mfp[p.type];
   const bool scatters = scatlen < e.len;
   const double len = scatters ? scatlen : e.len;
 
@@ -178,62 +191,85 @@ R3D_HD int step(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng, Lane
   else if constexpr (KIND == CELL_TET) tet_advance(c, tarc, p, len);
   else sph_advance(c, sarc, p, len);
 
-  if (scatters) {
+  ev.face = scatters ? -1 : e.face;
+  ev.flags = scatters ? 0u : face_flags(c.flags, e.face);
+  ev.vel = cell_velocity(c, p.loc, p.type);
+  return FATE_ALIVE;
+}
+
+// Second half (phonons.cpp:611-618, :640-676): scatter, or act on the face
+// reached.  Seismometer collection (phonons.cpp:629-631) happens BETWEEN the
+// halves, with the incident state: per lane in step(), wave-cooperatively in
+// the kernel.
+template <int KIND>
+R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng, LaneStats& st,
+                      const Pending& ev) {
+  using Cell = typename CellOf<KIND>::type;
+  const Cell& c = T.cells[p.cell];
+  if (ev.face < 0) {
     // Scatterer::GetRandomScatteredRelativePhonon, scatterers.cpp:318-363
     st.scatter++;
     if (a.no_deflect) {
       scatter_transform(p, v3(a.nodeflect_dir), 0.0, p.type);
     } else {
+      const ScatHead& sh = T.scat_head[c.scat];
       const ScatPtrs sp = a.scat_ptrs[c.scat];
       int conv = sample_small(sh.whole[p.type], 4, rng_draw(rng));  // GPP GPS GSP GSS
-      uint64_t k = sample_cdf(sp.cdf[conv], a.n_toa, rng_draw(rng));
+      uint64_t k = sample_cdf_guided(sp.cdf[conv], sp.guide[conv], a.guide_bits, sh.total[conv],
+                                     rng_draw(rng));
       double rpol = (conv == 3) ? sp.spol[k] : 0.0;
       scatter_transform(p, v3(a.toa_xyz + 3 * k), rpol, (conv & 1) ? RAY_S : RAY_P);
     }
     return FATE_ALIVE;
   }
-
-  // --- at a cell face (phonons.cpp:629-676)
-  const uint32_t fl = face_flags(c.flags, e.face);
-  if (fl & F_COLLECT) collect<KIND>(a, T, p, cell_velocity(c, p.loc, p.type), st);
-  if (fl & (F_REFLECT | F_ADJOIN)) {
-    const int nbr = cell_neighbor(c, e.face);
-    const bool adjoin = (fl & F_ADJOIN) != 0;
-    bool crossed;
-    if ((fl & F_REFLECT) || (fl & F_DISCON)) {
-      Iface f;
-      f.normal = cell_face_normal(c, e.face, p.loc);
-      f.vR[0] = cell_velocity(c, p.loc, 0), f.vR[1] = cell_velocity(c, p.loc, 1);
-      f.rhoR = cell_density(a, c, p.cell, p.loc);
-      f.has_neighbor = adjoin;
-      f.vT[0] = f.vT[1] = f.rhoT = 0;
-      if (adjoin) {
-        const Cell& o = T.cells[nbr];
-        f.vT[0] = cell_velocity(o, p.loc, 0), f.vT[1] = cell_velocity(o, p.loc, 1);
-        f.rhoT = cell_density(a, o, nbr, p.loc);
-      }
-      st.rtsolve++;
-      crossed = full_rt(p, f, rng);
-    } else {
-      // Phonon::Refract without a grid discontinuity (phonons.cpp:243-252):
-      // bend on a fractional velocity step > 1e-5, else plain hand-over.
+  const uint32_t fl = ev.flags;
+  if (!(fl & (F_REFLECT | F_ADJOIN))) return FATE_LOST;  // phonons.cpp:675
+  const int nbr = cell_neighbor(c, ev.face);
+  const bool adjoin = (fl & F_ADJOIN) != 0;
+  bool crossed;
+  if ((fl & F_REFLECT) || (fl & F_DISCON)) {
+    Iface f;
+    f.normal = cell_face_normal(c, ev.face, p.loc);
+    f.vR[0] = cell_velocity(c, p.loc, 0), f.vR[1] = cell_velocity(c, p.loc, 1);
+    f.rhoR = cell_density(a, c, p.cell, p.loc);
+    f.has_neighbor = adjoin;
+    f.vT[0] = f.vT[1] = f.rhoT = 0;
+    if (adjoin) {
       const Cell& o = T.cells[nbr];
-      double v1 = cell_velocity(c, p.loc, 0), v2 = cell_velocity(o, p.loc, 0);
-      double dvp = fabs(2 * (v2 - v1) / (v2 + v1));
-      double w1 = cell_velocity(c, p.loc, 1), w2 = cell_velocity(o, p.loc, 1);
-      double dvs = fabs(2 * (w2 - w1) / (w2 + w1));
-      if ((dvp > dvs ? dvp : dvs) > 0.00001) {
-        crossed = bend(p, cell_face_normal(c, e.face, p.loc), p.type == RAY_P ? v1 : w1,
-                       p.type == RAY_P ? v2 : w2);
-      } else {
-        crossed = true;
-      }
+      f.vT[0] = cell_velocity(o, p.loc, 0), f.vT[1] = cell_velocity(o, p.loc, 1);
+      f.rhoT = cell_density(a, o, nbr, p.loc);
     }
-    if (crossed) p.cell = nbr, st.transfer++;
-    else st.reflect++;
-    return FATE_ALIVE;
+    st.rtsolve++;
+    crossed = full_rt(p, f, rng);
+  } else {
+    // Phonon::Refract without a grid discontinuity (phonons.cpp:243-252):
+    // bend on a fractional velocity step > 1e-5, else plain hand-over.
+    const Cell& o = T.cells[nbr];
+    double v1 = cell_velocity(c, p.loc, 0), v2 = cell_velocity(o, p.loc, 0);
+    double dvp = fabs(2 * (v2 - v1) / (v2 + v1));
+    double w1 = cell_velocity(c, p.loc, 1), w2 = cell_velocity(o, p.loc, 1);
+    double dvs = fabs(2 * (w2 - w1) / (w2 + w1));
+    if ((dvp > dvs ? dvp : dvs) > 0.00001) {
+      crossed = bend(p, cell_face_normal(c, ev.face, p.loc), p.type == RAY_P ? v1 : w1,
+                     p.type == RAY_P ? v2 : w2);
+    } else {
+      crossed = true;
+    }
   }
-  return FATE_LOST;  // phonons.cpp:675
+  if (crossed) p.cell = nbr, st.transfer++;
+  else st.reflect++;
+  return FATE_ALIVE;
+}
+
+// The whole iteration for one work-item on its own (host emulation).
+template <int KIND>
+R3D_HD int step(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng, LaneStats& st,
+                int* reason) {
+  Pending ev;
+  int fate = step_move<KIND>(a, T, p, rng, st, reason, ev);
+  if (fate != FATE_ALIVE) return fate;
+  if (ev.flags & F_COLLECT) collect<KIND>(a, T, p, ev.vel, st);
+  return step_event<KIND>(a, T, p, rng, st, ev);
 }
 
 }  // namespace r3d

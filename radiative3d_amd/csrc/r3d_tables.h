@@ -69,10 +69,12 @@ struct RhoLin {       // density side table for tetra cells
 struct ScatHead {     // small per-scatterer record, staged in LDS
   double mfp[2];
   double whole[2][4]; // cumulative conversion weights for incoming P / S
+  double total[4];    // cdf[k][n_toa-1]
 };
 struct ScatPtrs {     // HBM-resident tables of one scatterer
   const double* cdf[4];
   const double* spol;
+  const uint32_t* guide[4];  // search guides of the four CDFs (see sample_cdf_guided)
 };
 
 // ---- seismometers ----------------------------------------------------------
@@ -110,6 +112,10 @@ struct KArgs {
   uint64_t n_toa;
   const double* toa_xyz;     // n_toa x 3, theta already nudged
   const double* src_cdf[3];
+  const uint32_t* src_guide[3];
+  double src_total[3];       // src_cdf[k][n_toa-1]
+  uint32_t guide_bits;       // guides have 2^guide_bits + 1 entries
+  uint32_t pad0_;
   double src_whole[3];
   double src_loc[3];
   int32_t src_cell;
