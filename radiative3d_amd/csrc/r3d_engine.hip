@@ -63,7 +63,8 @@ __device__ __forceinline__ void collect_wave(const KArgs& a, const Tables<KIND>&
                                              double vel_lane, int src_lane, unsigned lane, LaneStats& st) {
   const int src = __builtin_amdgcn_readfirstlane(src_lane);
   const V3 loc = bcast(p.loc, src), dir = bcast(p.dir, src);
-  const double t = bcast(p.t, src), amp = bcast(p.amp, src), pol = bcast(p.pol, src);
+  const double t = bcast(p.t, src), amp = bcast(p.amp, src);
+  const double pc = bcast(p.pc, src), ps = bcast(p.ps, src);
   const double vel = bcast(vel_lane, src);
   const int type = __builtin_amdgcn_readlane(p.type, src);
   if ((int)lane == src) st.collect++;
@@ -79,9 +80,7 @@ __device__ __forceinline__ void collect_wave(const KArgs& a, const Tables<KIND>&
   if (type != RAY_P) {
     V3 th, ph;
     sph_basis(dir, th, ph);
-    double s, c;
-    sincos(pol, &s, &c);
-    dopm = c * th + s * ph;
+    dopm = pc * th + ps * ph;
   }
   uint32_t hits = 0;
   for (uint32_t kb = k0; kb < k1; kb += 64u) {
@@ -201,6 +200,9 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
     // ---- seismometers: the wave serves its arriving lanes one at a time, all 64
     //      lanes testing candidate receivers in parallel ----
     unsigned long long arrivals = __ballot(moved && (ev.flags & F_COLLECT));
+#ifdef R3D_ABLATE_COLLECT  // timing-only developer build
+    arrivals = 0ull;
+#endif
     while (arrivals) {
       const int src = __ffsll((long long)arrivals) - 1;
       arrivals &= arrivals - 1ull;

@@ -32,7 +32,7 @@ enum { FATE_ALIVE = 0, FATE_LOST = 1, FATE_TIMEOUT = 2, FATE_INVALID = 3 };
 struct Phonon {            // reference phonons.hpp:69-126
   double t, path, recent, amp;
   V3 loc, dir;
-  double pol;
+  double pc, ps;           // cos, sin of the polarisation angle mPol (the angle itself is never needed)
   int32_t type, cell;
   uint32_t moves;
 };
@@ -51,16 +51,22 @@ R3D_HD V3 direction_of_motion(const Phonon& p) {
   if (p.type == RAY_P) return p.dir;
   V3 th, ph;
   sph_basis(p.dir, th, ph);
-  double s, c;
-  sincos(p.pol, &s, &c);
-  return c * th + s * ph;
+  return p.pc * th + p.ps * ph;
 }
-// Polarisation angle of particle motion `pdom` about direction d
-// (phonons.cpp:389-391, :462-465).
-R3D_HD double pol_angle(V3 pdom, V3 d) {
+// Polarisation of particle motion `pdom` about direction d: the reference
+// stores atan2(pdom.phi^, pdom.theta^) (phonons.cpp:389-391, :462-465) and
+// later takes its cosine and sine; this yields those two directly.
+R3D_HD void set_pol(Phonon& p, V3 pdom, V3 d) {
   V3 th, ph;
   sph_basis(d, th, ph);
-  return atan2(dot(pdom, ph), dot(pdom, th));
+  const double x = dot(pdom, th), y = dot(pdom, ph);
+  const double h = sqrt(x * x + y * y);
+  if (h == 0) {
+    p.pc = 1.0, p.ps = 0.0;   // atan2(0, 0) = 0
+  } else {
+    const double ih = 1.0 / h;
+    p.pc = x * ih, p.ps = y * ih;
+  }
 }
 
 // ===================================================================== CYL ==
@@ -110,10 +116,19 @@ R3D_HD void cyl_advance(const CellCyl& c, Phonon& p, double len) {
 // Frame in which the ray through a linear-velocity cell is a circle about the
 // origin of the (x,z) plane (reference CoordinateTransformation,
 // media.hpp:560-587): rows v1,v2,v3; `trans` is the arc centre in the rotated
-// frame; the phonon sits at angle a0 measured from +z towards +x.
+// frame; the phonon sits at angle a0 measured from +z towards +x, always in
+// [-pi/2, pi/2] (cos a0 = t.v1 >= 0); velocity is |g| R cos a along the arc.
+//
+// ANGLES ARE NEVER FORMED.  Every angle the reference compares
+// (media_cellface.cpp:333-426, :767-794, media.cpp:542-559) is either +-inf or
+// lies in (-pi/2, pi/2), where sin is monotone; so each is represented by its
+// sine (with +-inf kept as +-inf) and all orderings carry over.  Only the arc
+// length of the chosen exit needs an angle (one atan2 of the sine / cosine of
+// the difference), and the end point of a boundary leg is the exit point
+// itself, so its sine / cosine are already known.
 struct TetArc {
   V3 v1, v2, v3, trans;
-  double R, a0, s0, c0;   // radius, start angle and its sine / cosine
+  double R, s0, c0;   // radius, sine / cosine of the start angle
 };
 R3D_HD TetArc tet_arc(const CellTet& c, const Phonon& p) {
   TetArc A;
@@ -127,15 +142,17 @@ R3D_HD TetArc tet_arc(const CellTet& c, const Phonon& p) {
   V3 x0 = v3(dot(A.v1, p.loc), dot(A.v2, p.loc), dot(A.v3, p.loc));
   A.trans = v3(x0.x + A.R * tzp, x0.y, x0.z - A.R * txp);
   double px = x0.x - A.trans.x, pz = x0.z - A.trans.z;  // phonon in the centred frame
-  A.a0 = atan2(px, pz);
   double h = 1.0 / sqrt(px * px + pz * pz);
   A.s0 = px * h, A.c0 = pz * h;
   return A;
 }
-// Entry / exit / bisector angles of one plane against the arc circle
-// (reference PlaneFace::GetCircArcDistToFace, media_cellface.cpp:333-426).
+// One plane against the arc circle, in sine space (reference
+// PlaneFace::GetCircArcDistToFace, media_cellface.cpp:333-426): the arc is
+// outside the face between the exit angle bis - q and the entry angle bis + q,
+// bis = direction of the in-plane normal, cos q = (centre-to-trace distance)/R.
 struct Gcad {
-  double entry, exit, half;
+  double entry, exit, half;   // sines of the angles, or +-inf
+  double entry_cos, exit_cos; // cosines of entry / exit where those are finite
   bool continuous;
 };
 R3D_HD Gcad tet_face_arc(const double n[3], double dplane, const TetArc& A) {
@@ -143,63 +160,71 @@ R3D_HD Gcad tet_face_arc(const double n[3], double dplane, const TetArc& A) {
   V3 nn = v3(n);
   V3 rn = v3(dot(nn, A.v1), dot(nn, A.v2), dot(nn, A.v3));
   double rho = sqrt(rn.x * rn.x + rn.z * rn.z);
-  double D = (dplane - dot(rn, A.trans)) / rho;   // centre-to-trace distance along the in-plane normal
   double ir = 1.0 / rho;
-  double bis = atan2(rn.x * ir, rn.z * ir);
-  double en = 0, ex = 0;
-  bool cont = true;
-  const double ratio = D / A.R;
+  const double sb = rn.x * ir, cb = rn.z * ir;              // sin, cos of the bisector angle
+  const double ratio = ((dplane - dot(rn, A.trans)) * ir) / A.R;   // cos q
+  Gcad g;
+  g.entry = 0, g.exit = 0, g.entry_cos = 1, g.exit_cos = 1, g.continuous = true;
+  const bool front = cb > 0;            // bisector within (-pi/2, pi/2)
   if (ratio < 1 && ratio > -1) {
-    double q = acos(ratio);
-    if (bis > -kPi90 && bis < kPi90) {
-      en = bis + q, ex = bis - q, cont = false;
-    } else if (bis <= -kPi90) {
-      en = bis + q, ex = bis - q + kPi360;
-    } else if (bis >= kPi90) {
-      en = bis + q - kPi360, ex = bis - q;
-    } else {
-      en = ex = bis;  // NaN bisector: the reference exit(1)s here; let it propagate
-    }
+    const double sq = sqrt(1.0 - ratio * ratio);             // sin q > 0
+    const double se = sb * ratio + cb * sq, ce = cb * ratio - sb * sq;   // entry = bis + q
+    const double sx = sb * ratio - cb * sq, cx = cb * ratio + sb * sq;   // exit  = bis - q
+    // an angle is inside (-pi/2, pi/2) iff its cosine is positive; which infinity
+    // replaces it otherwise depends on the side the bisector is on
+    g.entry = (ce > 0) ? se : (front ? inf : -inf);
+    g.exit = (cx > 0) ? sx : (front ? -inf : inf);
+    g.entry_cos = ce, g.exit_cos = cx;
+    g.continuous = !front;
+    if (!(cb == cb)) g.entry = g.exit = cb;   // NaN bisector (the reference exit(1)s): propagate
   }
-  if (bis >= kPi90 || bis <= -kPi90) bis = inf;
-  if (en >= kPi90) en = inf;
-  if (en <= -kPi90) en = -inf;
-  if (ex >= kPi90) ex = inf;
-  if (ex <= -kPi90) ex = -inf;
-  if (ratio >= 1) en = -inf, ex = inf;
-  if (ratio <= -1) en = inf, ex = -inf, bis = -inf, cont = false;
-  return Gcad{en, ex, bis, cont};
+  g.half = front ? sb : inf;
+  if (ratio >= 1) g.entry = -inf, g.exit = inf;
+  if (ratio <= -1) g.entry = inf, g.exit = -inf, g.half = -inf, g.continuous = false;
+  return g;
 }
-R3D_HD bool gcad_inside(const Gcad& g, double th) {  // media_cellface.cpp:767-782
-  const double slack = 0.0000000001;
-  if (g.continuous) return th <= g.exit && th >= (g.entry - slack);
-  return (th >= -kPi90 && th <= g.exit) || (th >= (g.entry - slack) && th <= kPi90);
+// GCAD_RetVal::Inside (media_cellface.cpp:767-782); th is a sine or +-inf.  The
+// reference's 1e-10 rad of slack on the entry side becomes 1e-10 cos(entry).
+R3D_HD bool gcad_inside(const Gcad& g, double th) {
+  const double inf = pos_inf();
+  const double lo = g.entry - 0.0000000001 * g.entry_cos;
+  if (g.continuous) return th <= g.exit && th >= lo;
+  return (th > -inf && th <= g.exit) || (th >= lo && th < inf);
 }
-// reference Tetra::GetPathToBoundary, media.cpp:518-567 (search part)
-R3D_HD Exit tet_exit(const CellTet& c, const TetArc& A) {
+// reference Tetra::GetPathToBoundary, media.cpp:518-567 (search part).
+// Result: face, and the exit point on the circle as (sin, cos); len is filled
+// in by tet_exit_length().
+struct TetExit {
+  double s, c;      // sine / cosine of the exit angle (s may be +-inf)
+  int face;
+};
+R3D_HD TetExit tet_exit(const CellTet& c, const TetArc& A) {
   Gcad rv[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) rv[i] = tet_face_arc(c.n[i], c.d[i], A);
-  Exit e{pos_inf(), 0};
+  TetExit e{pos_inf(), 1.0, 0};
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    double x = rv[i].exit;
+    const double x = rv[i].exit;
     bool proper = gcad_inside(rv[(i + 1) & 3], x) && gcad_inside(rv[(i + 2) & 3], x) &&
                   gcad_inside(rv[(i + 3) & 3], x);
-    if (proper) {
-      double nl = (x - A.a0) * A.R;
-      if (nl < 0 && (A.a0 > rv[i].half)) nl = e.len;  // dismissed exit
-      if (nl < e.len) e.len = nl, e.face = i;
-    }
+    // an exit behind the phonon (negative arc) is dismissed only beyond the face's bisector
+    if (proper && x < A.s0 && A.s0 > rv[i].half) proper = false;
+    if (proper && x < e.s) e.s = x, e.c = rv[i].exit_cos, e.face = i;
   }
   return e;
 }
-// reference Tetra::AdvanceLength (media.cpp:442-499) + Phonon::Move
-R3D_HD void tet_advance(const CellTet& c, const TetArc& A, Phonon& p, double len) {
+// Arc length to the exit: R (a_exit - a0), the difference taken from its sine
+// and cosine (both angles lie in [-pi/2, pi/2]).
+R3D_HD double tet_exit_length(const TetArc& A, const TetExit& e) {
+  if (!(e.s > -pos_inf() && e.s < pos_inf())) return e.s;   // +-inf (NaN propagates)
+  return A.R * atan2(e.s * A.c0 - e.c * A.s0, e.c * A.c0 + e.s * A.s0);
+}
+// reference Tetra::AdvanceLength (media.cpp:442-499) + Phonon::Move.  (s1, c1)
+// are the sine / cosine of the end angle: the exit's own for a boundary leg,
+// a0 + len/R for a scatter leg.
+R3D_HD void tet_advance(const CellTet& c, const TetArc& A, Phonon& p, double len, double s1, double c1) {
   const int t = p.type;
-  double a1 = A.a0 + len / A.R;
-  double s1, c1;
-  sincos(a1, &s1, &c1);
   V3 q = v3(A.R * s1 + A.trans.x, A.trans.y, A.R * c1 + A.trans.z);  // new position, rotated frame
   V3 nl = q.x * A.v1 + q.y * A.v2 + q.z * A.v3;                       // back-rotate (S^T)
   V3 nd = c1 * A.v1 + (-s1) * A.v3;                                   // tangent (cos a, 0, -sin a)
@@ -467,7 +492,7 @@ R3D_HD bool full_rt(Phonon& p, Iface f, Rng& rng) {
     if (choice == T_SH || choice == R_SH) dopm = fparash;
     else if (choice == R_SV) dopm = cross(out, fparash);
     else dopm = cross(fparash, out);
-    p.pol = pol_angle(dopm, nd);
+    set_pol(p, dopm, nd);
   }
   p.dir = nd;
   return !reflected;
@@ -489,16 +514,16 @@ R3D_HD bool bend(Phonon& p, V3 fnorm, double veli, double velo) {
     transfer = true, coso = sqrt(1.0 - sino * sino);
   }
   V3 out = sino * fpara + coso * fnorm;
-  double polout = 0;
+  const V3 nd = through_angles(unit(out));   // outdir.ThetaHat()/PhiHat() go through Theta()/Phi()
   if (p.type != RAY_P) {
     V3 pdomi = direction_of_motion(p);
     V3 svi = cross(fparash, p.dir), svo = cross(fparash, out);
     V3 pdomo = dot(pdomi, fparash) * fparash + dot(pdomi, svi) * svo;
-    // outdir.ThetaHat()/PhiHat() normalise through Theta()/Phi()
-    polout = pol_angle(pdomo, through_angles(unit(out)));
+    set_pol(p, pdomo, nd);
+  } else {
+    p.pc = 1.0, p.ps = 0.0;                  // polout = 0
   }
-  p.dir = through_angles(unit(out));
-  p.pol = polout;
+  p.dir = nd;
   return transfer;
 }
 
@@ -540,22 +565,19 @@ R3D_HD int sample_small(const double* cdf, int n, double u) {
 }
 // Rotate (dir, pol) by a deflection given in the phonon's own frame
 // (reference Phonon::Transform, phonons.cpp:116-170; OrthoAxes,
-// geom_r3.cpp:212-286).  rel is the unit deflection vector, rpol the relative
-// polarisation angle.
-R3D_HD void scatter_transform(Phonon& p, V3 rel, double rpol, int new_type) {
+// geom_r3.cpp:212-286).  rel is the unit deflection vector, (rc, rs) the cosine
+// and sine of the relative polarisation angle.
+R3D_HD void scatter_transform(Phonon& p, V3 rel, double rc, double rs, int new_type) {
   V3 e1, e2;
   sph_basis(p.dir, e1, e2);
-  double s, c;
-  sincos(p.pol, &s, &c);
-  const V3 s1 = c * e1 + s * e2, s2 = (-s) * e1 + c * e2, e3 = p.dir;
+  const V3 s1 = p.pc * e1 + p.ps * e2, s2 = (-p.ps) * e1 + p.pc * e2, e3 = p.dir;
   V3 b1, b2;
   sph_basis(rel, b1, b2);
-  sincos(rpol, &s, &c);
-  const V3 bs1 = c * b1 + s * b2;               // S1 axis of the deflection frame
+  const V3 bs1 = rc * b1 + rs * b2;              // S1 axis of the deflection frame
   V3 nd = rel.x * s1 + rel.y * s2 + rel.z * e3;  // AA.Express(BB.E3)
   V3 ns1 = bs1.x * s1 + bs1.y * s2 + bs1.z * e3;
   nd = through_angles(nd);                       // theta = acos(z), phi = atan2(y, x)
-  p.pol = pol_angle(ns1, nd);
+  set_pol(p, ns1, nd);
   p.dir = nd;
   p.type = new_type;
 }

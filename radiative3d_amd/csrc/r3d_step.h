@@ -78,7 +78,9 @@ R3D_HD void spray(const KArgs& a, Phonon& p, Rng& rng) {
   p.amp = 1.0;
   p.moves = 0;
   p.dir = v3(a.toa_xyz + 3 * k);
-  p.pol = (rt3 == 1) ? kPi * 0.5 : 0.0;
+  // mPol = pi/2 for SH, else 0 (phonons.hpp:200); cos(pi/2) in fp64 is 6.1e-17, not 0
+  p.pc = (rt3 == 1) ? 6.123233995736766e-17 : 1.0;
+  p.ps = (rt3 == 1) ? 1.0 : 0.0;
   p.type = (rt3 == 0) ? RAY_P : RAY_S;
   p.loc = v3(a.src_loc);
   p.cell = a.src_cell;
@@ -168,12 +170,15 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
   // --- where does the ray leave the cell? (phonons.cpp:590)
   Exit e;
   TetArc tarc;
+  TetExit texit;
   SphArc sarc;
   if constexpr (KIND == CELL_CYL) {
     e = cyl_exit(c, a.cyl_radius2, p);
   } else if constexpr (KIND == CELL_TET) {
     tarc = tet_arc(c, p);
-    e = tet_exit(c, tarc);
+    texit = tet_exit(c, tarc);
+    e.face = texit.face;
+    e.len = tet_exit_length(tarc, texit);
   } else {
     sarc = sph_arc(c, a.earth_center, p);
     e = sph_exit(c, sarc, p);
@@ -187,9 +192,19 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
   const double len = scatters ? scatlen : e.len;
 
   // --- advance (both branches) and Move (phonons.cpp:608-609, :623)
-  if constexpr (KIND == CELL_CYL) cyl_advance(c, p, len);
-  else if constexpr (KIND == CELL_TET) tet_advance(c, tarc, p, len);
-  else sph_advance(c, sarc, p, len);
+  if constexpr (KIND == CELL_CYL) {
+    cyl_advance(c, p, len);
+  } else if constexpr (KIND == CELL_TET) {
+    double s1 = texit.s, c1 = texit.c;   // a boundary leg ends at the exit point itself
+    if (scatters || !(e.len > -pos_inf())) {
+      double sd, cd;                      // scatter leg: rotate the start angle by len / R
+      sincos(len / tarc.R, &sd, &cd);
+      s1 = tarc.s0 * cd + tarc.c0 * sd, c1 = tarc.c0 * cd - tarc.s0 * sd;
+    }
+    tet_advance(c, tarc, p, len, s1, c1);
+  } else {
+    sph_advance(c, sarc, p, len);
+  }
 
   ev.face = scatters ? -1 : e.face;
   ev.flags = scatters ? 0u : face_flags(c.flags, e.face);
@@ -210,15 +225,16 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
     // Scatterer::GetRandomScatteredRelativePhonon, scatterers.cpp:318-363
     st.scatter++;
     if (a.no_deflect) {
-      scatter_transform(p, v3(a.nodeflect_dir), 0.0, p.type);
+      scatter_transform(p, v3(a.nodeflect_dir), 1.0, 0.0, p.type);
     } else {
       const ScatHead& sh = T.scat_head[c.scat];
       const ScatPtrs sp = a.scat_ptrs[c.scat];
       int conv = sample_small(sh.whole[p.type], 4, rng_draw(rng));  // GPP GPS GSP GSS
       uint64_t k = sample_cdf_guided(sp.cdf[conv], sp.guide[conv], a.guide_bits, sh.total[conv],
                                      rng_draw(rng));
-      double rpol = (conv == 3) ? sp.spol[k] : 0.0;
-      scatter_transform(p, v3(a.toa_xyz + 3 * k), rpol, (conv & 1) ? RAY_S : RAY_P);
+      double rc = 1.0, rs = 0.0;      // relative polarisation 0 except S->S (scatterers.cpp:341-356)
+      if (conv == 3) sincos(sp.spol[k], &rs, &rc);
+      scatter_transform(p, v3(a.toa_xyz + 3 * k), rc, rs, (conv & 1) ? RAY_S : RAY_P);
     }
     return FATE_ALIVE;
   }
@@ -240,7 +256,15 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
       f.rhoT = cell_density(a, o, nbr, p.loc);
     }
     st.rtsolve++;
+#ifdef R3D_ABLATE_RT   // timing-only developer build: specular bounce / coin-flip transmission
+    {
+      double dn = dot(f.normal, p.dir);
+      crossed = adjoin && (rng_draw(rng) < 0.5);
+      if (!crossed) p.dir = p.dir - (2.0 * dn) * f.normal;
+    }
+#else
     crossed = full_rt(p, f, rng);
+#endif
   } else {
     // Phonon::Refract without a grid discontinuity (phonons.cpp:243-252):
     // bend on a fractional velocity step > 1e-5, else plain hand-over.
