@@ -42,6 +42,10 @@ constexpr unsigned kChunk = 256;     // history ids a wave claims per global ato
 #define R3D_REFILL_MIN 8
 #endif
 constexpr unsigned kRefillMin = R3D_REFILL_MIN;
+#ifndef R3D_RT_BATCH
+#define R3D_RT_BATCH 24
+#endif
+constexpr unsigned kRtBatch = R3D_RT_BATCH;      // parked R/T lanes that trigger the solve (<= 1: no parking)
 #ifndef R3D_WAVES_PER_SIMD
 #define R3D_WAVES_PER_SIMD 1   // register budget 512 / N per lane (second __launch_bounds__ argument)
 #endif  // idle lanes that trigger a refill
@@ -56,26 +60,20 @@ __device__ __forceinline__ V3 bcast(V3 v, int src) { return v3(bcast(v.x, src), 
 
 // Seismometer collection for the arrival held by lane `src`, executed by the
 // whole wave: same tests and same bin updates as collect() in r3d_step.h
-// (reference dataout.cpp:103-216, :545-568), with the candidate receivers of
-// the arrival's hash cell spread over the 64 lanes.
+// (reference dataout.cpp:103-216, :545-568), with the candidate receivers
+// [k0, k1) of the arrival's hash cell spread over the 64 lanes.
 template <int KIND>
 __device__ __forceinline__ void collect_wave(const KArgs& a, const Tables<KIND>& T, const Phonon& p,
-                                             double vel_lane, int src_lane, unsigned lane, LaneStats& st) {
+                                             double vel_lane, uint32_t k0_lane, uint32_t k1_lane,
+                                             int src_lane, unsigned lane, LaneStats& st) {
   const int src = __builtin_amdgcn_readfirstlane(src_lane);
   const V3 loc = bcast(p.loc, src), dir = bcast(p.dir, src);
   const double t = bcast(p.t, src), amp = bcast(p.amp, src);
   const double pc = bcast(p.pc, src), ps = bcast(p.ps, src);
   const double vel = bcast(vel_lane, src);
   const int type = __builtin_amdgcn_readlane(p.type, src);
-  if ((int)lane == src) st.collect++;
-  const SeisGrid& g = a.grid;
-  const double fx = (loc.x - g.origin[0]) * g.inv_h;
-  const double fy = (loc.y - g.origin[1]) * g.inv_h;
-  const double fz = (loc.z - g.origin[2]) * g.inv_h;
-  if (!(fx >= 0 && fy >= 0 && fz >= 0 && fx < g.dim[0] && fy < g.dim[1] && fz < g.dim[2])) return;
-  const int cellid = ((int)fz * g.dim[1] + (int)fy) * g.dim[0] + (int)fx;
-  const uint32_t k0 = g.start[cellid], k1 = g.start[cellid + 1];
-  if (k0 == k1) return;
+  const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)k0_lane, src);
+  const uint32_t k1 = (uint32_t)__builtin_amdgcn_readlane((int)k1_lane, src);
   V3 dopm = dir;  // Phonon::DirectionOfMotion of the broadcast phonon
   if (type != RAY_P) {
     V3 th, ph;
@@ -87,7 +85,7 @@ __device__ __forceinline__ void collect_wave(const KArgs& a, const Tables<KIND>&
     const uint32_t k = kb + lane;
     bool hit = false;
     if (k < k1) {
-      const uint32_t s = g.items[k];
+      const uint32_t s = a.grid.items[k];
       const SeisScan& S = T.seis_scan[s];
       const V3 to = v3(S.loc) - loc;
       const double dist = mag(to);
@@ -98,7 +96,7 @@ __device__ __forceinline__ void collect_wave(const KArgs& a, const Tables<KIND>&
         const double fl = floor(scaled);
         if (scaled >= 0.0 && fl < (double)a.n_bins) {
           const uint32_t bin = (uint32_t)fl;
-          const SeisHit& H = a.seis_hit[s];
+          const SeisHit& H = T.seis_hit[s];
           const double xf = dot(dopm, v3(H.axes[0])), yf = dot(dopm, v3(H.axes[1])), zf = dot(dopm, v3(H.axes[2]));
           const double energy = (amp * amp) * H.inv_norm[type];
           const size_t slot = (size_t)s * a.n_bins + bin;
@@ -133,6 +131,7 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
     if (LDS_CELLS) copy_words(smem + a.lds_cells_off, a.cells, (size_t)a.n_cells * sizeof(Cell));
     copy_words(smem + a.lds_scat_off, a.scat_head, (size_t)a.n_scat * sizeof(ScatHead));
     copy_words(smem + a.lds_seis_off, a.seis_scan, (size_t)a.n_seis * sizeof(SeisScan));
+    copy_words(smem + a.lds_hit_off, a.seis_hit, (size_t)a.n_seis * sizeof(SeisHit));
     __syncthreads();
   }
   Tables<KIND> T;
@@ -140,6 +139,7 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
                       : reinterpret_cast<const Cell*>(a.cells);
   T.scat_head = reinterpret_cast<const ScatHead*>(smem + a.lds_scat_off);
   T.seis_scan = reinterpret_cast<const SeisScan*>(smem + a.lds_seis_off);
+  T.seis_hit = reinterpret_cast<const SeisHit*>(smem + a.lds_hit_off);
 
   const unsigned lane = threadIdx.x & 63u;
   const unsigned long long lane_lt = (1ull << lane) - 1ull;
@@ -152,13 +152,16 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
   uint64_t my_id = 0;
   uint32_t catch_at_start = 0;
   bool alive = false;
+  bool parked = false;   // holds a reflection/transmission event in `ev`, waiting for company
+  Pending ev;
+  ev.vel = 0.0, ev.face = -1, ev.flags = 0u;
   unsigned long long w_next = 0, w_end = 0;  // wave-uniform: ids this wave still owns
   bool drained = false;                      // wave-uniform: the global counter ran out
 
   for (;;) {
-    // ---- refill dead lanes from the wave's id range ----
-    // (a refill costs a dependent table search, so wait until kRefillMin lanes are idle
-    //  -- or none is left running -- and serve them together)
+    // ---- refill idle lanes from the wave's id range.  A refill costs a dependent
+    //      table search, so wait until kRefillMin lanes are idle -- or none is left
+    //      running -- and serve them together ----
     unsigned long long need = __ballot(!alive);
     const bool refill_now = (unsigned)__popcll(need) >= kRefillMin || need == ~0ull;
     while (refill_now && need != 0ull && !drained) {
@@ -190,27 +193,56 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
     }
     if (!__any(alive)) break;  // every lane idle and nothing left to hand out
 
-    // ---- first half of the iteration for every live lane: search, draw, advance ----
-    Pending ev;
-    ev.vel = 0.0, ev.face = -1, ev.flags = 0u;
+    // ---- first half of the iteration for every running lane: search, draw, advance ----
     int fate = FATE_ALIVE, reason = 0;
-    if (alive) fate = step_move<KIND>(a, T, p, rng, st, &reason, ev);
-    const bool moved = alive && fate == FATE_ALIVE;
+    const bool run = alive && !parked;
+    if (run) fate = step_move<KIND>(a, T, p, rng, st, &reason, ev);
+    const bool moved = run && fate == FATE_ALIVE;
 
-    // ---- seismometers: the wave serves its arriving lanes one at a time, all 64
-    //      lanes testing candidate receivers in parallel ----
-    unsigned long long arrivals = __ballot(moved && (ev.flags & F_COLLECT));
+    // ---- seismometers.  Each arriving lane looks up its own hash cell (the loads of
+    //      different lanes overlap); then the wave serves the arrivals that have
+    //      candidate receivers one at a time, 64 candidates per pass ----
+    uint32_t k0 = 0, k1 = 0;
+    if (moved && (ev.flags & F_COLLECT)) {
+      st.collect++;
+      const SeisGrid& g = a.grid;
+      const double fx = (p.loc.x - g.origin[0]) * g.inv_h;
+      const double fy = (p.loc.y - g.origin[1]) * g.inv_h;
+      const double fz = (p.loc.z - g.origin[2]) * g.inv_h;
+      if (fx >= 0 && fy >= 0 && fz >= 0 && fx < g.dim[0] && fy < g.dim[1] && fz < g.dim[2]) {
+        const int cellid = ((int)fz * g.dim[1] + (int)fy) * g.dim[0] + (int)fx;
+        k0 = g.start[cellid], k1 = g.start[cellid + 1];
+      }
+    }
+    unsigned long long arrivals = __ballot(k1 > k0);
 #ifdef R3D_ABLATE_COLLECT  // timing-only developer build
     arrivals = 0ull;
 #endif
     while (arrivals) {
       const int src = __ffsll((long long)arrivals) - 1;
       arrivals &= arrivals - 1ull;
-      collect_wave<KIND>(a, T, p, ev.vel, src, lane, st);
+      collect_wave<KIND>(a, T, p, ev.vel, k0, k1, src, lane, st);
     }
 
-    // ---- second half: scatter / reflect-transmit / bend / hand-over ----
-    if (moved) fate = step_event<KIND>(a, T, p, rng, st, ev);
+    // ---- second half.  Scatter, bend and hand-over are served at once.  The
+    //      reflection/transmission solve is the one long divergent branch (about a fifth
+    //      of the lanes per iteration): lanes that need it park until kRtBatch of them
+    //      have gathered -- or nothing else can run -- and then take it together ----
+    if (moved) {
+      const bool heavy = kRtBatch > 1 && ev.face >= 0 && (ev.flags & (F_REFLECT | F_DISCON)) != 0;
+      if (heavy) parked = true;
+      else fate = step_event<KIND>(a, T, p, rng, st, ev);
+    }
+    if (kRtBatch > 1) {
+      const unsigned n_parked = (unsigned)__popcll(__ballot(parked));
+      const bool any_running = __any(alive && !parked && fate == FATE_ALIVE);
+      if (n_parked >= kRtBatch || (n_parked > 0 && !any_running)) {
+        if (parked) {
+          fate = step_event<KIND>(a, T, p, rng, st, ev);
+          parked = false;
+        }
+      }
+    }
 
     if (alive && fate != FATE_ALIVE) {
       alive = false;
@@ -468,6 +500,7 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   if (e->lds_cells) a.lds_cells_off = (uint32_t)off, off = align16(off + cell_bytes);
   a.lds_scat_off = (uint32_t)off, off = align16(off + (size_t)m->n_scatterers * sizeof(ScatHead));
   a.lds_seis_off = (uint32_t)off, off = align16(off + (size_t)std::max(1, m->n_seismometers) * sizeof(SeisScan));
+  a.lds_hit_off = (uint32_t)off, off = align16(off + (size_t)std::max(1, m->n_seismometers) * sizeof(SeisHit));
   e->lds_bytes = off;
   if (e->lds_bytes > 160 * 1024) {
     g_error = "model's scan tables exceed the 160 KB of LDS per CU";
@@ -484,8 +517,22 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
     }
     R3D_HIP_OK(r);
   }
-  // persistent grid: as many workgroups per CU as LDS allows, up to 4
-  int per_cu = (int)std::min<size_t>(4, std::max<size_t>(1, (160 * 1024) / std::max<size_t>(e->lds_bytes, 1)));
+  // persistent grid: exactly the workgroups that can be resident at once (register- and
+  // LDS-limited), so every block is running while there is work and none queues behind
+  int per_cu = 1;
+  {
+    hipError_t r;
+#define R3D_OCC(K, L) \
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, propagate_kernel<K, L, false>, kBlock, e->lds_bytes)
+    switch (e->kind) {
+      case R3D_CELL_CYLINDER: r = e->lds_cells ? R3D_OCC(CELL_CYL, true) : R3D_OCC(CELL_CYL, false); break;
+      case R3D_CELL_TETRA: r = e->lds_cells ? R3D_OCC(CELL_TET, true) : R3D_OCC(CELL_TET, false); break;
+      default: r = e->lds_cells ? R3D_OCC(CELL_SPH, true) : R3D_OCC(CELL_SPH, false);
+    }
+#undef R3D_OCC
+    R3D_HIP_OK(r);
+    per_cu = std::max(1, std::min(per_cu, 8));
+  }
   e->grid_blocks = prop.multiProcessorCount * per_cu;
 
   // ---- result scratch, work counter, stream, events ----

@@ -41,6 +41,7 @@ struct Tables {
   const typename CellOf<KIND>::type* cells;
   const ScatHead* scat_head;
   const SeisScan* seis_scan;
+  const SeisHit* seis_hit;
 };
 
 // ---- per-kind property lookups --------------------------------------------
@@ -67,12 +68,18 @@ R3D_HD int cell_neighbor(const CellSph& c, int f) { return c.nbr[f]; }
 
 // ---- source spray ----------------------------------------------------------
 R3D_HD void spray(const KArgs& a, Phonon& p, Rng& rng) {
-  int rt3 = sample_small(a.src_whole, 3, rng_draw(rng));            // 0 P, 1 SH, 2 SV
+  // 0 P, 1 SH, 2 SV: smallest k with r <= whole[k] (probability.cpp:104-128 on 3 entries)
+  const double r3 = a.src_whole[2] * rng_draw(rng);
+  const int rt3 = (r3 <= a.src_whole[0]) ? 0 : (r3 <= a.src_whole[1]) ? 1 : 2;
 #ifdef R3D_ABLATE_SPRAY_SEARCH
   uint64_t k = (uint64_t)(rng_draw(rng) * (double)(a.n_toa - 1));
 #else
-  uint64_t k = sample_cdf_guided(a.src_cdf[rt3], a.src_guide[rt3], a.guide_bits, a.src_total[rt3],
-                                 rng_draw(rng));
+  // (selects, not a[rt3]: a dynamic index into the by-value argument block would
+  //  make the compiler copy the arrays to scratch memory)
+  const double* cdf = rt3 == 0 ? a.src_cdf[0] : rt3 == 1 ? a.src_cdf[1] : a.src_cdf[2];
+  const uint32_t* guide = rt3 == 0 ? a.src_guide[0] : rt3 == 1 ? a.src_guide[1] : a.src_guide[2];
+  const double total = rt3 == 0 ? a.src_total[0] : rt3 == 1 ? a.src_total[1] : a.src_total[2];
+  uint64_t k = sample_cdf_guided(cdf, guide, a.guide_bits, total, rng_draw(rng));
 #endif
   p.t = p.path = p.recent = 0.0;
   p.amp = 1.0;
@@ -121,7 +128,7 @@ R3D_HD void collect(const KArgs& a, const Tables<KIND>& T, const Phonon& p, doub
     if (!(fl < (double)a.n_bins)) continue;
     uint32_t bin = (uint32_t)fl;
     if (!have_dopm) dopm = direction_of_motion(p), have_dopm = true;
-    const SeisHit& H = a.seis_hit[s];
+    const SeisHit& H = T.seis_hit[s];
     double xf = dot(dopm, v3(H.axes[0])), yf = dot(dopm, v3(H.axes[1])), zf = dot(dopm, v3(H.axes[2]));
     double energy = (p.amp * p.amp) * H.inv_norm[t];
     size_t slot = (size_t)s * a.n_bins + bin;
@@ -228,12 +235,12 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
       scatter_transform(p, v3(a.nodeflect_dir), 1.0, 0.0, p.type);
     } else {
       const ScatHead& sh = T.scat_head[c.scat];
-      const ScatPtrs sp = a.scat_ptrs[c.scat];
+      const ScatPtrs* sp = a.scat_ptrs + c.scat;   // (indexed in place: a local copy would go to scratch)
       int conv = sample_small(sh.whole[p.type], 4, rng_draw(rng));  // GPP GPS GSP GSS
-      uint64_t k = sample_cdf_guided(sp.cdf[conv], sp.guide[conv], a.guide_bits, sh.total[conv],
+      uint64_t k = sample_cdf_guided(sp->cdf[conv], sp->guide[conv], a.guide_bits, sh.total[conv],
                                      rng_draw(rng));
       double rc = 1.0, rs = 0.0;      // relative polarisation 0 except S->S (scatterers.cpp:341-356)
-      if (conv == 3) sincos(sp.spol[k], &rs, &rc);
+      if (conv == 3) sincos(sp->spol[k], &rs, &rc);
       scatter_transform(p, v3(a.toa_xyz + 3 * k), rc, rs, (conv & 1) ? RAY_S : RAY_P);
     }
     return FATE_ALIVE;

@@ -138,6 +138,7 @@ struct KArgs {
   uint32_t lds_cells_off;    // 0xFFFFFFFF: cells stay in HBM
   uint32_t lds_scat_off;
   uint32_t lds_seis_off;
+  uint32_t lds_hit_off;
 };
 
 }  // namespace r3d
