@@ -47,7 +47,8 @@ constexpr unsigned kRefillMin = R3D_REFILL_MIN;
 #endif
 constexpr unsigned kRtBatch = R3D_RT_BATCH;      // parked R/T lanes that trigger the solve (<= 1: no parking)
 #ifndef R3D_WAVES_PER_SIMD
-#define R3D_WAVES_PER_SIMD 1   // register budget 512 / N per lane (second __launch_bounds__ argument)
+#define R3D_WAVES_PER_SIMD 2   // register budget 512 / N per lane (second __launch_bounds__ argument);
+                               // measured on NSCP: 1 -> 56 ms, 2 -> 44 ms, 3 -> 89 ms (spills)
 #endif  // idle lanes that trigger a refill
 
 // ---------------------------------------------------- wave-level helpers ----
@@ -65,7 +66,7 @@ __device__ __forceinline__ V3 bcast(V3 v, int src) { return v3(bcast(v.x, src), 
 template <int KIND>
 __device__ __forceinline__ void collect_wave(const KArgs& a, const Tables<KIND>& T, const Phonon& p,
                                              double vel_lane, uint32_t k0_lane, uint32_t k1_lane,
-                                             int src_lane, unsigned lane, LaneStats& st) {
+                                             int src_lane, unsigned lane, uint32_t& lane_catches) {
   const int src = __builtin_amdgcn_readfirstlane(src_lane);
   const V3 loc = bcast(p.loc, src), dir = bcast(p.dir, src);
   const double t = bcast(p.t, src), amp = bcast(p.amp, src);
@@ -112,7 +113,7 @@ __device__ __forceinline__ void collect_wave(const KArgs& a, const Tables<KIND>&
     }
     hits += (uint32_t)__popcll(__ballot(hit));
   }
-  if ((int)lane == src) st.n_catch += hits;
+  if ((int)lane == src) lane_catches += hits;
 }
 
 // --------------------------------------------------------------- the kernel --
@@ -134,6 +135,8 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
     copy_words(smem + a.lds_hit_off, a.seis_hit, (size_t)a.n_seis * sizeof(SeisHit));
     __syncthreads();
   }
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned long long lane_lt = (1ull << lane) - 1ull;
   Tables<KIND> T;
   T.cells = LDS_CELLS ? reinterpret_cast<const Cell*>(smem + a.lds_cells_off)
                       : reinterpret_cast<const Cell*>(a.cells);
@@ -141,16 +144,22 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
   T.seis_scan = reinterpret_cast<const SeisScan*>(smem + a.lds_seis_off);
   T.seis_hit = reinterpret_cast<const SeisHit*>(smem + a.lds_hit_off);
 
-  const unsigned lane = threadIdx.x & 63u;
-  const unsigned long long lane_lt = (1ull << lane) - 1ull;
+  // Tallies live in LDS, not in registers: each iteration the wave adds its lanes'
+  // 0/1 events with one ballot + one LDS atomic per counter; the block flushes them
+  // to HBM once at the end.  Slot order = r3d_run_device's d_scalars.
+  __shared__ unsigned long long s_tally[R3D_N_SCALARS];
+  if (threadIdx.x < R3D_N_SCALARS) s_tally[threadIdx.x] = 0ull;
+  __syncthreads();
+  auto tally = [&](bool cond, int slot) {
+    const unsigned long long m = __ballot(cond);
+    if (lane == 0 && m) atomicAdd(&s_tally[slot], (unsigned long long)__popcll(m));
+  };
+  constexpr int kEv = 3 + R3D_INV_NUM;
 
   Phonon p;
   Rng rng;
-  LaneStats st = {0, 0, 0, 0, 0, 0, 0};
-  uint32_t n_gen = 0, n_lost = 0, n_timeout = 0;
-  uint32_t inv[R3D_INV_NUM] = {0, 0, 0, 0, 0, 0, 0};
-  uint64_t my_id = 0;
-  uint32_t catch_at_start = 0;
+  uint64_t my_id = 0;        // (only read when TRACE)
+  uint32_t lane_catches = 0; // catches of the current history (only read when TRACE)
   bool alive = false;
   bool parked = false;   // holds a reflection/transmission event in `ev`, waiting for company
   Pending ev;
@@ -182,12 +191,12 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
       const unsigned rank = (unsigned)__popcll(need & lane_lt);
       if (!alive && rank < take) {
         my_id = a.first_id + w_next + rank;
-        rng_init(rng, a.seed, my_id);
+        rng_init(rng, my_id);
         spray(a, p, rng);
         alive = true;
-        n_gen++;
-        if (TRACE) catch_at_start = st.n_catch;
+        lane_catches = 0;
       }
+      if (lane == 0 && take) atomicAdd(&s_tally[kEv + R3D_EV_GENERATED], (unsigned long long)take);
       w_next += take;
       need = __ballot(!alive);
     }
@@ -195,6 +204,7 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
 
     // ---- first half of the iteration for every running lane: search, draw, advance ----
     int fate = FATE_ALIVE, reason = 0;
+    LaneStats st = {0, 0, 0, 0, 0, 0, 0};   // this iteration's events of this lane
     const bool run = alive && !parked;
     if (run) fate = step_move<KIND>(a, T, p, rng, st, &reason, ev);
     const bool moved = run && fate == FATE_ALIVE;
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
     while (arrivals) {
       const int src = __ffsll((long long)arrivals) - 1;
       arrivals &= arrivals - 1ull;
-      collect_wave<KIND>(a, T, p, ev.vel, k0, k1, src, lane, st);
+      collect_wave<KIND>(a, T, p, ev.vel, k0, k1, src, lane, st.n_catch);
     }
 
     // ---- second half.  Scatter, bend and hand-over are served at once.  The
@@ -244,14 +254,30 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
       }
     }
 
-    if (alive && fate != FATE_ALIVE) {
-      alive = false;
-      if (fate == FATE_LOST) n_lost++;
-      else if (fate == FATE_TIMEOUT) n_timeout++;
-      else {
+    // ---- book-keeping: this iteration's events, and lanes whose history ended ----
+    tally(st.iterations != 0, kEv + R3D_EV_ITERATIONS);
+    tally(st.scatter != 0, kEv + R3D_EV_SCATTER);
+    tally(st.collect != 0, kEv + R3D_EV_COLLECT);
+    tally(st.reflect != 0, kEv + R3D_EV_REFLECT);
+    tally(st.transfer != 0, kEv + R3D_EV_TRANSFER);
+    tally(st.rtsolve != 0, kEv + R3D_EV_RTSOLVE);
+    if (__any(st.n_catch != 0)) {   // a lane can be caught by several receivers at once
+      unsigned long long c = st.n_catch;
 #pragma unroll
-        for (int r = 0; r < R3D_INV_NUM; r++) inv[r] += (r == reason);
-      }
+      for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+      if (lane == 0) atomicAdd(&s_tally[kEv + R3D_EV_CATCH], c);
+    }
+    if (TRACE) lane_catches += st.n_catch;
+    const bool died = alive && fate != FATE_ALIVE;
+    if (__any(died)) {
+      tally(died && fate == FATE_LOST, 0);
+      tally(died && fate == FATE_TIMEOUT, 1);
+      tally(died && fate == FATE_INVALID, 2);
+#pragma unroll
+      for (int r = 0; r < R3D_INV_NUM; r++) tally(died && fate == FATE_INVALID && reason == r, 3 + r);
+    }
+    if (died) {
+      alive = false;
       if (TRACE) {
         r3d_final* f = reinterpret_cast<r3d_final*>(a.finals) + (my_id - a.first_id);
         f->time = p.t, f->path = p.path, f->amp = p.amp;
@@ -260,36 +286,15 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
         f->moves = p.moves;
         f->fate = (uint8_t)fate;
         f->type = (uint8_t)p.type;
-        uint32_t nc = st.n_catch - catch_at_start;
-        f->n_catch = (uint16_t)(nc > 65535u ? 65535u : nc);
+        f->n_catch = (uint16_t)(lane_catches > 65535u ? 65535u : lane_catches);
       }
     }
   }
 
-  // ---- flush the per-lane tallies: wave reduction, one atomic per counter ----
-  auto flush = [&](uint32_t v, int slot) {
-    unsigned long long s = v;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if (lane == 0 && s) atomicAdd(a.scalars + slot, s);
-  };
-  flush(n_lost, 0);
-  flush(n_timeout, 1);
-  uint32_t n_inv = 0;
-#pragma unroll
-  for (int r = 0; r < R3D_INV_NUM; r++) n_inv += inv[r];
-  flush(n_inv, 2);
-#pragma unroll
-  for (int r = 0; r < R3D_INV_NUM; r++) flush(inv[r], 3 + r);
-  const int ev0 = 3 + R3D_INV_NUM;
-  flush(n_gen, ev0 + R3D_EV_GENERATED);
-  flush(st.iterations, ev0 + R3D_EV_ITERATIONS);
-  flush(st.scatter, ev0 + R3D_EV_SCATTER);
-  flush(st.collect, ev0 + R3D_EV_COLLECT);
-  flush(st.n_catch, ev0 + R3D_EV_CATCH);
-  flush(st.reflect, ev0 + R3D_EV_REFLECT);
-  flush(st.transfer, ev0 + R3D_EV_TRANSFER);
-  flush(st.rtsolve, ev0 + R3D_EV_RTSOLVE);
+  // ---- flush the block's tallies to HBM: one atomic per counter per block ----
+  __syncthreads();
+  if (threadIdx.x < R3D_N_SCALARS && s_tally[threadIdx.x] != 0ull)
+    atomicAdd(a.scalars + threadIdx.x, s_tally[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------- engine --

@@ -118,6 +118,8 @@ R3D_HD void cyl_advance(const CellCyl& c, Phonon& p, double len) {
 // media.hpp:560-587): rows v1,v2,v3; `trans` is the arc centre in the rotated
 // frame; the phonon sits at angle a0 measured from +z towards +x, always in
 // [-pi/2, pi/2] (cos a0 = t.v1 >= 0); velocity is |g| R cos a along the arc.
+// Only the two in-plane axes and the arc centre in model coordinates are kept:
+// a face's trace in the arc plane is n.v1, n.v3 and its distance (n.p - n.centre).
 //
 // ANGLES ARE NEVER FORMED.  Every angle the reference compares
 // (media_cellface.cpp:333-426, :767-794, media.cpp:542-559) is either +-inf or
@@ -127,7 +129,8 @@ R3D_HD void cyl_advance(const CellCyl& c, Phonon& p, double len) {
 // the difference), and the end point of a boundary leg is the exit point
 // itself, so its sine / cosine are already known.
 struct TetArc {
-  V3 v1, v2, v3, trans;
+  V3 v1, v3;          // in-plane axes: v1 = component of the ray direction normal to grad v, v3 = unit grad v
+  V3 center;          // arc centre (model coordinates); it lies on the plane where v = 0
   double R, s0, c0;   // radius, sine / cosine of the start angle
 };
 R3D_HD TetArc tet_arc(const CellTet& c, const Phonon& p) {
@@ -136,12 +139,13 @@ R3D_HD TetArc tet_arc(const CellTet& c, const Phonon& p) {
   V3 g = v3(c.g[t]);
   double vel = dot(p.loc, g) + c.v0[t];
   V3 w2 = cross(g, p.dir), w1 = cross(w2, g);
-  A.v1 = unit(w1), A.v2 = unit(w2), A.v3 = c.inv_gmag[t] * g;
+  A.v1 = unit(w1), A.v3 = c.inv_gmag[t] * g;
   double txp = dot(p.dir, A.v1), tzp = dot(p.dir, A.v3);
   A.R = 1.0 / ((txp / vel) * mag(g));
-  V3 x0 = v3(dot(A.v1, p.loc), dot(A.v2, p.loc), dot(A.v3, p.loc));
-  A.trans = v3(x0.x + A.R * tzp, x0.y, x0.z - A.R * txp);
-  double px = x0.x - A.trans.x, pz = x0.z - A.trans.z;  // phonon in the centred frame
+  // In the rotated frame the phonon sits at R (-tz', 0, tx') from the centre
+  // (media.hpp:574-580), i.e. centre = loc + R tz' v1 - R tx' v3.
+  const double px = -A.R * tzp, pz = A.R * txp;
+  A.center = p.loc + ((-px) * A.v1 + (-pz) * A.v3);
   double h = 1.0 / sqrt(px * px + pz * pz);
   A.s0 = px * h, A.c0 = pz * h;
   return A;
@@ -151,20 +155,21 @@ R3D_HD TetArc tet_arc(const CellTet& c, const Phonon& p) {
 // outside the face between the exit angle bis - q and the entry angle bis + q,
 // bis = direction of the in-plane normal, cos q = (centre-to-trace distance)/R.
 struct Gcad {
-  double entry, exit, half;   // sines of the angles, or +-inf
-  double entry_cos, exit_cos; // cosines of entry / exit where those are finite
+  double entry_lo;            // sine of (entry - 1e-10 rad), or +-inf: the Inside() test's lower bound
+  double exit, half;          // sines of the exit and bisector angles, or +-inf
+  double exit_cos;            // cosine of the exit angle where that is finite
   bool continuous;
 };
 R3D_HD Gcad tet_face_arc(const double n[3], double dplane, const TetArc& A) {
   const double inf = pos_inf();
   V3 nn = v3(n);
-  V3 rn = v3(dot(nn, A.v1), dot(nn, A.v2), dot(nn, A.v3));
-  double rho = sqrt(rn.x * rn.x + rn.z * rn.z);
-  double ir = 1.0 / rho;
-  const double sb = rn.x * ir, cb = rn.z * ir;              // sin, cos of the bisector angle
-  const double ratio = ((dplane - dot(rn, A.trans)) * ir) / A.R;   // cos q
+  const double rx = dot(nn, A.v1), rz = dot(nn, A.v3);      // in-plane components of the face normal
+  double ir = 1.0 / sqrt(rx * rx + rz * rz);
+  const double sb = rx * ir, cb = rz * ir;                  // sin, cos of the bisector angle
+  const double ratio = ((dplane - dot(nn, A.center)) * ir) / A.R;   // cos q
   Gcad g;
-  g.entry = 0, g.exit = 0, g.entry_cos = 1, g.exit_cos = 1, g.continuous = true;
+  double entry = 0, entry_cos = 1;
+  g.exit = 0, g.exit_cos = 1, g.continuous = true;
   const bool front = cb > 0;            // bisector within (-pi/2, pi/2)
   if (ratio < 1 && ratio > -1) {
     const double sq = sqrt(1.0 - ratio * ratio);             // sin q > 0
@@ -172,24 +177,24 @@ R3D_HD Gcad tet_face_arc(const double n[3], double dplane, const TetArc& A) {
     const double sx = sb * ratio - cb * sq, cx = cb * ratio + sb * sq;   // exit  = bis - q
     // an angle is inside (-pi/2, pi/2) iff its cosine is positive; which infinity
     // replaces it otherwise depends on the side the bisector is on
-    g.entry = (ce > 0) ? se : (front ? inf : -inf);
+    entry = (ce > 0) ? se : (front ? inf : -inf);
     g.exit = (cx > 0) ? sx : (front ? -inf : inf);
-    g.entry_cos = ce, g.exit_cos = cx;
+    entry_cos = ce, g.exit_cos = cx;
     g.continuous = !front;
-    if (!(cb == cb)) g.entry = g.exit = cb;   // NaN bisector (the reference exit(1)s): propagate
+    if (!(cb == cb)) entry = g.exit = cb;   // NaN bisector (the reference exit(1)s): propagate
   }
   g.half = front ? sb : inf;
-  if (ratio >= 1) g.entry = -inf, g.exit = inf;
-  if (ratio <= -1) g.entry = inf, g.exit = -inf, g.half = -inf, g.continuous = false;
+  if (ratio >= 1) entry = -inf, g.exit = inf;
+  if (ratio <= -1) entry = inf, g.exit = -inf, g.half = -inf, g.continuous = false;
+  // the reference's 1e-10 rad of slack on the entry side becomes 1e-10 cos(entry) in sine space
+  g.entry_lo = entry - 0.0000000001 * entry_cos;
   return g;
 }
-// GCAD_RetVal::Inside (media_cellface.cpp:767-782); th is a sine or +-inf.  The
-// reference's 1e-10 rad of slack on the entry side becomes 1e-10 cos(entry).
+// GCAD_RetVal::Inside (media_cellface.cpp:767-782); th is a sine or +-inf.
 R3D_HD bool gcad_inside(const Gcad& g, double th) {
   const double inf = pos_inf();
-  const double lo = g.entry - 0.0000000001 * g.entry_cos;
-  if (g.continuous) return th <= g.exit && th >= lo;
-  return (th > -inf && th <= g.exit) || (th >= lo && th < inf);
+  if (g.continuous) return th <= g.exit && th >= g.entry_lo;
+  return (th > -inf && th <= g.exit) || (th >= g.entry_lo && th < inf);
 }
 // reference Tetra::GetPathToBoundary, media.cpp:518-567 (search part).
 // Result: face, and the exit point on the circle as (sin, cos); len is filled
@@ -225,9 +230,8 @@ R3D_HD double tet_exit_length(const TetArc& A, const TetExit& e) {
 // a0 + len/R for a scatter leg.
 R3D_HD void tet_advance(const CellTet& c, const TetArc& A, Phonon& p, double len, double s1, double c1) {
   const int t = p.type;
-  V3 q = v3(A.R * s1 + A.trans.x, A.trans.y, A.R * c1 + A.trans.z);  // new position, rotated frame
-  V3 nl = q.x * A.v1 + q.y * A.v2 + q.z * A.v3;                       // back-rotate (S^T)
-  V3 nd = c1 * A.v1 + (-s1) * A.v3;                                   // tangent (cos a, 0, -sin a)
+  V3 nl = A.center + ((A.R * s1) * A.v1 + (A.R * c1) * A.v3);   // point of the circle at the end angle
+  V3 nd = c1 * A.v1 + (-s1) * A.v3;                             // tangent (cos a, 0, -sin a)
   // time = (ln|tan(a1/2+pi/4)| - ln|tan(a0/2+pi/4)|) / |g|,  ln|tan(a/2+pi/4)| = atanh(sin a)
   double time = 0.5 * c.inv_gmag[t] * log(((1.0 + s1) * (1.0 - A.s0)) / ((1.0 - s1) * (1.0 + A.s0)));
   p.path += len, p.t += time, p.recent += time;
@@ -387,7 +391,12 @@ enum { R_P, R_SV, R_SH, T_P, T_SV, T_SH, RT_NUM };
 // ~20 fp64 divisions.  A vanishing or non-finite determinant gives the
 // reference a NaN total and hence its default choice; that case is tested
 // explicitly.
-R3D_HD bool full_rt(Phonon& p, Iface f, Rng& rng) {
+#if defined(__HIPCC__) && defined(R3D_NOINLINE_RT)
+__host__ __device__ __attribute__((noinline))
+#else
+R3D_HD
+#endif
+bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
   const V3 fnorm = f.normal;
   const V3 fpara = in_plane_unit_perp(fnorm, p.dir);
   const V3 fparash = cross(fnorm, fpara);
@@ -400,7 +409,7 @@ R3D_HD bool full_rt(Phonon& p, Iface f, Rng& rng) {
   int intype = 0;  // 0 P, 1 SH, 2 SV
   if (p.type == RAY_S) {  // ChooseSPolType, rtcoef.cpp:406-422
     double sh = dot(direction_of_motion(p), fparash);
-    intype = (rng_draw(rng) <= sh * sh) ? 1 : 2;
+    intype = (rng_draw(rng, key) <= sh * sh) ? 1 : 2;
   }
   const double rho1 = f.rhoR, rho2 = f.rhoT;
   const double a1 = f.vR[0], a2 = f.vT[0], b1 = f.vR[1], b2 = f.vT[1];
@@ -469,7 +478,7 @@ R3D_HD bool full_rt(Phonon& p, Iface f, Rng& rng) {
 #pragma unroll
   for (int i = 1; i < RT_NUM; i++) cum[i] = cum[i - 1] + w[i];
   const double total = cum[RT_NUM - 1];
-  const double ran = rng_draw(rng) * total;
+  const double ran = rng_draw(rng, key) * total;
   int choice = RT_NUM - 1;
 #pragma unroll
   for (int i = RT_NUM - 2; i >= 0; i--)

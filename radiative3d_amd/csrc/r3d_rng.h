@@ -22,10 +22,14 @@
 namespace r3d {
 
 struct Rng {
-  uint32_t id_lo, id_hi, key0, key1;
-  uint32_t k;        // next draw index
-  uint32_t w2, w3;   // second half of the current Philox block
+  uint32_t id_lo, id_hi;   // history id = Philox counter words 0,1
+  uint32_t k;              // next draw index
+  uint32_t w2, w3;         // second half of the current Philox block
 };
+struct RngKey {            // the run's seed: the same for every history, so not kept per lane
+  uint32_t k0, k1;
+};
+R3D_HD RngKey rng_key(uint64_t seed) { return RngKey{(uint32_t)seed, (uint32_t)(seed >> 32)}; }
 
 R3D_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -57,18 +61,17 @@ R3D_HD double u01_from_words(uint32_t hi, uint32_t lo) {
   return (double)(m + 1) * (1.0 / 9007199254740992.0);
 }
 
-R3D_HD void rng_init(Rng& g, uint64_t seed, uint64_t id) {
+R3D_HD void rng_init(Rng& g, uint64_t id) {
   g.id_lo = (uint32_t)id, g.id_hi = (uint32_t)(id >> 32);
-  g.key0 = (uint32_t)seed, g.key1 = (uint32_t)(seed >> 32);
   g.k = 0;
   g.w2 = g.w3 = 0;
 }
 
-R3D_HD double rng_draw(Rng& g) {
+R3D_HD double rng_draw(Rng& g, RngKey key) {
   double u;
   if ((g.k & 1u) == 0) {
     uint32_t w[4];
-    philox4x32_10(g.id_lo, g.id_hi, g.k >> 1, 0u, g.key0, g.key1, w);
+    philox4x32_10(g.id_lo, g.id_hi, g.k >> 1, 0u, key.k0, key.k1, w);
     g.w2 = w[2], g.w3 = w[3];
     u = u01_from_words(w[0], w[1]);
   } else {

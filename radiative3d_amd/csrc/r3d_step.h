@@ -69,17 +69,17 @@ R3D_HD int cell_neighbor(const CellSph& c, int f) { return c.nbr[f]; }
 // ---- source spray ----------------------------------------------------------
 R3D_HD void spray(const KArgs& a, Phonon& p, Rng& rng) {
   // 0 P, 1 SH, 2 SV: smallest k with r <= whole[k] (probability.cpp:104-128 on 3 entries)
-  const double r3 = a.src_whole[2] * rng_draw(rng);
+  const double r3 = a.src_whole[2] * rng_draw(rng, rng_key(a.seed));
   const int rt3 = (r3 <= a.src_whole[0]) ? 0 : (r3 <= a.src_whole[1]) ? 1 : 2;
 #ifdef R3D_ABLATE_SPRAY_SEARCH
-  uint64_t k = (uint64_t)(rng_draw(rng) * (double)(a.n_toa - 1));
+  uint64_t k = (uint64_t)(rng_draw(rng, rng_key(a.seed)) * (double)(a.n_toa - 1));
 #else
   // (selects, not a[rt3]: a dynamic index into the by-value argument block would
   //  make the compiler copy the arrays to scratch memory)
   const double* cdf = rt3 == 0 ? a.src_cdf[0] : rt3 == 1 ? a.src_cdf[1] : a.src_cdf[2];
   const uint32_t* guide = rt3 == 0 ? a.src_guide[0] : rt3 == 1 ? a.src_guide[1] : a.src_guide[2];
   const double total = rt3 == 0 ? a.src_total[0] : rt3 == 1 ? a.src_total[1] : a.src_total[2];
-  uint64_t k = sample_cdf_guided(cdf, guide, a.guide_bits, total, rng_draw(rng));
+  uint64_t k = sample_cdf_guided(cdf, guide, a.guide_bits, total, rng_draw(rng, rng_key(a.seed)));
 #endif
   p.t = p.path = p.recent = 0.0;
   p.amp = 1.0;
@@ -194,7 +194,7 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
 
   // --- free path to the next scattering event, drawn afresh every iteration
   //     (scatterers.cpp:297-307, phonons.cpp:601)
-  const double scatlen = -log(rng_draw(rng)) * T.scat_head[c.scat].mfp[p.type];
+  const double scatlen = -log(rng_draw(rng, rng_key(a.seed))) * T.scat_head[c.scat].mfp[p.type];
   const bool scatters = scatlen < e.len;
   const double len = scatters ? scatlen : e.len;
 
@@ -236,9 +236,9 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
     } else {
       const ScatHead& sh = T.scat_head[c.scat];
       const ScatPtrs* sp = a.scat_ptrs + c.scat;   // (indexed in place: a local copy would go to scratch)
-      int conv = sample_small(sh.whole[p.type], 4, rng_draw(rng));  // GPP GPS GSP GSS
+      int conv = sample_small(sh.whole[p.type], 4, rng_draw(rng, rng_key(a.seed)));  // GPP GPS GSP GSS
       uint64_t k = sample_cdf_guided(sp->cdf[conv], sp->guide[conv], a.guide_bits, sh.total[conv],
-                                     rng_draw(rng));
+                                     rng_draw(rng, rng_key(a.seed)));
       double rc = 1.0, rs = 0.0;      // relative polarisation 0 except S->S (scatterers.cpp:341-356)
       if (conv == 3) sincos(sp->spol[k], &rs, &rc);
       scatter_transform(p, v3(a.toa_xyz + 3 * k), rc, rs, (conv & 1) ? RAY_S : RAY_P);
@@ -266,11 +266,11 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
 #ifdef R3D_ABLATE_RT   // timing-only developer build: specular bounce / coin-flip transmission
     {
       double dn = dot(f.normal, p.dir);
-      crossed = adjoin && (rng_draw(rng) < 0.5);
+      crossed = adjoin && (rng_draw(rng, rng_key(a.seed)) < 0.5);
       if (!crossed) p.dir = p.dir - (2.0 * dn) * f.normal;
     }
 #else
-    crossed = full_rt(p, f, rng);
+    crossed = full_rt(p, f, rng, rng_key(a.seed));
 #endif
   } else {
     // Phonon::Refract without a grid discontinuity (phonons.cpp:243-252):

@@ -25,7 +25,7 @@ static void run_kind(const KArgs& a, uint64_t n, uint64_t first_id, uint64_t see
     Phonon p;
     Rng rng;
     LaneStats st = {0, 0, 0, 0, 0, 0, 0};
-    rng_init(rng, seed, first_id + i);
+    rng_init(rng, first_id + i);
     spray(a, p, rng);
     out->events[R3D_EV_GENERATED]++;
     int fate, reason = 0;
@@ -61,6 +61,7 @@ extern "C" int r3d_emul_run(const r3d_model_desc* m, uint64_t n, uint64_t first_
   PackedModel pm;
   pack_model(*m, pm);
   KArgs a = pm.args;
+  a.seed = seed;
   a.energy = out->energy;
   a.counts = reinterpret_cast<unsigned long long*>(out->counts);
   switch (m->cell_kind) {
