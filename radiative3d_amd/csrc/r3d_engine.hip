@@ -51,6 +51,19 @@ constexpr unsigned kRtBatch = R3D_RT_BATCH;      // parked R/T lanes that trigge
                                // measured on NSCP: 1 -> 56 ms, 2 -> 44 ms, 3 -> 89 ms (spills)
 #endif  // idle lanes that trigger a refill
 
+// ---- optional in-kernel phase timing (diagnostic build only: -DR3D_PHASE_TIMING) ----
+#ifdef R3D_PHASE_TIMING
+__device__ unsigned long long g_phase_cycles[8];
+#define R3D_STAMP(slot)                                                        \
+  do {                                                                         \
+    unsigned long long now__ = __builtin_readcyclecounter();                   \
+    if (lane == 0) atomicAdd(&s_phase[slot], now__ - t_phase);                 \
+    t_phase = now__;                                                           \
+  } while (0)
+#else
+#define R3D_STAMP(slot) do { } while (0)
+#endif
+
 // ---------------------------------------------------- wave-level helpers ----
 __device__ __forceinline__ double bcast(double v, int src) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -155,6 +168,12 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
     if (lane == 0 && m) atomicAdd(&s_tally[slot], (unsigned long long)__popcll(m));
   };
   constexpr int kEv = 3 + R3D_INV_NUM;
+#ifdef R3D_PHASE_TIMING
+  __shared__ unsigned long long s_phase[8];
+  if (threadIdx.x < 8) s_phase[threadIdx.x] = 0ull;
+  __syncthreads();
+  unsigned long long t_phase = __builtin_readcyclecounter();
+#endif
 
   Phonon p;
   Rng rng;
@@ -201,6 +220,7 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
       need = __ballot(!alive);
     }
     if (!__any(alive)) break;  // every lane idle and nothing left to hand out
+    R3D_STAMP(0);  // refill
 
     // ---- first half of the iteration for every running lane: search, draw, advance ----
     int fate = FATE_ALIVE, reason = 0;
@@ -208,6 +228,7 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
     const bool run = alive && !parked;
     if (run) fate = step_move<KIND>(a, T, p, rng, st, &reason, ev);
     const bool moved = run && fate == FATE_ALIVE;
+    R3D_STAMP(1);  // move
 
     // ---- seismometers.  Each arriving lane looks up its own hash cell (the loads of
     //      different lanes overlap); then the wave serves the arrivals that have
@@ -234,6 +255,8 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
       collect_wave<KIND>(a, T, p, ev.vel, k0, k1, src, lane, st.n_catch);
     }
 
+    R3D_STAMP(2);  // collect
+
     // ---- second half.  Scatter, bend and hand-over are served at once.  The
     //      reflection/transmission solve is the one long divergent branch (about a fifth
     //      of the lanes per iteration): lanes that need it park until kRtBatch of them
@@ -243,6 +266,7 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
       if (heavy) parked = true;
       else fate = step_event<KIND>(a, T, p, rng, st, ev);
     }
+    R3D_STAMP(3);  // light events
     if (kRtBatch > 1) {
       const unsigned n_parked = (unsigned)__popcll(__ballot(parked));
       const bool any_running = __any(alive && !parked && fate == FATE_ALIVE);
@@ -254,6 +278,7 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
       }
     }
 
+    R3D_STAMP(4);  // parked R/T
     // ---- book-keeping: this iteration's events, and lanes whose history ended ----
     tally(st.iterations != 0, kEv + R3D_EV_ITERATIONS);
     tally(st.scatter != 0, kEv + R3D_EV_SCATTER);
@@ -289,10 +314,15 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
         f->n_catch = (uint16_t)(lane_catches > 65535u ? 65535u : lane_catches);
       }
     }
+    R3D_STAMP(5);  // tallies + deaths
   }
 
+    // (end of loop body)
   // ---- flush the block's tallies to HBM: one atomic per counter per block ----
   __syncthreads();
+#ifdef R3D_PHASE_TIMING
+  if (threadIdx.x < 8) atomicAdd(&g_phase_cycles[threadIdx.x], s_phase[threadIdx.x]);
+#endif
   if (threadIdx.x < R3D_N_SCALARS && s_tally[threadIdx.x] != 0ull)
     atomicAdd(a.scalars + threadIdx.x, s_tally[threadIdx.x]);
 }
@@ -630,6 +660,15 @@ int r3d_run_traced(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, 
   if (!finals) return g_error = "null finals", 1;
   return run_host(e, n, first_id, seed, out, finals);
 }
+
+#ifdef R3D_PHASE_TIMING
+// diagnostic builds only: cumulative per-phase wave cycles since the last call
+int r3d_debug_phase_cycles(unsigned long long out[8]) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof zero) != hipSuccess;
+}
+#endif
 
 double r3d_last_kernel_ms(r3d_engine* e) {
   if (!e || !e->timed) return -1.0;

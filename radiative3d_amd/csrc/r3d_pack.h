@@ -127,6 +127,89 @@ inline uint32_t guide_bits_for(uint64_t n_toa) {
   return bits;
 }
 
+// ---- velocity-step classification of interior faces -------------------------
+// Phonon::Refract (phonons.cpp:243-252) evaluates max over P,S of
+// |2 (v2 - v1) / (v2 + v1)| at the crossing point and compares it with 1e-5.
+// On a face this is a ratio of affine functions of position (constants for
+// layered and spherical cells), so over the face it lies between its values at
+// the face's corners.  If every corner is safely below the threshold the face
+// is SMOOTH, if every corner is safely above it is a STEP; only faces that
+// straddle it keep the run-time test.  The 10 % guard band dwarfs any rounding
+// in where exactly on the face the phonon sits.
+inline double frac_step(double v1, double v2) { return std::fabs(2 * (v2 - v1) / (v2 + v1)); }
+
+inline uint32_t classify_from_corner_steps(const double* steps, int n) {
+  double lo = 1e300, hi = -1e300;
+  for (int i = 0; i < n; i++) {
+    if (!(steps[i] == steps[i])) return 0;   // NaN: decide at run time
+    lo = std::min(lo, steps[i]), hi = std::max(hi, steps[i]);
+  }
+  if (hi < 0.9e-5) return F_SMOOTH;
+  if (lo > 1.1e-5) return F_STEP;
+  return 0;
+}
+
+// Corner of a tetrahedron opposite face `skip`: intersection of the other three face planes.
+inline bool tet_corner(const r3d_cell& c, int skip, double out[3]) {
+  double A[3][4];
+  int r = 0;
+  for (int f = 0; f < 4; f++) {
+    if (f == skip) continue;
+    for (int k = 0; k < 3; k++) A[r][k] = c.faces[f].normal[k];
+    A[r][3] = dot3(c.faces[f].normal, c.faces[f].point);
+    r++;
+  }
+  for (int col = 0; col < 3; col++) {
+    int piv = col;
+    for (int i = col + 1; i < 3; i++)
+      if (std::fabs(A[i][col]) > std::fabs(A[piv][col])) piv = i;
+    if (A[piv][col] == 0) return false;
+    for (int k = 0; k < 4; k++) std::swap(A[piv][k], A[col][k]);
+    for (int i = 0; i < 3; i++) {
+      if (i == col) continue;
+      double f = A[i][col] / A[col][col];
+      for (int k = col; k < 4; k++) A[i][k] -= f * A[col][k];
+    }
+  }
+  for (int k = 0; k < 3; k++) out[k] = A[k][3] / A[k][k];
+  return true;
+}
+
+inline uint32_t classify_velocity_step(const r3d_model_desc& m, int ci, int f) {
+  const r3d_cell& c = m.cells[ci];
+  const r3d_face& F = c.faces[f];
+  if (!(F.flags & R3D_FACE_ADJOIN) || (F.flags & (R3D_FACE_DISCON | R3D_FACE_REFLECT))) return 0;
+  const r3d_cell& o = m.cells[F.neighbor];
+  if (m.cell_kind == R3D_CELL_CYLINDER) {
+    double s = std::max(frac_step(c.vel_c[0], o.vel_c[0]), frac_step(c.vel_c[1], o.vel_c[1]));
+    return classify_from_corner_steps(&s, 1);
+  }
+  if (m.cell_kind == R3D_CELL_SPHERESHELL) {
+    const double r2 = F.radius * F.radius;
+    double s = std::max(frac_step(c.vel_c[0] + c.vel_a[0] * r2, o.vel_c[0] + o.vel_a[0] * r2),
+                        frac_step(c.vel_c[1] + c.vel_a[1] * r2, o.vel_c[1] + o.vel_a[1] * r2));
+    return classify_from_corner_steps(&s, 1);
+  }
+  double steps[3];
+  int n = 0;
+  for (int corner = 0; corner < 4; corner++) {
+    if (corner == f) continue;                 // corners ON face f are those opposite the other faces
+    double x[3];
+    if (!tet_corner(c, corner, x)) return 0;
+    double s = 0;
+    for (int t = 0; t < 2; t++)
+      s = std::max(s, frac_step(dot3(c.vel_grad[t], x) + c.vel_c[t], dot3(o.vel_grad[t], x) + o.vel_c[t]));
+    steps[n++] = s;
+  }
+  return classify_from_corner_steps(steps, n);
+}
+
+inline uint32_t pack_flags_classified(const r3d_model_desc& m, int ci) {
+  uint32_t f = pack_flags(m.cells[ci]);
+  for (int i = 0; i < m.cells[ci].n_faces && i < 4; i++) f |= classify_velocity_step(m, ci, i) << (8 * i);
+  return f;
+}
+
 inline void pack_model(const r3d_model_desc& m, PackedModel& pm) {
   KArgs& a = pm.args;
   std::memset(&a, 0, sizeof a);
@@ -147,7 +230,7 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm) {
         d.d[f] = dot3(c.faces[f].normal, c.faces[f].point);
         d.nbr[f] = (c.faces[f].flags & R3D_FACE_ADJOIN) ? c.faces[f].neighbor : -1;
       }
-      d.flags = pack_flags(c);
+      d.flags = pack_flags_classified(m, i);
       d.scat = c.scatterer;
     }
     a.cyl_radius2 = m.cells[0].faces[2].radius * m.cells[0].faces[2].radius;
@@ -170,7 +253,7 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm) {
         d.d[f] = dot3(c.faces[f].normal, c.faces[f].point);
         d.nbr[f] = (c.faces[f].flags & R3D_FACE_ADJOIN) ? c.faces[f].neighbor : -1;
       }
-      d.flags = pack_flags(c);
+      d.flags = pack_flags_classified(m, i);
       d.scat = c.scatterer;
       for (int k = 0; k < 3; k++) pm.rho[i].g[k] = c.rho_grad[k];
       pm.rho[i].c = c.rho_c;
@@ -192,7 +275,7 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm) {
         d.radius[f] = c.faces[f].radius;
         d.nbr[f] = (c.faces[f].flags & R3D_FACE_ADJOIN) ? c.faces[f].neighbor : -1;
       }
-      d.flags = pack_flags(c);
+      d.flags = pack_flags_classified(m, i);
       d.scat = c.scatterer;
     }
     a.cells = pm.sph.data();

@@ -141,7 +141,7 @@ R3D_HD TetArc tet_arc(const CellTet& c, const Phonon& p) {
   V3 w2 = cross(g, p.dir), w1 = cross(w2, g);
   A.v1 = unit(w1), A.v3 = c.inv_gmag[t] * g;
   double txp = dot(p.dir, A.v1), tzp = dot(p.dir, A.v3);
-  A.R = 1.0 / ((txp / vel) * mag(g));
+  A.R = (vel * c.inv_gmag[t]) / txp;     // = 1 / ((t.v1 / v) |g|), media.hpp:568-569
   // In the rotated frame the phonon sits at R (-tz', 0, tx') from the centre
   // (media.hpp:574-580), i.e. centre = loc + R tz' v1 - R tx' v3.
   const double px = -A.R * tzp, pz = A.R * txp;
@@ -236,7 +236,10 @@ R3D_HD void tet_advance(const CellTet& c, const TetArc& A, Phonon& p, double len
   double time = 0.5 * c.inv_gmag[t] * log(((1.0 + s1) * (1.0 - A.s0)) / ((1.0 - s1) * (1.0 + A.s0)));
   p.path += len, p.t += time, p.recent += time;
   p.loc = nl;
-  p.dir = through_angles(unit(nd));
+  // (nd = c1 v1 - s1 v3 with v1, v3 orthonormal is unit to rounding; the reference's
+  //  renormalisation + (theta, phi) round trip changes it by ~1e-16 and is skipped --
+  //  the next leg rebuilds v1 from scratch, so nothing accumulates)
+  p.dir = nd;
   p.amp *= exp(c.att[t] * time);
   p.moves += 1;
 }

@@ -272,15 +272,21 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
 #else
     crossed = full_rt(p, f, rng, rng_key(a.seed));
 #endif
+  } else if (fl & F_SMOOTH) {
+    crossed = true;   // velocity step below 1e-5 everywhere on this face: plain hand-over
   } else {
     // Phonon::Refract without a grid discontinuity (phonons.cpp:243-252):
     // bend on a fractional velocity step > 1e-5, else plain hand-over.
     const Cell& o = T.cells[nbr];
     double v1 = cell_velocity(c, p.loc, 0), v2 = cell_velocity(o, p.loc, 0);
-    double dvp = fabs(2 * (v2 - v1) / (v2 + v1));
     double w1 = cell_velocity(c, p.loc, 1), w2 = cell_velocity(o, p.loc, 1);
-    double dvs = fabs(2 * (w2 - w1) / (w2 + w1));
-    if ((dvp > dvs ? dvp : dvs) > 0.00001) {
+    bool step = (fl & F_STEP) != 0;
+    if (!step) {      // straddling face: evaluate the reference's test here
+      double dvp = fabs(2 * (v2 - v1) / (v2 + v1));
+      double dvs = fabs(2 * (w2 - w1) / (w2 + w1));
+      step = (dvp > dvs ? dvp : dvs) > 0.00001;
+    }
+    if (step) {
       crossed = bend(p, cell_face_normal(c, ev.face, p.loc), p.type == RAY_P ? v1 : w1,
                      p.type == RAY_P ? v2 : w2);
     } else {

@@ -20,7 +20,13 @@
 namespace r3d {
 
 // face flag byte (same bit values as include/r3d.h)
-enum : uint32_t { F_COLLECT = 1u, F_REFLECT = 2u, F_ADJOIN = 4u, F_DISCON = 8u };
+enum : uint32_t { F_COLLECT = 1u, F_REFLECT = 2u, F_ADJOIN = 4u, F_DISCON = 8u,
+                  // engine-only, derived at pack time for ADJOIN faces without DISCON (see
+                  // classify_velocity_step in r3d_pack.h): the reference's run-time test
+                  // "fractional velocity step > 1e-5" (phonons.cpp:243-252) has the same
+                  // outcome everywhere on the face
+                  F_SMOOTH = 16u,   // never exceeds it: plain hand-over
+                  F_STEP = 32u };   // always exceeds it: Snell bend
 
 // ---- cells -----------------------------------------------------------------
 // Layered cylinder cell (reference RCUCylinder, media.hpp:312-331): uniform
