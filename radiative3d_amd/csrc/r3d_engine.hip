@@ -36,7 +36,12 @@
 
 namespace r3d {
 
-constexpr int kBlock = 256;          // 4 waves
+#ifndef R3D_BLOCK
+#define R3D_BLOCK 512
+#endif
+constexpr int kBlock = R3D_BLOCK;    // 8 waves = 2 per SIMD: one workgroup per CU shares one copy of the LDS tables
+constexpr int kWaves = kBlock / 64;
+constexpr unsigned kQueueCap = 128;  // per-wave catch queue entries (flushed 64 at a time)
 constexpr unsigned kChunk = 256;     // history ids a wave claims per global atomic
 #ifndef R3D_REFILL_MIN
 #define R3D_REFILL_MIN 8
@@ -72,14 +77,41 @@ __device__ __forceinline__ double bcast(double v, int src) {
 }
 __device__ __forceinline__ V3 bcast(V3 v, int src) { return v3(bcast(v.x, src), bcast(v.y, src), bcast(v.z, src)); }
 
+// Per-wave queue of seismometer catches, in LDS.  Bin updates are global atomics,
+// and on CDNA a wave's vector-memory operations retire in issue order: a load
+// issued after an atomic waits for it (~1-3 us under load).  Issuing the five
+// atomics of every catch where it happens would stall the next cell fetch a couple
+// of times per iteration.  Instead catches are parked here and flushed 64 at a
+// time, one catch per lane: one such stall per 64 catches, and full-width atomics.
+struct CatchQueue {
+  uint32_t slot[kQueueCap];      // (seismometer * n_bins + bin) * 2 + type
+  double e[4][kQueueCap];        // energy on X, Y, Z and total
+};
+
+__device__ __forceinline__ void flush_catches(const KArgs& a, CatchQueue& q, unsigned n, unsigned lane) {
+  if (lane < n) {
+    const uint32_t sl = q.slot[lane];
+    const size_t bin = sl >> 1;
+    const uint32_t type = sl & 1u;
+    double* e = a.energy + bin * 5;
+    unsafeAtomicAdd(e + 0, q.e[0][lane]);
+    unsafeAtomicAdd(e + 1, q.e[1][lane]);
+    unsafeAtomicAdd(e + 2, q.e[2][lane]);
+    unsafeAtomicAdd(e + 3 + type, q.e[3][lane]);
+    atomicAdd(a.counts + bin * 2 + type, 1ull);
+  }
+}
+
 // Seismometer collection for the arrival held by lane `src`, executed by the
 // whole wave: same tests and same bin updates as collect() in r3d_step.h
 // (reference dataout.cpp:103-216, :545-568), with the candidate receivers
-// [k0, k1) of the arrival's hash cell spread over the 64 lanes.
+// [k0, k1) of the arrival's hash cell spread over the 64 lanes.  q_count is the
+// wave-uniform fill of the wave's catch queue.
 template <int KIND>
 __device__ __forceinline__ void collect_wave(const KArgs& a, const Tables<KIND>& T, const Phonon& p,
                                              double vel_lane, uint32_t k0_lane, uint32_t k1_lane,
-                                             int src_lane, unsigned lane, uint32_t& lane_catches) {
+                                             int src_lane, unsigned lane, uint32_t& lane_catches,
+                                             CatchQueue& q, unsigned& q_count) {
   const int src = __builtin_amdgcn_readfirstlane(src_lane);
   const V3 loc = bcast(p.loc, src), dir = bcast(p.dir, src);
   const double t = bcast(p.t, src), amp = bcast(p.amp, src);
@@ -88,6 +120,7 @@ __device__ __forceinline__ void collect_wave(const KArgs& a, const Tables<KIND>&
   const int type = __builtin_amdgcn_readlane(p.type, src);
   const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)k0_lane, src);
   const uint32_t k1 = (uint32_t)__builtin_amdgcn_readlane((int)k1_lane, src);
+  const unsigned long long lane_lt = (1ull << lane) - 1ull;
   V3 dopm = dir;  // Phonon::DirectionOfMotion of the broadcast phonon
   if (type != RAY_P) {
     V3 th, ph;
@@ -98,6 +131,8 @@ __device__ __forceinline__ void collect_wave(const KArgs& a, const Tables<KIND>&
   for (uint32_t kb = k0; kb < k1; kb += 64u) {
     const uint32_t k = kb + lane;
     bool hit = false;
+    uint32_t hit_slot = 0;
+    double ex = 0, ey = 0, ez = 0, et = 0;
     if (k < k1) {
       const uint32_t s = a.grid.items[k];
       const SeisScan& S = T.seis_scan[s];
@@ -112,26 +147,53 @@ __device__ __forceinline__ void collect_wave(const KArgs& a, const Tables<KIND>&
           const uint32_t bin = (uint32_t)fl;
           const SeisHit& H = T.seis_hit[s];
           const double xf = dot(dopm, v3(H.axes[0])), yf = dot(dopm, v3(H.axes[1])), zf = dot(dopm, v3(H.axes[2]));
-          const double energy = (amp * amp) * H.inv_norm[type];
-          const size_t slot = (size_t)s * a.n_bins + bin;
-          double* e = a.energy + slot * 5;
-          unsafeAtomicAdd(e + 0, energy * (xf * xf));
-          unsafeAtomicAdd(e + 1, energy * (yf * yf));
-          unsafeAtomicAdd(e + 2, energy * (zf * zf));
-          unsafeAtomicAdd(e + 3 + type, energy);
-          atomicAdd(a.counts + slot * 2 + type, 1ull);
+          et = (amp * amp) * H.inv_norm[type];
+          ex = et * (xf * xf), ey = et * (yf * yf), ez = et * (zf * zf);
+          hit_slot = ((s * a.n_bins + bin) << 1) | (uint32_t)type;
           hit = true;
         }
       }
     }
-    hits += (uint32_t)__popcll(__ballot(hit));
+    const unsigned long long m = __ballot(hit);
+    if (m) {
+      if (hit) {
+        const unsigned at = q_count + (unsigned)__popcll(m & lane_lt);
+        q.slot[at] = hit_slot;
+        q.e[0][at] = ex, q.e[1][at] = ey, q.e[2][at] = ez, q.e[3][at] = et;
+      }
+      q_count += (unsigned)__popcll(m);
+      hits += (uint32_t)__popcll(m);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (q_count >= 64u) {   // flush the oldest 64, slide the rest down
+        flush_catches(a, q, 64u, lane);
+        const unsigned rest = q_count - 64u;
+        uint32_t ms = 0;
+        double m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+        if (lane < rest) {
+          ms = q.slot[64u + lane];
+          m0 = q.e[0][64u + lane], m1 = q.e[1][64u + lane], m2 = q.e[2][64u + lane], m3 = q.e[3][64u + lane];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < rest) {
+          q.slot[lane] = ms;
+          q.e[0][lane] = m0, q.e[1][lane] = m1, q.e[2][lane] = m2, q.e[3][lane] = m3;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        q_count = rest;
+      }
+    }
   }
   if ((int)lane == src) lane_catches += hits;
 }
 
 // --------------------------------------------------------------- the kernel --
 template <int KIND, bool LDS_CELLS, bool TRACE>
-__global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(const KArgs a) {
+__global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
   using Cell = typename CellOf<KIND>::type;
   extern __shared__ __align__(16) unsigned char smem[];
 
@@ -145,7 +207,8 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
     if (LDS_CELLS) copy_words(smem + a.lds_cells_off, a.cells, (size_t)a.n_cells * sizeof(Cell));
     copy_words(smem + a.lds_scat_off, a.scat_head, (size_t)a.n_scat * sizeof(ScatHead));
     copy_words(smem + a.lds_seis_off, a.seis_scan, (size_t)a.n_seis * sizeof(SeisScan));
-    copy_words(smem + a.lds_hit_off, a.seis_hit, (size_t)a.n_seis * sizeof(SeisHit));
+    if (a.lds_hit_off != 0xFFFFFFFFu)
+      copy_words(smem + a.lds_hit_off, a.seis_hit, (size_t)a.n_seis * sizeof(SeisHit));
     __syncthreads();
   }
   const unsigned lane = threadIdx.x & 63u;
@@ -155,11 +218,15 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
                       : reinterpret_cast<const Cell*>(a.cells);
   T.scat_head = reinterpret_cast<const ScatHead*>(smem + a.lds_scat_off);
   T.seis_scan = reinterpret_cast<const SeisScan*>(smem + a.lds_seis_off);
-  T.seis_hit = reinterpret_cast<const SeisHit*>(smem + a.lds_hit_off);
+  T.seis_hit = (a.lds_hit_off != 0xFFFFFFFFu) ? reinterpret_cast<const SeisHit*>(smem + a.lds_hit_off)
+                                              : a.seis_hit;
 
   // Tallies live in LDS, not in registers: each iteration the wave adds its lanes'
   // 0/1 events with one ballot + one LDS atomic per counter; the block flushes them
   // to HBM once at the end.  Slot order = r3d_run_device's d_scalars.
+  __shared__ CatchQueue s_queue[kWaves];
+  CatchQueue& queue = s_queue[threadIdx.x >> 6];
+  unsigned q_count = 0;   // wave-uniform
   __shared__ unsigned long long s_tally[R3D_N_SCALARS];
   if (threadIdx.x < R3D_N_SCALARS) s_tally[threadIdx.x] = 0ull;
   __syncthreads();
@@ -252,7 +319,7 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
     while (arrivals) {
       const int src = __ffsll((long long)arrivals) - 1;
       arrivals &= arrivals - 1ull;
-      collect_wave<KIND>(a, T, p, ev.vel, k0, k1, src, lane, st.n_catch);
+      collect_wave<KIND>(a, T, p, ev.vel, k0, k1, src, lane, st.n_catch, queue, q_count);
     }
 
     R3D_STAMP(2);  // collect
@@ -317,8 +384,8 @@ __global__ __launch_bounds__(kBlock, R3D_WAVES_PER_SIMD) void propagate_kernel(c
     R3D_STAMP(5);  // tallies + deaths
   }
 
-    // (end of loop body)
-  // ---- flush the block's tallies to HBM: one atomic per counter per block ----
+  // ---- drain the wave's catch queue, then flush the block's tallies to HBM ----
+  flush_catches(a, queue, q_count, lane);
   __syncthreads();
 #ifdef R3D_PHASE_TIMING
   if (threadIdx.x < 8) atomicAdd(&g_phase_cycles[threadIdx.x], s_phase[threadIdx.x]);
@@ -535,10 +602,15 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   if (e->lds_cells) a.lds_cells_off = (uint32_t)off, off = align16(off + cell_bytes);
   a.lds_scat_off = (uint32_t)off, off = align16(off + (size_t)m->n_scatterers * sizeof(ScatHead));
   a.lds_seis_off = (uint32_t)off, off = align16(off + (size_t)std::max(1, m->n_seismometers) * sizeof(SeisScan));
-  a.lds_hit_off = (uint32_t)off, off = align16(off + (size_t)std::max(1, m->n_seismometers) * sizeof(SeisHit));
+  // the kernel also has ~37 KB of static LDS (catch queues, tallies); the receiver "hit"
+  // records go to LDS only if everything still fits in the CU's 160 KB
+  const size_t kStaticLds = sizeof(CatchQueue) * kWaves + 1024;
+  const size_t hit_bytes = (size_t)std::max(1, m->n_seismometers) * sizeof(SeisHit);
+  a.lds_hit_off = 0xFFFFFFFFu;
+  if (off + hit_bytes + kStaticLds <= 160 * 1024) a.lds_hit_off = (uint32_t)off, off = align16(off + hit_bytes);
   e->lds_bytes = off;
-  if (e->lds_bytes > 160 * 1024) {
-    g_error = "model's scan tables exceed the 160 KB of LDS per CU";
+  if (e->lds_bytes + kStaticLds > 160 * 1024) {
+    g_error = "model's receiver scan table exceeds the 160 KB of LDS per CU";
     return nullptr;
   }
   hipDeviceProp_t prop;

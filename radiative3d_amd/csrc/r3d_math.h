@@ -25,6 +25,9 @@ constexpr double kPi90 = kPi * 0.5;
 constexpr double kPi360 = kPi * 2.0;
 
 R3D_HD double pos_inf() { return __builtin_inf(); }
+#if !defined(__HIPCC__)
+inline double rsqrt(double x) { return 1.0 / sqrt(x); }   // device builds use the HIP intrinsic
+#endif
 
 struct V3 {
   double x, y, z;
@@ -43,7 +46,7 @@ R3D_HD double mag2(V3 a) { return dot(a, a); }
 R3D_HD double mag(V3 a) { return sqrt(mag2(a)); }
 R3D_HD bool is_zero(V3 a) { return a.x == 0 && a.y == 0 && a.z == 0; }
 R3D_HD V3 unit(V3 a) {
-  double s = 1.0 / mag(a);
+  double s = rsqrt(mag2(a));
   return s * a;
 }
 R3D_HD V3 unit_else(V3 a, V3 fallback) {  // reference geom_r3.hpp:127-132
@@ -60,16 +63,17 @@ R3D_HD V3 through_angles(V3 v) {
   double h2 = v.x * v.x + v.y * v.y;
   double st = sqrt(fmax(0.0, 1.0 - v.z * v.z));
   if (h2 == 0) return v3(st, 0.0, v.z);  // atan2(0,0) = 0
-  double s = st / sqrt(h2);
+  double s = st * rsqrt(h2);
   return v3(s * v.x, s * v.y, v.z);
 }
 
 // theta^ and phi^ at unit direction d (reference OrthoAxes E1, E2,
 // geom_r3.cpp:222-224).
 R3D_HD void sph_basis(V3 d, V3& th_hat, V3& ph_hat) {
-  double st = sqrt(d.x * d.x + d.y * d.y);
-  double cp = 1.0, sp = 0.0;
-  if (st != 0) cp = d.x / st, sp = d.y / st;
+  double h2 = d.x * d.x + d.y * d.y;
+  double st = sqrt(h2);
+  double ih = (h2 != 0) ? rsqrt(h2) : 0.0;
+  double cp = (h2 != 0) ? d.x * ih : 1.0, sp = d.y * ih;
   th_hat = v3(d.z * cp, d.z * sp, -st);
   ph_hat = v3(-sp, cp, 0.0);
 }

@@ -60,13 +60,10 @@ R3D_HD void set_pol(Phonon& p, V3 pdom, V3 d) {
   V3 th, ph;
   sph_basis(d, th, ph);
   const double x = dot(pdom, th), y = dot(pdom, ph);
-  const double h = sqrt(x * x + y * y);
-  if (h == 0) {
-    p.pc = 1.0, p.ps = 0.0;   // atan2(0, 0) = 0
-  } else {
-    const double ih = 1.0 / h;
-    p.pc = x * ih, p.ps = y * ih;
-  }
+  const double h2 = x * x + y * y;
+  const double ih = rsqrt(h2);
+  p.pc = (h2 == 0) ? 1.0 : x * ih;   // atan2(0, 0) = 0
+  p.ps = (h2 == 0) ? 0.0 : y * ih;
 }
 
 // ===================================================================== CYL ==
@@ -160,32 +157,39 @@ struct Gcad {
   double exit_cos;            // cosine of the exit angle where that is finite
   bool continuous;
 };
-R3D_HD Gcad tet_face_arc(const double n[3], double dplane, const TetArc& A) {
+R3D_HD Gcad tet_face_arc(const double n[3], double dplane, const TetArc& A, double inv_R) {
+  // (written with selects and non-short-circuit logic: this runs four times per
+  //  iteration for every lane, and branches here cost more than the arithmetic)
   const double inf = pos_inf();
   V3 nn = v3(n);
   const double rx = dot(nn, A.v1), rz = dot(nn, A.v3);      // in-plane components of the face normal
-  double ir = 1.0 / sqrt(rx * rx + rz * rz);
+  const double ir = rsqrt(rx * rx + rz * rz);
   const double sb = rx * ir, cb = rz * ir;                  // sin, cos of the bisector angle
-  const double ratio = ((dplane - dot(nn, A.center)) * ir) / A.R;   // cos q
-  Gcad g;
-  double entry = 0, entry_cos = 1;
-  g.exit = 0, g.exit_cos = 1, g.continuous = true;
+  const double ratio = ((dplane - dot(nn, A.center)) * ir) * inv_R;   // cos q
   const bool front = cb > 0;            // bisector within (-pi/2, pi/2)
-  if (ratio < 1 && ratio > -1) {
-    const double sq = sqrt(1.0 - ratio * ratio);             // sin q > 0
-    const double se = sb * ratio + cb * sq, ce = cb * ratio - sb * sq;   // entry = bis + q
-    const double sx = sb * ratio - cb * sq, cx = cb * ratio + sb * sq;   // exit  = bis - q
-    // an angle is inside (-pi/2, pi/2) iff its cosine is positive; which infinity
-    // replaces it otherwise depends on the side the bisector is on
-    entry = (ce > 0) ? se : (front ? inf : -inf);
-    g.exit = (cx > 0) ? sx : (front ? -inf : inf);
-    entry_cos = ce, g.exit_cos = cx;
-    g.continuous = !front;
-    if (!(cb == cb)) entry = g.exit = cb;   // NaN bisector (the reference exit(1)s): propagate
-  }
+  const bool crosses = (ratio < 1) & (ratio > -1);
+  const double sq = sqrt(fmax(0.0, 1.0 - ratio * ratio));   // sin q > 0 when the circle crosses the plane
+  const double se = sb * ratio + cb * sq, ce = cb * ratio - sb * sq;   // entry = bis + q
+  const double sx = sb * ratio - cb * sq, cx = cb * ratio + sb * sq;   // exit  = bis - q
+  // an angle is inside (-pi/2, pi/2) iff its cosine is positive; which infinity
+  // replaces it otherwise depends on the side the bisector is on
+  double entry = (ce > 0) ? se : (front ? inf : -inf);
+  double exit = (cx > 0) ? sx : (front ? -inf : inf);
+  const bool bis_nan = !(cb == cb);     // NaN bisector (the reference exit(1)s): propagate
+  entry = bis_nan ? cb : entry, exit = bis_nan ? cb : exit;
+  // ratio outside (-1, 1) or NaN: the reference's defaults, then its two overrides
+  entry = crosses ? entry : 0.0, exit = crosses ? exit : 0.0;
+  double entry_cos = crosses ? ce : 1.0;
+  Gcad g;
+  g.exit_cos = crosses ? cx : 1.0;
+  g.continuous = crosses ? !front : true;
   g.half = front ? sb : inf;
-  if (ratio >= 1) entry = -inf, g.exit = inf;
-  if (ratio <= -1) entry = inf, g.exit = -inf, g.half = -inf, g.continuous = false;
+  const bool all_in = ratio >= 1, all_out = ratio <= -1;
+  entry = all_in ? -inf : (all_out ? inf : entry);
+  exit = all_in ? inf : (all_out ? -inf : exit);
+  g.half = all_out ? -inf : g.half;
+  g.continuous = all_out ? false : g.continuous;
+  g.exit = exit;
   // the reference's 1e-10 rad of slack on the entry side becomes 1e-10 cos(entry) in sine space
   g.entry_lo = entry - 0.0000000001 * entry_cos;
   return g;
@@ -193,8 +197,9 @@ R3D_HD Gcad tet_face_arc(const double n[3], double dplane, const TetArc& A) {
 // GCAD_RetVal::Inside (media_cellface.cpp:767-782); th is a sine or +-inf.
 R3D_HD bool gcad_inside(const Gcad& g, double th) {
   const double inf = pos_inf();
-  if (g.continuous) return th <= g.exit && th >= g.entry_lo;
-  return (th > -inf && th <= g.exit) || (th >= g.entry_lo && th < inf);
+  const bool below = th <= g.exit, above = th >= g.entry_lo;
+  const bool two_piece = ((th > -inf) & below) | (above & (th < inf));
+  return g.continuous ? (below & above) : two_piece;
 }
 // reference Tetra::GetPathToBoundary, media.cpp:518-567 (search part).
 // Result: face, and the exit point on the circle as (sin, cos); len is filled
@@ -204,18 +209,20 @@ struct TetExit {
   int face;
 };
 R3D_HD TetExit tet_exit(const CellTet& c, const TetArc& A) {
+  const double inv_R = 1.0 / A.R;
   Gcad rv[4];
 #pragma unroll
-  for (int i = 0; i < 4; i++) rv[i] = tet_face_arc(c.n[i], c.d[i], A);
+  for (int i = 0; i < 4; i++) rv[i] = tet_face_arc(c.n[i], c.d[i], A, inv_R);
   TetExit e{pos_inf(), 1.0, 0};
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const double x = rv[i].exit;
-    bool proper = gcad_inside(rv[(i + 1) & 3], x) && gcad_inside(rv[(i + 2) & 3], x) &&
-                  gcad_inside(rv[(i + 3) & 3], x);
+    const bool proper = gcad_inside(rv[(i + 1) & 3], x) & gcad_inside(rv[(i + 2) & 3], x) &
+                        gcad_inside(rv[(i + 3) & 3], x);
     // an exit behind the phonon (negative arc) is dismissed only beyond the face's bisector
-    if (proper && x < A.s0 && A.s0 > rv[i].half) proper = false;
-    if (proper && x < e.s) e.s = x, e.c = rv[i].exit_cos, e.face = i;
+    const bool dismissed = (x < A.s0) & (A.s0 > rv[i].half);
+    const bool take = proper & !dismissed & (x < e.s);
+    e.s = take ? x : e.s, e.c = take ? rv[i].exit_cos : e.c, e.face = take ? i : e.face;
   }
   return e;
 }

@@ -194,7 +194,12 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
 
   // --- free path to the next scattering event, drawn afresh every iteration
   //     (scatterers.cpp:297-307, phonons.cpp:601)
-  const double scatlen = -log(rng_draw(rng, rng_key(a.seed))) * T.scat_head[c.scat].mfp[p.type];
+  // scatlen = -ln(u) mfp.  Since -ln(u) >= 1 - u, (1-u) mfp >= len already rules a scatter
+  // out, and the logarithm is only taken for the lanes that pass this screen.
+  const double u_free = rng_draw(rng, rng_key(a.seed));
+  const double mfp = T.scat_head[c.scat].mfp[p.type];
+  double scatlen = pos_inf();
+  if (!((1.0 - u_free) * mfp >= e.len)) scatlen = -log(u_free) * mfp;
   const bool scatters = scatlen < e.len;
   const double len = scatters ? scatlen : e.len;
 
