@@ -40,6 +40,20 @@ def algorithmic_bytes_per_history(ev, n_toa, n_seis, cell_kind):
             + 104)
 
 
+def recorded_hbm_traffic(toa_degree, n):
+    """HBM bytes per launch of the traversal kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE + WRITE_SIZE, KiB -> bytes; profiles/r01/pmc_counters_bench_nscp_deg9.json).
+    PMC collection needs the profiler around the process, so bench.py cannot measure it in
+    line; the figure is only reported when it was taken on this very workload."""
+    path = os.path.join(REPO, "profiles", "r01", "pmc_counters_bench_nscp_deg9.json")
+    if toa_degree != 9 or n != 10_000_000 or not os.path.exists(path):
+        return None
+    try:
+        return float(json.load(open(path))["hbm_traffic_bytes_per_launch"])
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def usable_cores(cap=16):
     """Host cores this process may really use: affinity, cgroup CPU quota, and the
     GPU box's per-GPU share (16) as an upper bound."""
@@ -183,7 +197,8 @@ def main():
                        "cells": model.n_cells, "scatterers": model.n_scatterers,
                        "parallelism": f"history-id shards x{world}, one all-reduce of the bins per step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": recorded_hbm_traffic(args.toa_degree, n),
                          "kernel": "propagate_kernel<tetra>", "kernel_ms_avg": avg_ms,
                          "algorithmic_bytes_per_history": b_hist,
                          "events_per_history": {k: round(v, 4) for k, v in ev.items()}},
