@@ -4,32 +4,40 @@
 #   make host       radiative3d_amd/lib/libr3d_host.so   (g++)
 #   make engine     radiative3d_amd/lib/libr3d_hip.so    (hipcc, gfx950)
 #   make oracle     oracle/libr3d_oracle.so              (g++; test infrastructure)
+#   make cli        ./main                               (g++; the reference's command-line surface)
 #
 # `make -q` succeeding is what scripts/do-fundamentals.sh (reference :145-152)
 # checks before a run.
 
 CXX      ?= g++
 HIPCC    ?= /opt/rocm/bin/hipcc
-CXXFLAGS ?= -std=c++17 -O2 -fPIC -Wall -Wno-unused-function
-HIPFLAGS ?= -std=c++17 -O3 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function
+CXXFLAGS ?= -std=c++17 -O2 -fPIC -Wall -Wno-unused-function -Wno-unknown-pragmas
+HIPFLAGS ?= -std=c++17 -O3 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical
 
 LIBDIR   := radiative3d_amd/lib
 HOSTDIR  := radiative3d_amd/host
 CSRC     := radiative3d_amd/csrc
 
 HOST_SRC := $(HOSTDIR)/ecs.cpp $(HOSTDIR)/grid.cpp $(HOSTDIR)/model.cpp \
-            $(HOSTDIR)/models_builtin.cpp $(HOSTDIR)/cmdline.cpp $(HOSTDIR)/capi.cpp
+            $(HOSTDIR)/models_builtin.cpp $(HOSTDIR)/cmdline.cpp $(HOSTDIR)/dataout.cpp \
+            $(HOSTDIR)/capi.cpp
 HOST_HDR := $(wildcard $(HOSTDIR)/*.hpp) include/r3d.h include/r3d_host.h
 ENGINE_SRC := $(CSRC)/r3d_engine.hip
 ENGINE_HDR := $(wildcard $(CSRC)/*.h) include/r3d.h
 
-.PHONY: default all host engine oracle clean
+.PHONY: default all host engine oracle cli clean
 default: all
-all: host engine oracle
+all: host engine oracle cli
 
 host: $(LIBDIR)/libr3d_host.so
 engine: $(LIBDIR)/libr3d_hip.so
 oracle: oracle/libr3d_oracle.so
+cli: main
+
+# The command-line program the reference's do-*.sh scripts call as ./main
+main: $(HOSTDIR)/main.cpp $(LIBDIR)/libr3d_host.so $(LIBDIR)/libr3d_hip.so $(ENGINE_HDR)
+	$(CXX) $(CXXFLAGS) -pthread -o $@ $(HOSTDIR)/main.cpp -L$(LIBDIR) -lr3d_host -lr3d_hip \
+	    -Wl,-rpath,'$$ORIGIN/$(LIBDIR)' -Wl,-rpath,/opt/rocm/lib
 
 $(LIBDIR)/libr3d_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIBDIR)
@@ -43,4 +51,4 @@ oracle/libr3d_oracle.so: oracle/r3d_oracle.cpp oracle/philox.h include/r3d.h
 	$(CXX) $(CXXFLAGS) -shared -o $@ oracle/r3d_oracle.cpp
 
 clean:
-	rm -f $(LIBDIR)/*.so oracle/*.so
+	rm -f $(LIBDIR)/*.so oracle/*.so main

@@ -42,6 +42,18 @@ const char* r3dh_grid_dump(r3dh_model* m);
  * MFP_P, MFP_S, dipole_P, dipole_S (scatterers.cpp:420-478). Returns 0 ok.  */
 int r3dh_scatterer_info(const r3dh_model* m, int i, double out[10]);
 
+/* Scatterer dump block ("#  BEGIN SCATTERER DUMP:" ... "#  END SCATTERERS",
+ * scatterers.cpp:420-478) and the run-parameter echo (model.cpp:88-132).    */
+const char* r3dh_scatterer_dump(r3dh_model* m);
+const char* r3dh_params_echo(r3dh_model* m);
+
+/* Write the reference's output files for a finished run (dataout.cpp:623-694):
+ * seis_NNN.octv into `outdir` ("" = cwd), the ASCII traces into `trace_path`,
+ * out_mparams.octv-style parameters into `mparams_path` (NULL to skip).
+ * Returns the post-sim console summary text, or NULL on error.              */
+const char* r3dh_write_outputs(r3dh_model* m, const r3d_result* result, const char* outdir,
+                               const char* trace_path, const char* mparams_path);
+
 const char* r3dh_last_error(void);
 
 #ifdef __cplusplus

@@ -109,6 +109,12 @@ def host_lib():
         L.r3dh_scatterer_info.restype = C.c_int
         L.r3dh_scatterer_info.argtypes = [C.c_void_p, C.c_int, _dp]
         L.r3dh_last_error.restype = C.c_char_p
+        L.r3dh_scatterer_dump.restype = C.c_char_p
+        L.r3dh_scatterer_dump.argtypes = [C.c_void_p]
+        L.r3dh_params_echo.restype = C.c_char_p
+        L.r3dh_params_echo.argtypes = [C.c_void_p]
+        L.r3dh_write_outputs.restype = C.c_char_p
+        L.r3dh_write_outputs.argtypes = [C.c_void_p, C.POINTER(Result), C.c_char_p, C.c_char_p, C.c_char_p]
         _host = L
     return _host
 

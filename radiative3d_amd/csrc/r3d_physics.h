@@ -401,36 +401,18 @@ enum { R_P, R_SV, R_SH, T_P, T_SV, T_SH, RT_NUM };
 // ~20 fp64 divisions.  A vanishing or non-finite determinant gives the
 // reference a NaN total and hence its default choice; that case is tested
 // explicitly.
-#if defined(__HIPCC__) && defined(R3D_NOINLINE_RT)
-__host__ __device__ __attribute__((noinline))
-#else
-R3D_HD
-#endif
-bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
-  const V3 fnorm = f.normal;
-  const V3 fpara = in_plane_unit_perp(fnorm, p.dir);
-  const V3 fparash = cross(fnorm, fpara);
-  const double sini = dot(fpara, p.dir);
-  bool no_transmit = false;
-  if (!f.has_neighbor) {  // free surface: vanishing medium on the far side
-    f.rhoT = 0.0, f.vT[0] = f.vT[1] = 1e-12;
-    no_transmit = true;
-  }
-  int intype = 0;  // 0 P, 1 SH, 2 SV
-  if (p.type == RAY_S) {  // ChooseSPolType, rtcoef.cpp:406-422
-    double sh = dot(direction_of_motion(p), fparash);
-    intype = (rng_draw(rng, key) <= sh * sh) ? 1 : 2;
-  }
+// Outcome weights of one interface for incidence sine `sini` and incident type
+// `intype` (0 P, 1 SH, 2 SV): w[k] = |det|^2 x the reference's mProb[k]
+// (rtcoef.cpp:207-278, :107-198, :289-393); sn / cr = sine and real cosine of each
+// outgoing ray; det2 = |determinant|^2.  Outcome order R_P, R_SV, R_SH, T_P, T_SV,
+// T_SH (rtcoef.hpp:79-87).
+R3D_HD void rt_weights(const Iface& f, double sini, int intype, double w[RT_NUM], double sn[RT_NUM],
+                       double cr[RT_NUM], double& det2) {
   const double rho1 = f.rhoR, rho2 = f.rhoT;
   const double a1 = f.vR[0], a2 = f.vT[0], b1 = f.vR[1], b2 = f.vT[1];
-  // outcome order R_P, R_SV, R_SH, T_P, T_SV, T_SH (rtcoef.hpp:79-87)
-  double w[RT_NUM] = {0, 0, 0, 0, 0, 0};
-  double sn[RT_NUM] = {0, 0, 0, 0, 0, 0};   // sine of each outgoing angle
-  double cr[RT_NUM] = {0, 0, 0, 0, 0, 0};   // real part of each outgoing cosine
-  double det2;                              // |determinant|^2
-  int defchoice;
+#pragma unroll
+  for (int i = 0; i < RT_NUM; i++) w[i] = 0, sn[i] = 0, cr[i] = 0;
   if (intype == 1) {  // GetCoefs_SH, rtcoef.cpp:207-278
-    defchoice = R_SH;
     sn[R_SH] = sini;
     sn[T_SH] = (b2 / b1) * sini;
     const Cx cj1 = sqrt_real(1.0 - sn[R_SH] * sn[R_SH]);
@@ -442,7 +424,6 @@ bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
     w[T_SH] = rho2 * b2 * cj2.re * (4.0 * norm(a));
   } else {  // GetCoefs_PSV, rtcoef.cpp:107-198, :289-393
     const bool in_p = (intype == 0);
-    defchoice = in_p ? R_P : R_SV;
     const double ia1 = 1.0 / a1, ia2 = 1.0 / a2, ib1 = 1.0 / b1, ib2 = 1.0 / b2;
     const double pp = sini * (in_p ? ia1 : ib1);  // horizontal slowness
     sn[T_P] = a2 * pp, sn[T_SV] = b2 * pp, sn[R_SV] = b1 * pp, sn[R_P] = a1 * pp;
@@ -482,6 +463,31 @@ bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
     w[T_P] = rho2 * a2 * cTP.re * (norm(nTP) * (ia2 * ia2));
     w[T_SV] = rho2 * b2 * cTS.re * (norm(nTS) * (ib2 * ib2));
   }
+}
+
+#if defined(__HIPCC__) && defined(R3D_NOINLINE_RT)
+__host__ __device__ __attribute__((noinline))
+#else
+R3D_HD
+#endif
+bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
+  const V3 fnorm = f.normal;
+  const V3 fpara = in_plane_unit_perp(fnorm, p.dir);
+  const V3 fparash = cross(fnorm, fpara);
+  const double sini = dot(fpara, p.dir);
+  bool no_transmit = false;
+  if (!f.has_neighbor) {  // free surface: vanishing medium on the far side
+    f.rhoT = 0.0, f.vT[0] = f.vT[1] = 1e-12;
+    no_transmit = true;
+  }
+  int intype = 0;  // 0 P, 1 SH, 2 SV
+  if (p.type == RAY_S) {  // ChooseSPolType, rtcoef.cpp:406-422
+    double sh = dot(direction_of_motion(p), fparash);
+    intype = (rng_draw(rng, key) <= sh * sh) ? 1 : 2;
+  }
+  double w[RT_NUM], sn[RT_NUM], cr[RT_NUM], det2;
+  rt_weights(f, sini, intype, w, sn, cr, det2);
+  const int defchoice = intype == 0 ? R_P : intype == 1 ? R_SH : R_SV;   // GetCoefs, rtcoef.cpp:76-97
   // Choose, rtcoef.cpp:436-475
   double cum[RT_NUM];
   cum[0] = w[0];

@@ -4,7 +4,10 @@
 #include <sstream>
 
 #include "../../include/r3d_host.h"
+#include <fstream>
+
 #include "cmdline.hpp"
+#include "dataout.hpp"
 
 namespace {
 thread_local std::string g_error;
@@ -15,7 +18,7 @@ struct r3dh_model {
   MissionParams mission;
   std::ostringstream log;
   std::unique_ptr<Model> model;
-  std::string grid_dump;
+  std::string grid_dump, text;
 };
 
 extern "C" {
@@ -69,6 +72,42 @@ int r3dh_scatterer_info(const r3dh_model* m, int i, double out[10]) {
   const double v[10] = {s.nu, s.eps, s.a, s.kappa, s.el, s.gam0, s.mfp[0], s.mfp[1], s.dipole[0], s.dipole[1]};
   for (int k = 0; k < 10; k++) out[k] = v[k];
   return 0;
+}
+
+const char* r3dh_scatterer_dump(r3dh_model* m) {
+  if (!m) return "";
+  std::ostringstream os;
+  PrintAllScatteringStats(*m->model, os);
+  m->text = os.str();
+  return m->text.c_str();
+}
+
+const char* r3dh_params_echo(r3dh_model* m) {
+  if (!m) return "";
+  std::ostringstream os;
+  OutputModelParams(m->params, os);
+  m->text = os.str();
+  return m->text.c_str();
+}
+
+const char* r3dh_write_outputs(r3dh_model* m, const r3d_result* result, const char* outdir,
+                               const char* trace_path, const char* mparams_path) {
+  if (!m || !result || !trace_path) return nullptr;
+  try {
+    std::ostringstream console;
+    std::ofstream trace(trace_path);
+    if (!trace) throw Runtime(std::string("cannot open ") + trace_path);
+    OutputPostSimSummary(*m->model, *result, outdir ? outdir : "", console, trace);
+    if (mparams_path) {
+      std::ofstream f(mparams_path);
+      OutputModelParamsOctave(m->params, f);
+    }
+    m->text = console.str();
+    return m->text.c_str();
+  } catch (const std::exception& e) {
+    g_error = e.what();
+  }
+  return nullptr;
 }
 
 const char* r3dh_last_error(void) { return g_error.c_str(); }

@@ -113,6 +113,13 @@ EarthCoords::Generic EarthCoords::OutConvert(R3::XYZ p) const {
   return {p.x(), p.y(), p.z()};
 }
 
+// reference ecs.cpp:436-460: local (east, north, up) components unless --ocsraw
+EarthCoords::Generic EarthCoords::OutConvertDirectional(R3::XYZ loc, R3::XYZ dir) const {
+  if (mOut == OUT_NOTRANSFORM) return {dir.x(), dir.y(), dir.z()};
+  if (mOut == OUT_ECS) throw Runtime("ECS OutConvertDirectional: Unimplemented for this mapping");
+  return {dir.Dot(GetEast(loc)), dir.Dot(GetNorth(loc)), dir.Dot(GetUp(loc))};
+}
+
 // reference ecs.cpp:478-505 + :579-590
 Elastic::HElastic EarthCoords::OutConvert(R3::XYZ loc, Elastic::HElastic p) const {
   if (mOut == OUT_NOTRANSFORM || !mFlatten) return p;

@@ -60,6 +60,7 @@ class EarthCoords {
   R3::XYZ Convert(Generic g) const;                               // grid -> model space
   Elastic::HElastic Convert(Generic g, Elastic::HElastic p) const; // ... for properties
   Generic OutConvert(R3::XYZ loc) const;                          // model -> output coords
+  Generic OutConvertDirectional(R3::XYZ loc, R3::XYZ dir) const;  // direction at loc -> output axes
   Elastic::HElastic OutConvert(R3::XYZ loc, Elastic::HElastic p) const;
 
   Real FlattenDepth(Real z) const { return mRadE * std::log((mRadE + z) / mRadE); }

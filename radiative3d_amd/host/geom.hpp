@@ -9,6 +9,7 @@
 #define R3DH_GEOM_HPP_
 
 #include <cmath>
+#include <ostream>
 #include <vector>
 
 #include "typedefs.hpp"
@@ -151,6 +152,7 @@ class Matrix {
             m[2][0] * v.x() + m[2][1] * v.y() + m[2][2] * v.z()};
   }
   void ScaleBy(Real s) { *this *= s; }
+  void OutputContents(std::ostream& out) const;   // labelled dump (reference geom_r3.cpp:174-190)
   // Rescale so that the Frobenius norm squared becomes n2
   // (reference geom_r3.hpp:382-385).
   void SetSquaredMag(Real n2) {
@@ -165,6 +167,18 @@ class Matrix {
   }
 };
 
+inline void Matrix::OutputContents(std::ostream& out) const {
+  Real mag = Mag(), tr = Trace();
+  Real iso = tr * tr / (3.0 * mag * mag);
+  if (tr < 0) iso *= -1;
+  out << "The contents of this matrix are:" << std::endl
+      << "\tx\ty\tz\t" << std::endl
+      << "    +---------------------------" << std::endl
+      << "  x |\t" << m[0][0] << "\t" << m[0][1] << "\t" << m[0][2] << "\t\tMagnitude: " << mag << "\n"
+      << "  y |\t" << m[1][0] << "\t" << m[1][1] << "\t" << m[1][2] << "\t\tTrace:     " << tr << "\n"
+      << "  z |\t" << m[2][0] << "\t" << m[2][1] << "\t" << m[2][2] << "\t\tIso Frac:  " << iso << "\n"
+      << std::endl;
+}
 inline Matrix operator*(Matrix a, const Matrix& b) { return a *= b; }
 inline Matrix operator*(Matrix a, Real s) { return a *= s; }
 inline Matrix operator*(Real s, Matrix a) { return a *= s; }

@@ -1,0 +1,203 @@
+// main.cpp -- command-line shell around the HIP engine, flag-compatible with
+// the reference's `main` (reference main.cpp:27-136) so that the do-*.sh
+// drivers run unchanged: same option tokens, same stdout markers
+// ("@@ __PHASE__", "#  R3D_GRID:", "#  BEGIN SCATTERER DUMP:"), same output
+// files.  The N-phonon loop itself (Model::RunSimulation, model.cpp:602-633)
+// is one call into the engine's C-ABI.
+//
+// Differences a user can see: `--seed=S` and `--gpus=N` are accepted (the
+// reference seeds from the clock and is single-process); `--reports` keywords
+// other than INV / ALL_OFF are accepted but the per-event text stream is not
+// produced.
+#include <cstdlib>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+#include <thread>
+
+#include "../../include/r3d.h"
+#include "../csrc/r3d_physics.h"   // rt_weights(): the --rtcoef-test mission
+#include "cmdline.hpp"
+#include "dataout.hpp"
+
+namespace {
+
+void print_banner() {
+  std::cout << "**\n"
+            << "**  Radiative3D / MI355X engine - radiative transport in 3D Earth models\n"
+            << "**\n"
+            << "**  Propagation on AMD Instinct MI355X (HIP, fp64); model definition,\n"
+            << "**  options and output formats follow Radiative3D\n"
+            << "**  (https://github.com/christophersanborn/Radiative3D).\n"
+            << "**\n"
+            << "**  BUILD STATS:  " << r3d_version() << "\n"
+            << "**                Floating-point representation: " << (8 * sizeof(Real)) << "-bit\n"
+            << "**\n**\n";
+}
+
+// RTCoef::RunRTCoefTest(100, 10,8,4, 8,4,2) + PrintChosenRaytype (rtcoef.cpp:604-742),
+// without the random "Result" column.
+void run_rtcoef_test(unsigned n_sini, double rho1, double a1, double b1, double rho2, double a2,
+                     double b2) {
+  using namespace r3d;
+  const int width = 14;
+  const char* names[3] = {"RAY_P", "RAY_SH", "RAY_SV"};   // raytype order P, SH, SV (raytype.hpp)
+  for (int irt = 0; irt < 3; irt++) {
+    std::cout << "\n##RTCoef Probability Test:\n##\n##       Input Raytype:  " << names[irt] << "\n##\n"
+              << "##     Reflection Side:  (rho,alpha,beta) = ( " << rho1 << " " << a1 << " " << b1
+              << " )\n"
+              << "##   Transmission Side:  (rho,alpha,beta) = ( " << rho2 << " " << a2 << " " << b2
+              << " )\n##\n";
+    for (unsigned i = 0; i < n_sini; i++) {
+      const double theta = kPi90 * ((double)i / (n_sini - 1));
+      const V3 fnorm = v3(0, 0, 1), dir = v3(sin(theta), 0.0, cos(theta));
+      const double sini = dot(in_plane_unit_perp(fnorm, dir), dir);
+      Iface f;
+      f.normal = fnorm, f.has_neighbor = true;
+      f.rhoR = rho1, f.vR[0] = a1, f.vR[1] = b1, f.rhoT = rho2, f.vT[0] = a2, f.vT[1] = b2;
+      double w[RT_NUM], sn[RT_NUM], cr[RT_NUM], det2;
+      rt_weights(f, sini, irt, w, sn, cr, det2);
+      if (i == 0)
+        std::cout << "##" << std::setw(width) << "Sine_in" << std::setw(width) << "Prob_R_P"
+                  << std::setw(width) << "Prob_T_P" << std::setw(width) << "Prob_R_SV"
+                  << std::setw(width) << "Prob_T_SV" << std::setw(width) << "Prob_R_SH"
+                  << std::setw(width) << "Prob_T_SH" << "\n\n";
+      std::cout << "  " << std::setw(width) << sini;
+      for (int k : {R_P, T_P, R_SV, T_SV, R_SH, T_SH}) std::cout << std::setw(width) << w[k] / det2;
+      std::cout << "\n";
+    }
+  }
+}
+
+// --event-test (main.cpp:86-104, sources.cpp:71-87): radiation patterns on a
+// degree-3 take-off set, as GMT symbol rows.
+void run_event_test(const ModelParams& par) {
+  std::cout << "@@ __EVENT_SOURCE_TEST__" << std::endl;
+  ModelParams p = par;
+  p.TOA_Degree = 3;
+  p.GridSource = ModelParams::GRID_COMPILED;
+  if (p.CompiledSelector == 0) p.CompiledSelector = 40, p.CompiledArgs.clear();
+  std::ostringstream sink;
+  Model m(p, &sink);
+  const r3d_source& s = m.Desc().source;
+  const size_t n = m.Desc().n_toa;
+  const char* sym[3] = {"c", "-", "y"};
+  const double total = s.whole_cdf[2];
+  for (int t = 0; t < 3; t++) {
+    const double share = (s.whole_cdf[t] - (t ? s.whole_cdf[t - 1] : 0.0)) / total;
+    const double mag = s.cdf[t][n - 1];
+    for (size_t k = 0; k < n; k++) {
+      const double diff = mag == 0 ? 0 : (s.cdf[t][k] - (k ? s.cdf[t][k - 1] : 0.0)) / mag;
+      const S2::ThetaPhi& a = m.TOA()[k];
+      std::cout << std::setw(16) << Geometry::RtoD * a.Phi() << std::setw(16)
+                << 90.0 - Geometry::RtoD * a.Theta() << std::setw(16)
+                << std::sqrt(share * diff * n) * 0.2 << "  " << sym[t] << std::endl;
+    }
+  }
+}
+
+struct Shard {
+  std::vector<double> energy;
+  std::vector<uint64_t> counts;
+  r3d_result res{};
+  std::string error;
+};
+
+// The replacement for Model::RunSimulation()'s loop: shard the id range over the
+// requested GPUs (one engine per device, one host thread each), sum on the host.
+void run_simulation(const Model& model, uint64_t n, uint64_t seed, int gpus, r3d_result& total,
+                    std::vector<double>& energy, std::vector<uint64_t>& counts) {
+  const r3d_model_desc& d = model.Desc();
+  const size_t ne = (size_t)d.n_seismometers * d.params.n_bins * R3D_N_ENERGY;
+  const size_t nc = (size_t)d.n_seismometers * d.params.n_bins * R3D_N_COUNT;
+  energy.assign(ne, 0.0), counts.assign(nc, 0);
+  total = r3d_result{};
+  total.energy = energy.data(), total.counts = counts.data();
+  std::vector<Shard> shards(gpus);
+  std::vector<std::thread> pool;
+  for (int g = 0; g < gpus; g++) {
+    pool.emplace_back([&, g] {
+      Shard& sh = shards[g];
+      sh.energy.assign(ne, 0.0), sh.counts.assign(nc, 0);
+      sh.res.energy = sh.energy.data(), sh.res.counts = sh.counts.data();
+      const uint64_t lo = n / gpus * g + std::min<uint64_t>(g, n % gpus);
+      const uint64_t cnt = n / gpus + ((uint64_t)g < n % gpus ? 1 : 0);
+      r3d_engine* e = r3d_engine_create(&d, g);
+      if (!e) {
+        sh.error = r3d_last_error();
+        return;
+      }
+      if (r3d_run(e, cnt, lo, seed, &sh.res)) sh.error = r3d_last_error();
+      r3d_engine_destroy(e);
+    });
+  }
+  for (auto& t : pool) t.join();
+  for (const Shard& sh : shards) {
+    if (!sh.error.empty()) throw Runtime(sh.error);
+    for (size_t i = 0; i < ne; i++) energy[i] += sh.energy[i];
+    for (size_t i = 0; i < nc; i++) counts[i] += sh.counts[i];
+    total.n_lost += sh.res.n_lost, total.n_timeout += sh.res.n_timeout, total.n_invalid += sh.res.n_invalid;
+    for (int r = 0; r < R3D_INV_NUM; r++) total.invalid_reasons[r] += sh.res.invalid_reasons[r];
+    for (int k = 0; k < R3D_EV_NUM; k++) total.events[k] += sh.res.events[k];
+  }
+}
+
+}  // namespace
+
+int main(int argc, char* argv[]) {
+  print_banner();
+  MissionParams mission;
+  ModelParams par;
+  try {
+    ParseCommandLine(std::vector<std::string>(argv + 1, argv + argc), par, mission);
+  } catch (std::exception& e) {
+    std::cout << "** Error processing command-line options\n** Message: " << e.what()
+              << "\n** Exiting...\n";
+    return 1;
+  }
+  if (mission.bHelpMsg) {
+    std::cout << "\nOptions follow the Radiative3D manual (doc/MANUAL.md of the reference);\n"
+              << "additional: --seed=<n>  --gpus=<n>\n\n";
+    return 0;
+  }
+  OutputModelParams(par, std::cout);
+  if (mission.bOutputModParamsOctv) {
+    std::string fn = mission.OutputDir.empty() ? mission.FNModParamsOctv
+                                               : mission.OutputDir + "/" + mission.FNModParamsOctv;
+    std::ofstream f(fn.c_str());
+    OutputModelParamsOctave(par, f);
+  }
+  if (!mission.Reports.empty() && mission.Reports != "INV" && mission.Reports != "ALL_OFF")
+    std::cerr << "Note: per-event report stream (--reports=" << mission.Reports
+              << ") is not produced by the GPU engine.\n";
+  if (mission.bRTCoefTest) run_rtcoef_test(100, 10, 8, 4, 8, 4, 2);
+  const char* phase = "while constructing Earth model:";
+  try {
+    if (mission.bSourcePatternTest) run_event_test(par);
+    if (mission.bRunSim || mission.bDumpGrid) {
+      Model model(par);
+      phase = "during model retrospective output:";
+      if (mission.bDumpGrid) model.GetGridRef().DumpGridToAscii();
+      PrintAllScatteringStats(model, std::cout);
+      phase = "during simulation execution:";
+      if (mission.bRunSim) {
+        std::cout << "@@ __BEGINNING_SIMULATION__" << std::endl;
+        r3d_result res;
+        std::vector<double> energy;
+        std::vector<uint64_t> counts;
+        run_simulation(model, (uint64_t)std::max(0L, par.NumPhonons), mission.Seed,
+                       std::max(1, mission.Gpus), res, energy, counts);
+        std::cerr << "100% of " << par.NumPhonons << " have been cast.\n";
+        std::cout << "@@ __SIMULATION_COMPLETE__" << std::endl;
+        // seis_traces_asc.dat is opened in the CWD whatever --output-dir says (dataout.hpp:332)
+        std::ofstream trace("seis_traces_asc.dat");
+        OutputPostSimSummary(model, res, mission.OutputDir, std::cout, trace);
+      }
+    }
+  } catch (std::exception& e) {
+    std::cout << "**\n** Error " << phase << "\n** What: " << e.what() << "\n** Exiting...\n";
+    return 1;
+  }
+  return 0;
+}

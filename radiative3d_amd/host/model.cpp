@@ -557,6 +557,7 @@ R3::XYZ Model::FindSurface(R3::XYZ loc) const {
 // reference model.cpp:431-447 + events.cpp:42-107 (Aki & Richards box 9.10)
 void Model::BuildSource(const ModelParams& par) {
   Tensor::Tensor mt = par.EventSourceMT;
+  mEventMTUser = par.EventSourceMT;
   mEventLoc = ECS.Convert(par.EventSourceLoc);
   mt.Transform(ECS.GetXYZToLocalNEDRotation(mEventLoc));
   const Real mxx = mt.xx(), myy = mt.yy(), mzz = mt.zz();
@@ -623,6 +624,7 @@ void Model::BuildSeismometers(const ModelParams& par) {
     x1 = x2.Cross(x3);
     put3(s.axes[0], x1), put3(s.axes[1], x2), put3(s.axes[2], x3);
     mSeis.push_back(s);
+    mSeisAxes.push_back(sr.Orientation == ModelParams::AX_RTZ ? "RTZ" : "ENZ");
   }
 }
 

@@ -90,6 +90,11 @@ class Model {
   const Grid& GetGridRef() const { return mGrid; }
   long NumPhonons() const { return mNumPhonons; }
   const std::vector<ScattererInfo>& Scatterers() const { return mScatInfo; }
+  const std::vector<std::string>& SeisAxesDesc() const { return mSeisAxes; }   // "RTZ" / "ENZ" per seismometer
+  const Tensor::Tensor& EventMT() const { return mEventMTUser; }               // as given by the user (NED)
+  R3::XYZ EventLoc() const { return mEventLoc; }
+  bool OverridesMFP() const { return mOverrideMFP; }
+  bool NoDeflect() const { return mNoDeflect; }
   const std::vector<S2::ThetaPhi>& TOA() const { return mTOA; }
 
   // Locators (reference model.cpp:521-551, :562-594) over the flat tables.
@@ -118,6 +123,8 @@ class Model {
   std::vector<r3d_scatterer> mScatDesc;
   std::vector<double> mSrcCdf[3];
   std::vector<r3d_seismometer> mSeis;
+  std::vector<std::string> mSeisAxes;
+  Tensor::Tensor mEventMTUser;
   R3::XYZ mEventLoc;
   bool mOverrideMFP = false, mNoDeflect = false;
   Real mMFPOverride[2] = {0, 0};

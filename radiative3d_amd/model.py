@@ -135,6 +135,24 @@ class Model:
         keys = ("nu", "eps", "a", "kappa", "el", "gam0", "mfp_p", "mfp_s", "dipole_p", "dipole_s")
         return dict(zip(keys, out))
 
+    def scatterer_dump(self):
+        return self._lib.r3dh_scatterer_dump(self._h).decode()
+
+    def params_echo(self):
+        return self._lib.r3dh_params_echo(self._h).decode()
+
+    def write_outputs(self, result, outdir, trace_path=None, mparams_path=None):
+        """Write seis_NNN.octv (+ ASCII traces, + parameter file) in the reference's
+        formats; returns the post-sim console summary."""
+        import os
+        trace_path = trace_path or os.path.join(outdir or ".", "seis_traces_asc.dat")
+        c = result._as_c()
+        txt = self._lib.r3dh_write_outputs(self._h, C.byref(c), (outdir or "").encode(), trace_path.encode(),
+                                           mparams_path.encode() if mparams_path else None)
+        if txt is None:
+            raise RuntimeError("write_outputs failed: " + self._lib.r3dh_last_error().decode())
+        return txt.decode()
+
     def new_result(self):
         return Result(self.n_seismometers, self.n_bins)
 
