@@ -23,7 +23,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "user.cpp")
 @pytest.fixture(scope="module")
 def user_lib(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("userlib") / "libr3d_host_user.so")
-    srcs = [f for f in glob.glob(os.path.join(HOST, "*.cpp"))]
+    srcs = [f for f in glob.glob(os.path.join(HOST, "*.cpp")) if not f.endswith("main.cpp")]
     # user.cpp says #include "grid.hpp": feed it on stdin so that the quote-include
     # resolves through -I to THIS repo's grid.hpp, and the user_*_inc.cpp files
     # through the second -I to the reference directory.
