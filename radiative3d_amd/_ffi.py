@@ -81,7 +81,7 @@ def _load(path):
         raise RuntimeError(
             f"native library missing: {path} -- build it with `make` (or "
             f"`python -c 'import __graft_entry__ as g; g.build()'`); there is no fallback path")
-    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return C.CDLL(path)
 
 
 _host = None
