@@ -69,7 +69,8 @@ def usable_cores(cap=16):
 
 def cpu_baseline(model, budget_s=12.0):
     """The oracle (CPU port of the reference's algorithm) on this box's host
-    cores: one thread per core, each on its own id range, bounded to ~budget_s."""
+    cores: one thread per core, each on its own id range, bounded to ~budget_s.
+    Returns the JSON object and the summed CPU result (for the envelope check)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle_ffi
     cores = usable_cores()
@@ -79,15 +80,40 @@ def cpu_baseline(model, budget_s=12.0):
     per_thread = max(2000, int(per_core_rate * budget_s))
 
     def work(i):
-        oracle_ffi.run(model, per_thread, first_id=(1 << 50) + (i + 1) * per_thread)
+        return oracle_ffi.run(model, per_thread, first_id=(1 << 50) + (i + 1) * per_thread)
 
     t = time.perf_counter()
     with ThreadPoolExecutor(cores) as pool:   # ctypes releases the GIL during the call
-        list(pool.map(work, range(cores)))
+        parts = list(pool.map(work, range(cores)))
     dt = time.perf_counter() - t
-    return {"value": cores * per_thread / dt, "unit": "histories/s", "cores": cores, "kind": "port",
-            "sample": f"{cores * per_thread} histories of the same workload "
+    total = parts[0]
+    for p in parts[1:]:
+        total.energy += p.energy
+        total.counts += p.counts
+    n_cpu = cores * per_thread
+    line = {"value": n_cpu / dt, "unit": "histories/s", "cores": cores, "kind": "port",
+            "sample": f"{n_cpu} histories of the same workload "
                       f"({per_thread} per thread x {cores} threads, {dt:.1f} s), oracle/r3d_oracle.cpp"}
+    return line, total, n_cpu
+
+
+def envelope_agreement(gpu, n_gpu, cpu, n_cpu, min_count=25):
+    """BASELINE metric part 2, as SURVEY.md 8(d) defines it: per-history-normalised
+    energies e = Trace/N of every seismometer, component (X,Y,Z,P,S) and bin; sigma^2 of
+    each from the counts (e^2/n, summed for the two runs); RMS of (e_gpu - e_cpu)/sigma over
+    bins with at least `min_count` CPU counts.  The two runs use disjoint history ids
+    (independent samples), so a value near 1 means agreement; the target is <= 2."""
+    import numpy as np
+    eg, ec = gpu.energy / n_gpu, cpu.energy / n_cpu
+    ng = gpu.counts.sum(-1).astype(float)[..., None]
+    nc = cpu.counts.sum(-1).astype(float)[..., None]
+    sel = np.broadcast_to((nc >= min_count) & (ng >= min_count), eg.shape) & (ec > 0) & (eg > 0)
+    var = eg ** 2 / np.maximum(ng, 1) + ec ** 2 / np.maximum(nc, 1)
+    z = (eg - ec)[sel] / np.sqrt(var[sel])
+    return {"rms_sigma": float(np.sqrt(np.mean(z ** 2))), "bins": int(sel.sum()),
+            "gpu_histories": int(n_gpu), "cpu_histories": int(n_cpu), "min_count": min_count,
+            "definition": "SURVEY.md 8(d): RMS over (seis, component, bin) of (e_gpu-e_cpu)/sigma, "
+                          "sigma^2 = e^2/n per run; independent id ranges"}
 
 
 def main():
@@ -109,14 +135,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ   # torch.distributed.run
+    if under_launcher:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if under_launcher:   # also at world size 1, so the RCCL path is the one that runs
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     # ---- build the model (host) and put it in HBM: not timed --------------
@@ -149,7 +176,7 @@ def main():
         return engine
 
     def sync():
-        if world > 1:
+        if under_launcher:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -171,7 +198,7 @@ def main():
         step(args.warmup + args.steps + i)
         kernel_ms[i] = engine.last_kernel_ms()
     sync()
-    if world > 1:
+    if under_launcher:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -206,11 +233,12 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             note("timing the CPU baseline (oracle) ...")
-            line["cpu_baseline"] = cpu_baseline(model)
+            line["cpu_baseline"], cpu_res, n_cpu = cpu_baseline(model)
+            line["envelope"] = envelope_agreement(res, total, cpu_res, n_cpu)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if under_launcher:
         dist.barrier()
         dist.destroy_process_group()
 

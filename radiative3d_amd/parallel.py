@@ -24,8 +24,8 @@ def allreduce_result_(energy, counts, scalars):
     """In-place SUM over ranks of the result block.
 
     energy: float64 tensor, counts/scalars: int64 tensors (uint64 values are
-    below 2^63 by construction).  No-op when not running distributed."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    below 2^63 by construction).  No-op when no process group is initialised."""
+    if dist.is_available() and dist.is_initialized():
         for t in (energy, counts, scalars):
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return energy, counts, scalars
