@@ -227,6 +227,34 @@ int r3d_run_device(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,
 int r3d_run_traced(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,
                    r3d_result* out, r3d_final* finals);
 
+/* ---- optional volumetric scatter-event grid ---------------------------------
+ * The reference's "scattervid" data are one text line per SCT / REF event
+ * (dataout.cpp:484-520, 570-577), cut down to (t, x, y, z) per resulting wave
+ * type by vis/scattervid/preprocess.sh:17-29 and binned per frame floor(t/dt)
+ * by scattervid_above.m:111 -- 6.6 KB of text per history.  The engine keeps
+ * the histogram those scripts build, in HBM:
+ *     count[type(P,S)][frame][iz][iy][ix]   (uint32, model coordinates)
+ * incremented with one atomic at every scatter (SCT) and reflection (REF)
+ * event that falls inside the grid and the frame range.                      */
+typedef struct r3d_volume_desc {
+  double   origin[3];     /* model-space corner of cell (0,0,0)               */
+  double   cell_size[3];
+  uint32_t dims[3];       /* nx, ny, nz                                       */
+  uint32_t n_frames;
+  double   frame_dt;      /* seconds per frame                                */
+} r3d_volume_desc;
+
+/* Attach (or with v == NULL detach) a volume grid; allocates and zeroes
+ * 2 * n_frames * nz * ny * nx uint32 counters in HBM.  Subsequent runs
+ * accumulate into it.                                                        */
+int    r3d_engine_set_volume(r3d_engine* e, const r3d_volume_desc* v);
+size_t r3d_volume_len(const r3d_engine* e);            /* counters (0 if none) */
+/* Copy the counters to `out` (r3d_volume_len entries); reset != 0 zeroes them
+ * on the device afterwards.                                                  */
+int    r3d_volume_read(r3d_engine* e, uint32_t* out, int reset);
+/* Device address of the counters, for an RCCL reduction across ranks.        */
+void*  r3d_volume_device_ptr(r3d_engine* e);
+
 /* Duration in milliseconds of the traversal kernel launches enqueued by the
  * most recent r3d_run / r3d_run_device call on this engine, measured with
  * HIP events on the engine's stream (blocks until they have completed).    */

@@ -30,8 +30,22 @@ def lib():
                                          C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double)]
         L.r3d_oracle_boundary.argtypes = [C.POINTER(_ffi.ModelDesc), C.c_int, C.c_int, C.POINTER(C.c_double),
                                           C.c_double, C.c_double, C.POINTER(C.c_double)]
+        L.r3d_oracle_set_volume.argtypes = [C.POINTER(_ffi.VolumeDesc), C.POINTER(C.c_uint32)]
         _lib = L
     return _lib
+
+
+def run_with_volume(model, n, vdesc, first_id=0, seed=0x5EED):
+    """Oracle run that also fills the volumetric scatter-event grid; -> (result, counts[2,F,z,y,x])."""
+    import numpy as np
+    shape = (2, int(vdesc.n_frames), int(vdesc.dims[2]), int(vdesc.dims[1]), int(vdesc.dims[0]))
+    vol = np.zeros(shape, dtype=np.uint32)
+    lib().r3d_oracle_set_volume(C.byref(vdesc), vol.ctypes.data_as(C.POINTER(C.c_uint32)))
+    try:
+        res = run(model, n, first_id, seed)
+    finally:
+        lib().r3d_oracle_set_volume(None, None)
+    return res, vol
 
 
 def advance(model, cell, rtype, loc, theta, phi, length):

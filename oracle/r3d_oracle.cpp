@@ -174,6 +174,26 @@ struct TravelRec {  // media.hpp:94-119
   int face;
 };
 
+// Volumetric scatter-event grid (include/r3d.h r3d_volume_desc): what the reference's
+// video scripts histogram from the SCT / REF report lines (dataout.cpp:570-577,
+// vis/scattervid/preprocess.sh:17-29, scattervid_above.m:111), in model coordinates.
+const r3d_volume_desc* g_vol_desc = nullptr;
+uint32_t* g_vol = nullptr;
+void volume_count(double t, V loc, int type) {
+  if (!g_vol) return;
+  const r3d_volume_desc& v = *g_vol_desc;
+  double f = t * (1.0 / v.frame_dt);
+  double x = (loc.x - v.origin[0]) * (1.0 / v.cell_size[0]);
+  double y = (loc.y - v.origin[1]) * (1.0 / v.cell_size[1]);
+  double z = (loc.z - v.origin[2]) * (1.0 / v.cell_size[2]);
+  if (!(f >= 0 && x >= 0 && y >= 0 && z >= 0 && f < v.n_frames && x < v.dims[0] && y < v.dims[1] &&
+        z < v.dims[2]))
+    return;
+  size_t idx = ((((size_t)type * v.n_frames + (size_t)f) * v.dims[2] + (size_t)z) * v.dims[1] + (size_t)y) *
+                   v.dims[0] + (size_t)x;
+  g_vol[idx] += 1;
+}
+
 struct Ctx {
   const r3d_model_desc* m;
   oracle_rng rng;
@@ -902,6 +922,7 @@ int run_history(Ctx& c, Phonon& p) {
       Axes SS = express(AA, BB);
       p.theta = SS.theta, p.phi = SS.phi, p.pol = SS.rot, p.type = rtype;
       out.events[R3D_EV_SCATTER]++;
+      volume_count(p.t, p.loc, p.type);   // ReportScatterEvent
       continue;
     }
     move(p, travel);
@@ -910,6 +931,7 @@ int run_history(Ctx& c, Phonon& p) {
     if (face.flags & R3D_FACE_REFLECT) {
       refraction_full_rt(c, p, travel.face);
       out.events[R3D_EV_REFLECT]++;
+      volume_count(p.t, p.loc, p.type);   // ReportReflection
       continue;
     }
     if (face.flags & R3D_FACE_ADJOIN) {
@@ -920,6 +942,7 @@ int run_history(Ctx& c, Phonon& p) {
         refraction_bend(c, p, travel.face);
       else p.cell = face.neighbor;
       out.events[p.cell == old ? R3D_EV_REFLECT : R3D_EV_TRANSFER]++;
+      if (p.cell == old) volume_count(p.t, p.loc, p.type);   // ReportReflection
       continue;
     }
     out.n_lost++;
@@ -958,6 +981,13 @@ int r3d_oracle_run(const r3d_model_desc* model, uint64_t n, uint64_t first_id, u
     }
   }
   return 0;
+}
+
+// Attach (v != NULL) or detach the volumetric scatter-event grid for subsequent runs.
+void r3d_oracle_set_volume(const r3d_volume_desc* v, uint32_t* counters) {
+  static r3d_volume_desc copy;
+  if (v) copy = *v, g_vol_desc = &copy, g_vol = counters;
+  else g_vol_desc = nullptr, g_vol = nullptr;
 }
 
 // Known-answer hook for tests: reflection/transmission probabilities of one

@@ -70,6 +70,11 @@ class Result(C.Structure):
                 ("invalid_reasons", C.c_uint64 * R3D_INV_NUM), ("events", C.c_uint64 * R3D_EV_NUM)]
 
 
+class VolumeDesc(C.Structure):
+    _fields_ = [("origin", C.c_double * 3), ("cell_size", C.c_double * 3), ("dims", C.c_uint32 * 3),
+                ("n_frames", C.c_uint32), ("frame_dt", C.c_double)]
+
+
 class Final(C.Structure):
     _fields_ = [("time", C.c_double), ("path", C.c_double), ("amp", C.c_double),
                 ("loc", C.c_double * 3), ("dir", C.c_double * 3), ("moves", C.c_uint32),
@@ -140,6 +145,14 @@ def hip_lib():
         L.r3d_run_device.restype = C.c_int
         L.r3d_run_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.r3d_engine_set_volume.restype = C.c_int
+        L.r3d_engine_set_volume.argtypes = [C.c_void_p, C.POINTER(VolumeDesc)]
+        L.r3d_volume_len.restype = C.c_size_t
+        L.r3d_volume_len.argtypes = [C.c_void_p]
+        L.r3d_volume_read.restype = C.c_int
+        L.r3d_volume_read.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]
+        L.r3d_volume_device_ptr.restype = C.c_void_p
+        L.r3d_volume_device_ptr.argtypes = [C.c_void_p]
         L.r3d_last_kernel_ms.restype = C.c_double
         L.r3d_last_kernel_ms.argtypes = [C.c_void_p]
         L.r3d_last_error.restype = C.c_char_p

@@ -445,6 +445,8 @@ struct r3d_engine {
   bool timed = false;
   std::vector<std::unique_ptr<DevBuf>> bufs;
   DevBuf d_energy, d_counts, d_scalars, d_next;
+  std::unique_ptr<DevBuf> d_volume;
+  size_t volume_len = 0;
 
   DevBuf* keep(std::unique_ptr<DevBuf> b) {
     bufs.push_back(std::move(b));
@@ -741,6 +743,48 @@ int r3d_debug_phase_cycles(unsigned long long out[8]) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof zero) != hipSuccess;
 }
 #endif
+
+int r3d_engine_set_volume(r3d_engine* e, const r3d_volume_desc* v) {
+  const int fail_value = 1;
+  if (!e) return g_error = "null engine", 1;
+  R3D_HIP_OK(hipSetDevice(e->device));
+  R3D_HIP_OK(hipStreamSynchronize(e->stream));
+  e->d_volume.reset();
+  e->volume_len = 0;
+  KArgs& a = e->args;
+  a.vol = nullptr;
+  if (!v) return 0;
+  if (!(v->frame_dt > 0) || v->n_frames == 0 || v->dims[0] == 0 || v->dims[1] == 0 || v->dims[2] == 0 ||
+      !(v->cell_size[0] > 0) || !(v->cell_size[1] > 0) || !(v->cell_size[2] > 0))
+    return g_error = "volume grid: dimensions, cell sizes and frame length must be positive", 1;
+  const size_t len = (size_t)2 * v->n_frames * v->dims[2] * v->dims[1] * v->dims[0];
+  auto buf = std::make_unique<DevBuf>();
+  R3D_HIP_OK(buf->alloc_zero(len * sizeof(unsigned int)));
+  for (int k = 0; k < 3; k++) {
+    a.vol_origin[k] = v->origin[k], a.vol_inv_cell[k] = 1.0 / v->cell_size[k], a.vol_dim[k] = v->dims[k];
+  }
+  a.vol_frames = v->n_frames;
+  a.vol_inv_dt = 1.0 / v->frame_dt;
+  a.vol = reinterpret_cast<unsigned int*>(buf->p);
+  e->d_volume = std::move(buf);
+  e->volume_len = len;
+  return 0;
+}
+
+size_t r3d_volume_len(const r3d_engine* e) { return e ? e->volume_len : 0; }
+
+void* r3d_volume_device_ptr(r3d_engine* e) { return (e && e->d_volume) ? e->d_volume->p : nullptr; }
+
+int r3d_volume_read(r3d_engine* e, uint32_t* out, int reset) {
+  const int fail_value = 1;
+  if (!e || !e->d_volume) return g_error = "no volume grid attached", 1;
+  if (!out) return g_error = "null output", 1;
+  R3D_HIP_OK(hipSetDevice(e->device));
+  R3D_HIP_OK(hipStreamSynchronize(e->stream));
+  R3D_HIP_OK(hipMemcpy(out, e->d_volume->p, e->volume_len * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (reset) R3D_HIP_OK(hipMemset(e->d_volume->p, 0, e->volume_len * sizeof(uint32_t)));
+  return 0;
+}
 
 double r3d_last_kernel_ms(r3d_engine* e) {
   if (!e || !e->timed) return -1.0;

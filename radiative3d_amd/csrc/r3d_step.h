@@ -18,9 +18,11 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 #define R3D_ADD_F64(ptr, val) unsafeAtomicAdd((ptr), (val))
 #define R3D_ADD_U64(ptr, val) atomicAdd((ptr), (unsigned long long)(val))
+#define R3D_ADD_U32(ptr, val) atomicAdd((ptr), (unsigned int)(val))
 #else
 #define R3D_ADD_F64(ptr, val) (*(ptr) += (val))
 #define R3D_ADD_U64(ptr, val) (*(ptr) += (unsigned long long)(val))
+#define R3D_ADD_U32(ptr, val) (*(ptr) += (unsigned int)(val))
 #endif
 
 namespace r3d {
@@ -142,6 +144,24 @@ R3D_HD void collect(const KArgs& a, const Tables<KIND>& T, const Phonon& p, doub
   }
 }
 
+// ---- volumetric scatter-event grid (include/r3d.h r3d_volume_desc) ------------
+// One count per SCT / REF event, binned by resulting wave type, frame
+// floor(t / dt) and model-space cell: the histogram the reference's video
+// scripts build from its per-event text stream.
+R3D_HD void volume_count(const KArgs& a, const Phonon& p) {
+  if (!a.vol) return;
+  const double f = p.t * a.vol_inv_dt;
+  const double x = (p.loc.x - a.vol_origin[0]) * a.vol_inv_cell[0];
+  const double y = (p.loc.y - a.vol_origin[1]) * a.vol_inv_cell[1];
+  const double z = (p.loc.z - a.vol_origin[2]) * a.vol_inv_cell[2];
+  if (!(f >= 0 && x >= 0 && y >= 0 && z >= 0 && f < a.vol_frames && x < a.vol_dim[0] &&
+        y < a.vol_dim[1] && z < a.vol_dim[2]))
+    return;
+  const size_t idx = ((((size_t)p.type * a.vol_frames + (size_t)f) * a.vol_dim[2] + (size_t)z) *
+                          a.vol_dim[1] + (size_t)y) * a.vol_dim[0] + (size_t)x;
+  R3D_ADD_U32(a.vol + idx, 1u);
+}
+
 // ---- one loop iteration, in two halves --------------------------------------
 // What the first half leaves for the second.
 struct Pending {
@@ -248,6 +268,7 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
       if (conv == 3) sincos(sp->spol[k], &rs, &rc);
       scatter_transform(p, v3(a.toa_xyz + 3 * k), rc, rs, (conv & 1) ? RAY_S : RAY_P);
     }
+    volume_count(a, p);   // SCT
     return FATE_ALIVE;
   }
   const uint32_t fl = ev.flags;
@@ -298,8 +319,12 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
       crossed = true;
     }
   }
-  if (crossed) p.cell = nbr, st.transfer++;
-  else st.reflect++;
+  if (crossed) {
+    p.cell = nbr, st.transfer++;
+  } else {
+    st.reflect++;
+    volume_count(a, p);   // REF
+  }
   return FATE_ALIVE;
 }
 

@@ -140,6 +140,10 @@ struct KArgs {
   unsigned long long* counts;
   unsigned long long* scalars;
   void* finals;              // r3d_final[n] or null
+  // optional volumetric scatter-event grid (null = off): count[type][frame][z][y][x]
+  unsigned int* vol;
+  double vol_origin[3], vol_inv_cell[3], vol_inv_dt;
+  uint32_t vol_dim[3], vol_frames;
   // LDS carve-up (bytes from the start of dynamic shared memory)
   uint32_t lds_cells_off;    // 0xFFFFFFFF: cells stay in HBM
   uint32_t lds_scat_off;

@@ -157,6 +157,14 @@ class Model:
         return Result(self.n_seismometers, self.n_bins)
 
 
+def volume_desc(origin, cell_size, dims, n_frames, frame_dt):
+    v = _ffi.VolumeDesc()
+    for k in range(3):
+        v.origin[k], v.cell_size[k], v.dims[k] = origin[k], cell_size[k], dims[k]
+    v.n_frames, v.frame_dt = n_frames, frame_dt
+    return v
+
+
 class Engine:
     """The model resident in HBM + the HIP traversal kernels (libr3d_hip.so)."""
 
@@ -200,6 +208,24 @@ class Engine:
                                       None, stream)
         if rc:
             raise RuntimeError("r3d_run_device failed: " + self._lib.r3d_last_error().decode())
+
+    # -- volumetric scatter-event grid (config 5 of BASELINE.json) -----------
+    def set_volume(self, origin, cell_size, dims, n_frames, frame_dt):
+        """Attach count[type][frame][z][y][x] (uint32, HBM) filled at SCT / REF events."""
+        v = volume_desc(origin, cell_size, dims, n_frames, frame_dt)
+        if self._lib.r3d_engine_set_volume(self._e, C.byref(v)):
+            raise RuntimeError("r3d_engine_set_volume failed: " + self._lib.r3d_last_error().decode())
+        self._vol_shape = (2, int(n_frames), int(dims[2]), int(dims[1]), int(dims[0]))
+
+    def read_volume(self, reset=False):
+        out = np.zeros(self._vol_shape, dtype=np.uint32)
+        assert out.size == self._lib.r3d_volume_len(self._e)
+        if self._lib.r3d_volume_read(self._e, out.ctypes.data_as(C.POINTER(C.c_uint32)), int(reset)):
+            raise RuntimeError("r3d_volume_read failed: " + self._lib.r3d_last_error().decode())
+        return out
+
+    def volume_device_ptr(self):
+        return self._lib.r3d_volume_device_ptr(self._e)
 
     def last_kernel_ms(self):
         return float(self._lib.r3d_last_kernel_ms(self._e))

@@ -55,6 +55,13 @@ static void run_kind(const KArgs& a, uint64_t n, uint64_t first_id, uint64_t see
   }
 }
 
+static r3d_volume_desc g_vol_desc;
+static uint32_t* g_vol = nullptr;
+extern "C" void r3d_emul_set_volume(const r3d_volume_desc* v, uint32_t* counters) {
+  g_vol = v ? counters : nullptr;
+  if (v) g_vol_desc = *v;
+}
+
 extern "C" int r3d_emul_run(const r3d_model_desc* m, uint64_t n, uint64_t first_id, uint64_t seed,
                             r3d_result* out, r3d_final* finals) {
   if (!m || !out) return 1;
@@ -64,6 +71,13 @@ extern "C" int r3d_emul_run(const r3d_model_desc* m, uint64_t n, uint64_t first_
   a.seed = seed;
   a.energy = out->energy;
   a.counts = reinterpret_cast<unsigned long long*>(out->counts);
+  if (g_vol) {
+    for (int k = 0; k < 3; k++) {
+      a.vol_origin[k] = g_vol_desc.origin[k], a.vol_inv_cell[k] = 1.0 / g_vol_desc.cell_size[k];
+      a.vol_dim[k] = g_vol_desc.dims[k];
+    }
+    a.vol_frames = g_vol_desc.n_frames, a.vol_inv_dt = 1.0 / g_vol_desc.frame_dt, a.vol = g_vol;
+  }
   switch (m->cell_kind) {
     case R3D_CELL_CYLINDER: run_kind<CELL_CYL>(a, n, first_id, seed, out, finals); break;
     case R3D_CELL_TETRA: run_kind<CELL_TET>(a, n, first_id, seed, out, finals); break;

@@ -24,8 +24,21 @@ def lib():
         L.r3d_emul_run.restype = C.c_int
         L.r3d_emul_run.argtypes = [C.POINTER(_ffi.ModelDesc), C.c_uint64, C.c_uint64, C.c_uint64,
                                    C.POINTER(_ffi.Result), C.POINTER(_ffi.Final)]
+        L.r3d_emul_set_volume.argtypes = [C.POINTER(_ffi.VolumeDesc), C.POINTER(C.c_uint32)]
         _lib = L
     return _lib
+
+
+def run_with_volume(model, n, vdesc, first_id=0, seed=0x5EED):
+    import numpy as np
+    shape = (2, int(vdesc.n_frames), int(vdesc.dims[2]), int(vdesc.dims[1]), int(vdesc.dims[0]))
+    vol = np.zeros(shape, dtype=np.uint32)
+    lib().r3d_emul_set_volume(C.byref(vdesc), vol.ctypes.data_as(C.POINTER(C.c_uint32)))
+    try:
+        res = run(model, n, first_id, seed)
+    finally:
+        lib().r3d_emul_set_volume(None, None)
+    return res, vol
 
 
 def run(model, n, first_id=0, seed=0x5EED, result=None, trace=False):
