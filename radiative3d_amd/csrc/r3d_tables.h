@@ -144,6 +144,9 @@ struct KArgs {
   unsigned int* vol;
   double vol_origin[3], vol_inv_cell[3], vol_inv_dt;
   uint32_t vol_dim[3], vol_frames;
+  // scheduling knobs (wave-uniform)
+  uint32_t rt_batch;         // parked R/T lanes that trigger the solve (<= 1: never park)
+  uint32_t refill_min;       // idle lanes that trigger a refill
   // LDS carve-up (bytes from the start of dynamic shared memory)
   uint32_t lds_cells_off;    // 0xFFFFFFFF: cells stay in HBM
   uint32_t lds_scat_off;
