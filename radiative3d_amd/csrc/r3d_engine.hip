@@ -37,24 +37,25 @@
 namespace r3d {
 
 #ifndef R3D_BLOCK
-#define R3D_BLOCK 512
+#define R3D_BLOCK 768
 #endif
-constexpr int kBlock = R3D_BLOCK;    // 8 waves = 2 per SIMD: one workgroup per CU shares one copy of the LDS tables
+// One workgroup per CU shares one copy of the LDS tables.  12 waves = 3 per SIMD, i.e. a
+// budget of 168 registers per lane (__launch_bounds__).  Measured on the four models
+// (TOA degree 9): 512 threads (2 per SIMD, 183 registers, no spills) 31.6 / 35.5 / 78.4 /
+// 10.9 ms, 768 threads (a few spills in the R/T solve) 30.2 / 33.6 / 67.5 / 8.8 ms,
+// 1024 threads (128 registers, heavy spills) slower than either.
+constexpr int kBlock = R3D_BLOCK;
 constexpr int kWaves = kBlock / 64;
 constexpr unsigned kQueueCap = 128;  // per-wave catch queue entries (flushed 64 at a time)
 constexpr unsigned kChunk = 256;     // history ids a wave claims per global atomic
 #ifndef R3D_REFILL_MIN
 #define R3D_REFILL_MIN 8
 #endif
-constexpr unsigned kRefillMin = R3D_REFILL_MIN;
+constexpr unsigned kRefillMin = R3D_REFILL_MIN;   // idle lanes that trigger a refill
 #ifndef R3D_RT_BATCH
 #define R3D_RT_BATCH 24
 #endif
 constexpr unsigned kRtBatch = R3D_RT_BATCH;      // parked R/T lanes that trigger the solve (<= 1: no parking)
-#ifndef R3D_WAVES_PER_SIMD
-#define R3D_WAVES_PER_SIMD 2   // register budget 512 / N per lane (second __launch_bounds__ argument);
-                               // measured on NSCP: 1 -> 56 ms, 2 -> 44 ms, 3 -> 89 ms (spills)
-#endif  // idle lanes that trigger a refill
 
 // ---- optional in-kernel phase timing (diagnostic build only: -DR3D_PHASE_TIMING) ----
 #ifdef R3D_PHASE_TIMING
@@ -89,6 +90,9 @@ struct CatchQueue {
 };
 
 __device__ __forceinline__ void flush_catches(const KArgs& a, CatchQueue& q, unsigned n, unsigned lane) {
+#ifdef R3D_ABLATE_CATCH   // timing-only developer build: drop the bin updates
+  return;
+#endif
   if (lane < n) {
     const uint32_t sl = q.slot[lane];
     const size_t bin = sl >> 1;
@@ -102,6 +106,43 @@ __device__ __forceinline__ void flush_catches(const KArgs& a, CatchQueue& q, uns
   }
 }
 
+// Per-workgroup accumulators for seismometer bins, in LDS.  First arrivals pile
+// onto a handful of (seismometer, time-bin) records -- in the LopNor runs one bin
+// takes a quarter of all catches and sixteen take 58 % -- and atomics on one
+// address are served one after the other by a single L2 channel: measured, that
+// contention alone was half of the LopNor kernel time.  So a catch first tries a
+// small open-addressed table here (first come, first admitted; hot bins show up
+// early and often); the block adds each entry to HBM once, at the end.  A catch
+// that finds no entry takes the queue above.
+struct BinCache {
+  double* e;        // [n][5] energies X, Y, Z, P, S
+  uint32_t* key;    // [n]    seismometer * n_bins + bin, or kEmpty
+  uint32_t* cnt;    // [n][2] catches by type
+  uint32_t mask, shift;   // n - 1, 32 - log2 n
+  bool on;
+};
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+constexpr size_t kAccEntryBytes = 5 * sizeof(double) + 3 * sizeof(uint32_t);
+
+__device__ __forceinline__ bool bin_cache_add(const BinCache& bc, uint32_t bin, uint32_t type, double ex,
+                                              double ey, double ez, double et) {
+  uint32_t idx = (bin * 2654435761u) >> bc.shift;
+  for (int probe = 0; probe < 4; probe++) {
+    const uint32_t old = atomicCAS(&bc.key[idx], kEmpty, bin);
+    if (old == kEmpty || old == bin) {
+      double* e = bc.e + idx * 5u;
+      unsafeAtomicAdd(e + 0, ex);
+      unsafeAtomicAdd(e + 1, ey);
+      unsafeAtomicAdd(e + 2, ez);
+      unsafeAtomicAdd(e + 3 + type, et);
+      atomicAdd(&bc.cnt[idx * 2u + type], 1u);
+      return true;
+    }
+    idx = (idx + 1u) & bc.mask;
+  }
+  return false;
+}
+
 // Seismometer collection for the arrival held by lane `src`, executed by the
 // whole wave: same tests and same bin updates as collect() in r3d_step.h
 // (reference dataout.cpp:103-216, :545-568), with the candidate receivers
@@ -111,7 +152,7 @@ template <int KIND>
 __device__ __forceinline__ void collect_wave(const KArgs& a, const Tables<KIND>& T, const Phonon& p,
                                              double vel_lane, uint32_t k0_lane, uint32_t k1_lane,
                                              int src_lane, unsigned lane, uint32_t& lane_catches,
-                                             CatchQueue& q, unsigned& q_count) {
+                                             const BinCache& bc, CatchQueue& q, unsigned& q_count) {
   const int src = __builtin_amdgcn_readfirstlane(src_lane);
   const V3 loc = bcast(p.loc, src), dir = bcast(p.dir, src);
   const double t = bcast(p.t, src), amp = bcast(p.amp, src);
@@ -143,7 +184,7 @@ __device__ __forceinline__ void collect_wave(const KArgs& a, const Tables<KIND>&
         if (S.r_in[type] <= 0) arv += dot(to, dir) / vel;
         const double scaled = arv / a.time_per_bin;
         const double fl = floor(scaled);
-        if (scaled >= 0.0 && fl < (double)a.n_bins) {
+        if (scaled >= 0.0 && fl < a.n_bins_f) {
           const uint32_t bin = (uint32_t)fl;
           const SeisHit& H = T.seis_hit[s];
           const double xf = dot(dopm, v3(H.axes[0])), yf = dot(dopm, v3(H.axes[1])), zf = dot(dopm, v3(H.axes[2]));
@@ -154,7 +195,9 @@ __device__ __forceinline__ void collect_wave(const KArgs& a, const Tables<KIND>&
         }
       }
     }
-    const unsigned long long m = __ballot(hit);
+    hits += (uint32_t)__popcll(__ballot(hit));
+    if (bc.on && hit && bin_cache_add(bc, hit_slot >> 1, (uint32_t)type, ex, ey, ez, et)) hit = false;
+    const unsigned long long m = __ballot(hit);   // catches the accumulators did not take
     if (m) {
       if (hit) {
         const unsigned at = q_count + (unsigned)__popcll(m & lane_lt);
@@ -162,7 +205,6 @@ __device__ __forceinline__ void collect_wave(const KArgs& a, const Tables<KIND>&
         q.e[0][at] = ex, q.e[1][at] = ey, q.e[2][at] = ez, q.e[3][at] = et;
       }
       q_count += (unsigned)__popcll(m);
-      hits += (uint32_t)__popcll(m);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -209,8 +251,21 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
     copy_words(smem + a.lds_seis_off, a.seis_scan, (size_t)a.n_seis * sizeof(SeisScan));
     if (a.lds_hit_off != 0xFFFFFFFFu)
       copy_words(smem + a.lds_hit_off, a.seis_hit, (size_t)a.n_seis * sizeof(SeisHit));
+    if (a.acc_bits) {   // energies and counts zero, keys empty
+      const size_t n = (size_t)1 << a.acc_bits;
+      unsigned long long* z = reinterpret_cast<unsigned long long*>(smem + a.lds_acc_off);
+      for (size_t i = threadIdx.x; i < n * 5; i += kBlock) z[i] = 0ull;
+      uint32_t* k = reinterpret_cast<uint32_t*>(smem + a.lds_acc_off + n * 5 * sizeof(double));
+      for (size_t i = threadIdx.x; i < n * 3; i += kBlock) k[i] = (i < n) ? kEmpty : 0u;
+    }
     __syncthreads();
   }
+  BinCache bc;
+  bc.on = a.acc_bits != 0;
+  bc.e = reinterpret_cast<double*>(smem + a.lds_acc_off);
+  bc.key = reinterpret_cast<uint32_t*>(smem + a.lds_acc_off + ((size_t)5 * sizeof(double) << a.acc_bits));
+  bc.cnt = bc.key + ((size_t)1 << a.acc_bits);
+  bc.mask = (1u << a.acc_bits) - 1u, bc.shift = 32u - a.acc_bits;
   const unsigned lane = threadIdx.x & 63u;
   const unsigned long long lane_lt = (1ull << lane) - 1ull;
   Tables<KIND> T;
@@ -293,6 +348,14 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
     int fate = FATE_ALIVE, reason = 0;
     LaneStats st = {0, 0, 0, 0, 0, 0, 0};   // this iteration's events of this lane
     const bool run = alive && !parked;
+#if defined(R3D_PHASE_TIMING) && defined(R3D_PROBE_FETCH)
+    if (run) {   // exposed latency of the cell fetch: touch both cache lines of the record, wait
+      const volatile double* rec = reinterpret_cast<const volatile double*>(&T.cells[p.cell]);
+      double x0 = rec[0], x1 = rec[sizeof(Cell) / 8 - 1];
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(x0), "v"(x1));
+    }
+    R3D_STAMP(6);
+#endif
     if (run) fate = step_move<KIND>(a, T, p, rng, st, &reason, ev);
     const bool moved = run && fate == FATE_ALIVE;
     R3D_STAMP(1);  // move
@@ -307,7 +370,7 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
       const double fx = (p.loc.x - g.origin[0]) * g.inv_h;
       const double fy = (p.loc.y - g.origin[1]) * g.inv_h;
       const double fz = (p.loc.z - g.origin[2]) * g.inv_h;
-      if (fx >= 0 && fy >= 0 && fz >= 0 && fx < g.dim[0] && fy < g.dim[1] && fz < g.dim[2]) {
+      if (fx >= 0 && fy >= 0 && fz >= 0 && fx < g.dim_f[0] && fy < g.dim_f[1] && fz < g.dim_f[2]) {
         const int cellid = ((int)fz * g.dim[1] + (int)fy) * g.dim[0] + (int)fx;
         k0 = g.start[cellid], k1 = g.start[cellid + 1];
       }
@@ -319,26 +382,35 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
     while (arrivals) {
       const int src = __ffsll((long long)arrivals) - 1;
       arrivals &= arrivals - 1ull;
-      collect_wave<KIND>(a, T, p, ev.vel, k0, k1, src, lane, st.n_catch, queue, q_count);
+      collect_wave<KIND>(a, T, p, ev.vel, k0, k1, src, lane, st.n_catch, bc, queue, q_count);
     }
 
     R3D_STAMP(2);  // collect
 
-    // ---- second half.  Scatter, bend and hand-over are served at once.  The
-    //      reflection/transmission solve is the one long divergent branch (about a fifth
-    //      of the lanes per iteration): lanes that need it park until kRtBatch of them
-    //      have gathered -- or nothing else can run -- and then take it together ----
+    // ---- second half.  Bend and hand-over are served at once.  The two long divergent
+    //      branches can be deferred: lanes that need the reflection/transmission solve, or
+    //      the scattering draw (a chain of dependent table probes whose latency the whole
+    //      wave would sit through for one or two lanes), park until rt_batch resp.
+    //      scat_batch of them have gathered -- or nothing else can run -- and then take
+    //      the branch together.  Draws are per-history counters, so the order in which
+    //      lanes are served does not change any history ----
     if (moved) {
-      const bool heavy = a.rt_batch > 1 && ev.face >= 0 && (ev.flags & (F_REFLECT | F_DISCON)) != 0;
+      const bool is_sc = ev.face < 0;
+      const bool is_rt = !is_sc && (ev.flags & (F_REFLECT | F_DISCON)) != 0;
+      const bool heavy = (is_rt & (a.rt_batch > 1)) | (is_sc & (a.scat_batch > 1));
       if (heavy) parked = true;
       else fate = step_event<KIND>(a, T, p, rng, st, ev);
     }
     R3D_STAMP(3);  // light events
-    if (a.rt_batch > 1) {
-      const unsigned n_parked = (unsigned)__popcll(__ballot(parked));
-      const bool any_running = __any(alive && !parked && fate == FATE_ALIVE);
-      if (n_parked >= a.rt_batch || (n_parked > 0 && !any_running)) {
-        if (parked) {
+    if (a.rt_batch > 1 || a.scat_batch > 1) {
+      const unsigned long long pm = __ballot(parked);
+      if (pm) {
+        const unsigned n_sc = (unsigned)__popcll(__ballot(parked && ev.face < 0));
+        const unsigned n_rt = (unsigned)__popcll(pm) - n_sc;
+        const bool any_running = __any(alive && !parked && fate == FATE_ALIVE);
+        const bool fire_rt = n_rt >= a.rt_batch || (n_rt > 0 && !any_running);
+        const bool fire_sc = n_sc >= a.scat_batch || (n_sc > 0 && !any_running);
+        if (parked && ((ev.face < 0) ? fire_sc : fire_rt)) {
           fate = step_event<KIND>(a, T, p, rng, st, ev);
           parked = false;
         }
@@ -387,6 +459,23 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
   // ---- drain the wave's catch queue, then flush the block's tallies to HBM ----
   flush_catches(a, queue, q_count, lane);
   __syncthreads();
+  if (bc.on) {
+    for (uint32_t i = threadIdx.x; i <= bc.mask; i += kBlock) {
+      const uint32_t bin = bc.key[i];
+      if (bin == kEmpty) continue;
+      double* e = a.energy + (size_t)bin * 5;
+#pragma unroll
+      for (int c = 0; c < 5; c++) {
+        const double v = bc.e[i * 5u + c];
+        if (v != 0.0) unsafeAtomicAdd(e + c, v);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const uint32_t n = bc.cnt[i * 2u + t];
+        if (n) atomicAdd(a.counts + (size_t)bin * 2 + t, (unsigned long long)n);
+      }
+    }
+  }
 #ifdef R3D_PHASE_TIMING
   if (threadIdx.x < 8) atomicAdd(&g_phase_cycles[threadIdx.x], s_phase[threadIdx.x]);
 #endif
@@ -569,6 +658,8 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   a.rt_batch = (m->cell_kind == R3D_CELL_TETRA) ? kRtBatch : 1u;
   a.refill_min = kRefillMin;
   if (const char* s = getenv("R3D_RT_BATCH")) a.rt_batch = (uint32_t)atoi(s);       // developer tuning
+  a.scat_batch = 1u;
+  if (const char* s = getenv("R3D_SCAT_BATCH")) a.scat_batch = (uint32_t)atoi(s);
   if (const char* s = getenv("R3D_REFILL_MIN")) a.refill_min = (uint32_t)std::max(1, atoi(s));
   hipError_t err = hipSuccess;
   // ---- move every table into HBM and point the launch arguments at it ----
@@ -617,6 +708,15 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   const size_t hit_bytes = (size_t)std::max(1, m->n_seismometers) * sizeof(SeisHit);
   a.lds_hit_off = 0xFFFFFFFFu;
   if (off + hit_bytes + kStaticLds <= 160 * 1024) a.lds_hit_off = (uint32_t)off, off = align16(off + hit_bytes);
+  // what is left (minus a little slack) goes to the bin accumulators
+  a.lds_acc_off = (uint32_t)off, a.acc_bits = 0;
+  if (m->n_seismometers > 0) {
+    const size_t left = 160 * 1024 - std::min<size_t>(160 * 1024, off + kStaticLds + 2048);
+    uint32_t bits = 0;
+    while (bits < 11 && (kAccEntryBytes << (bits + 1)) <= left) bits++;
+    if (const char* s = getenv("R3D_ACC_BITS")) bits = std::min<uint32_t>(bits, (uint32_t)atoi(s));   // developer tuning
+    if (bits >= 5) a.acc_bits = bits, off = align16(off + (kAccEntryBytes << bits));
+  }
   e->lds_bytes = off;
   if (e->lds_bytes + kStaticLds > 160 * 1024) {
     g_error = "model's receiver scan table exceeds the 160 KB of LDS per CU";
@@ -769,8 +869,9 @@ int r3d_engine_set_volume(r3d_engine* e, const r3d_volume_desc* v) {
   R3D_HIP_OK(buf->alloc_zero(len * sizeof(unsigned int)));
   for (int k = 0; k < 3; k++) {
     a.vol_origin[k] = v->origin[k], a.vol_inv_cell[k] = 1.0 / v->cell_size[k], a.vol_dim[k] = v->dims[k];
+    a.vol_dim_f[k] = (double)v->dims[k];
   }
-  a.vol_frames = v->n_frames;
+  a.vol_frames = v->n_frames, a.vol_frames_f = (double)v->n_frames;
   a.vol_inv_dt = 1.0 / v->frame_dt;
   a.vol = reinterpret_cast<unsigned int*>(buf->p);
   e->d_volume = std::move(buf);

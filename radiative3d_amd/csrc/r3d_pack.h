@@ -53,6 +53,7 @@ inline void build_seis_grid(const r3d_model_desc& m, SeisGrid& g, std::vector<ui
   const int n = m.n_seismometers;
   g.n_cells = 0;
   g.dim[0] = g.dim[1] = g.dim[2] = 0;
+  g.dim_f[0] = g.dim_f[1] = g.dim_f[2] = 0.0;
   g.inv_h = 0;
   g.origin[0] = g.origin[1] = g.origin[2] = 0;
   start.assign(2, 0);
@@ -81,7 +82,7 @@ inline void build_seis_grid(const r3d_model_desc& m, SeisGrid& g, std::vector<ui
     return cells;
   };
   while (dims_for(h) > 2.0e6) h *= 1.5;
-  for (int k = 0; k < 3; k++) g.origin[k] = lo[k], g.dim[k] = d[k];
+  for (int k = 0; k < 3; k++) g.origin[k] = lo[k], g.dim[k] = d[k], g.dim_f[k] = (double)d[k];
   g.inv_h = 1.0 / h;
   g.n_cells = d[0] * d[1] * d[2];
   std::vector<std::vector<uint32_t>> buckets(g.n_cells);
@@ -359,6 +360,7 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm) {
 
   // ---- scalars ----
   a.n_bins = par.n_bins;
+  a.n_bins_f = (double)par.n_bins;
   a.no_deflect = par.no_deflect;
   a.ttl = par.ttl;
   a.time_per_bin = par.time_per_bin;

@@ -109,7 +109,7 @@ R3D_HD void collect(const KArgs& a, const Tables<KIND>& T, const Phonon& p, doub
   double fx = (p.loc.x - g.origin[0]) * g.inv_h;
   double fy = (p.loc.y - g.origin[1]) * g.inv_h;
   double fz = (p.loc.z - g.origin[2]) * g.inv_h;
-  if (!(fx >= 0 && fy >= 0 && fz >= 0 && fx < g.dim[0] && fy < g.dim[1] && fz < g.dim[2])) return;
+  if (!(fx >= 0 && fy >= 0 && fz >= 0 && fx < g.dim_f[0] && fy < g.dim_f[1] && fz < g.dim_f[2])) return;
   int cellid = ((int)fz * g.dim[1] + (int)fy) * g.dim[0] + (int)fx;
   uint32_t k0 = g.start[cellid], k1 = g.start[cellid + 1];
   if (k0 == k1) return;
@@ -127,7 +127,7 @@ R3D_HD void collect(const KArgs& a, const Tables<KIND>& T, const Phonon& p, doub
     double scaled = arv / a.time_per_bin;
     if (!(scaled >= 0.0)) continue;
     double fl = floor(scaled);
-    if (!(fl < (double)a.n_bins)) continue;
+    if (!(fl < a.n_bins_f)) continue;
     uint32_t bin = (uint32_t)fl;
     if (!have_dopm) dopm = direction_of_motion(p), have_dopm = true;
     const SeisHit& H = T.seis_hit[s];
@@ -154,8 +154,8 @@ R3D_HD void volume_count(const KArgs& a, const Phonon& p) {
   const double x = (p.loc.x - a.vol_origin[0]) * a.vol_inv_cell[0];
   const double y = (p.loc.y - a.vol_origin[1]) * a.vol_inv_cell[1];
   const double z = (p.loc.z - a.vol_origin[2]) * a.vol_inv_cell[2];
-  if (!(f >= 0 && x >= 0 && y >= 0 && z >= 0 && f < a.vol_frames && x < a.vol_dim[0] &&
-        y < a.vol_dim[1] && z < a.vol_dim[2]))
+  if (!(f >= 0 && x >= 0 && y >= 0 && z >= 0 && f < a.vol_frames_f && x < a.vol_dim_f[0] &&
+        y < a.vol_dim_f[1] && z < a.vol_dim_f[2]))
     return;
   const size_t idx = ((((size_t)p.type * a.vol_frames + (size_t)f) * a.vol_dim[2] + (size_t)z) *
                           a.vol_dim[1] + (size_t)y) * a.vol_dim[0] + (size_t)x;

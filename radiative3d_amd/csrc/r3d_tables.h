@@ -97,6 +97,7 @@ struct SeisGrid {     // uniform hash over seismometer gather spheres
   double inv_h;
   int32_t dim[3];
   int32_t n_cells;
+  double dim_f[3];         // dim as doubles (the bounds test runs in fp64)
   const uint32_t* start;   // n_cells + 1 offsets into items
   const uint32_t* items;   // seismometer indices
 };
@@ -144,14 +145,20 @@ struct KArgs {
   unsigned int* vol;
   double vol_origin[3], vol_inv_cell[3], vol_inv_dt;
   uint32_t vol_dim[3], vol_frames;
+  double vol_dim_f[3], vol_frames_f;   // the same as doubles, for the bounds test
+  double n_bins_f;           // (double)n_bins
   // scheduling knobs (wave-uniform)
   uint32_t rt_batch;         // parked R/T lanes that trigger the solve (<= 1: never park)
   uint32_t refill_min;       // idle lanes that trigger a refill
+  uint32_t scat_batch;       // parked scattering lanes that trigger the table draw (<= 1: never park)
+  uint32_t pad1_;
   // LDS carve-up (bytes from the start of dynamic shared memory)
   uint32_t lds_cells_off;    // 0xFFFFFFFF: cells stay in HBM
   uint32_t lds_scat_off;
   uint32_t lds_seis_off;
   uint32_t lds_hit_off;
+  uint32_t lds_acc_off;      // bin accumulators (see BinCache in r3d_engine.hip)
+  uint32_t acc_bits;         // 2^acc_bits accumulator entries; 0: none
 };
 
 }  // namespace r3d

@@ -74,9 +74,9 @@ extern "C" int r3d_emul_run(const r3d_model_desc* m, uint64_t n, uint64_t first_
   if (g_vol) {
     for (int k = 0; k < 3; k++) {
       a.vol_origin[k] = g_vol_desc.origin[k], a.vol_inv_cell[k] = 1.0 / g_vol_desc.cell_size[k];
-      a.vol_dim[k] = g_vol_desc.dims[k];
+      a.vol_dim[k] = g_vol_desc.dims[k], a.vol_dim_f[k] = (double)g_vol_desc.dims[k];
     }
-    a.vol_frames = g_vol_desc.n_frames, a.vol_inv_dt = 1.0 / g_vol_desc.frame_dt, a.vol = g_vol;
+    a.vol_frames = g_vol_desc.n_frames, a.vol_frames_f = (double)g_vol_desc.n_frames, a.vol_inv_dt = 1.0 / g_vol_desc.frame_dt, a.vol = g_vol;
   }
   switch (m->cell_kind) {
     case R3D_CELL_CYLINDER: run_kind<CELL_CYL>(a, n, first_id, seed, out, finals); break;
