@@ -387,31 +387,26 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
 
     R3D_STAMP(2);  // collect
 
-    // ---- second half.  Bend and hand-over are served at once.  The two long divergent
-    //      branches can be deferred: lanes that need the reflection/transmission solve, or
-    //      the scattering draw (a chain of dependent table probes whose latency the whole
-    //      wave would sit through for one or two lanes), park until rt_batch resp.
-    //      scat_batch of them have gathered -- or nothing else can run -- and then take
-    //      the branch together.  Draws are per-history counters, so the order in which
-    //      lanes are served does not change any history ----
+    // ---- second half.  Scatter, bend and hand-over are served at once.  The
+    //      reflection/transmission solve is the one long divergent branch (in the tetra
+    //      models about a fifth of the lanes per iteration): lanes that need it park until
+    //      rt_batch of them have gathered -- or nothing else can run -- and then take it
+    //      together.  Draws are per-history counters, so the order in which lanes are
+    //      served does not change any history.  (Parking the scattering draw the same way
+    //      was tried and measured: no gain on any model.) ----
+    constexpr bool kPark = (KIND == CELL_TET);   // (see r3d_engine_create: measured per cell kind)
     if (moved) {
-      const bool is_sc = ev.face < 0;
-      const bool is_rt = !is_sc && (ev.flags & (F_REFLECT | F_DISCON)) != 0;
-      const bool heavy = (is_rt & (a.rt_batch > 1)) | (is_sc & (a.scat_batch > 1));
+      const bool heavy = kPark && ev.face >= 0 && (ev.flags & (F_REFLECT | F_DISCON)) != 0;
       if (heavy) parked = true;
-      else fate = step_event<KIND>(a, T, p, rng, st, ev);
+      else fate = step_event<KIND, kPark ? EV_LIGHT : EV_ALL>(a, T, p, rng, st, ev);
     }
     R3D_STAMP(3);  // light events
-    if (a.rt_batch > 1 || a.scat_batch > 1) {
-      const unsigned long long pm = __ballot(parked);
-      if (pm) {
-        const unsigned n_sc = (unsigned)__popcll(__ballot(parked && ev.face < 0));
-        const unsigned n_rt = (unsigned)__popcll(pm) - n_sc;
-        const bool any_running = __any(alive && !parked && fate == FATE_ALIVE);
-        const bool fire_rt = n_rt >= a.rt_batch || (n_rt > 0 && !any_running);
-        const bool fire_sc = n_sc >= a.scat_batch || (n_sc > 0 && !any_running);
-        if (parked && ((ev.face < 0) ? fire_sc : fire_rt)) {
-          fate = step_event<KIND>(a, T, p, rng, st, ev);
+    if (kPark) {
+      const unsigned n_parked = (unsigned)__popcll(__ballot(parked));
+      const bool any_running = __any(alive && !parked && fate == FATE_ALIVE);
+      if (n_parked >= a.rt_batch || (n_parked > 0 && !any_running)) {
+        if (parked) {
+          fate = step_event<KIND, EV_RT>(a, T, p, rng, st, ev);
           parked = false;
         }
       }
@@ -419,6 +414,7 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
 
     R3D_STAMP(4);  // parked R/T
     // ---- book-keeping: this iteration's events, and lanes whose history ended ----
+    const bool died = alive && fate != FATE_ALIVE;
     tally(st.iterations != 0, kEv + R3D_EV_ITERATIONS);
     tally(st.scatter != 0, kEv + R3D_EV_SCATTER);
     tally(st.collect != 0, kEv + R3D_EV_COLLECT);
@@ -431,11 +427,12 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
       for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
       if (lane == 0) atomicAdd(&s_tally[kEv + R3D_EV_CATCH], c);
     }
-    if (TRACE) lane_catches += st.n_catch;
-    const bool died = alive && fate != FATE_ALIVE;
     if (__any(died)) {
       tally(died && fate == FATE_LOST, 0);
       tally(died && fate == FATE_TIMEOUT, 1);
+    }
+    if (TRACE) lane_catches += st.n_catch;
+    if (__any(died && fate == FATE_INVALID)) {   // rare
       tally(died && fate == FATE_INVALID, 2);
 #pragma unroll
       for (int r = 0; r < R3D_INV_NUM; r++) tally(died && fate == FATE_INVALID && reason == r, 3 + r);
@@ -655,11 +652,10 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   // Scheduling knobs.  Parking pays where the R/T solve is a minority branch (tetra models:
   // ~1/5 of the lanes per iteration, measured -10 %); in the layered and spherical models it
   // is taken by most lanes anyway (measured +5 % with parking), so they do not park.
+  // (compiled in: the tetra kernel parks, the others do not; rt_batch is its trigger level)
   a.rt_batch = (m->cell_kind == R3D_CELL_TETRA) ? kRtBatch : 1u;
   a.refill_min = kRefillMin;
-  if (const char* s = getenv("R3D_RT_BATCH")) a.rt_batch = (uint32_t)atoi(s);       // developer tuning
-  a.scat_batch = 1u;
-  if (const char* s = getenv("R3D_SCAT_BATCH")) a.scat_batch = (uint32_t)atoi(s);
+  if (const char* s = getenv("R3D_RT_BATCH")) a.rt_batch = (uint32_t)std::max(1, atoi(s));   // developer tuning
   if (const char* s = getenv("R3D_REFILL_MIN")) a.refill_min = (uint32_t)std::max(1, atoi(s));
   hipError_t err = hipSuccess;
   // ---- move every table into HBM and point the launch arguments at it ----

@@ -112,7 +112,10 @@ R3D_HD Cx operator/(Cx a, Cx b) {
 R3D_HD double norm(Cx a) { return a.re * a.re + a.im * a.im; }  // squared modulus
 // sqrt of the real number s as a complex number (principal branch):
 // post-critical cosines come out purely imaginary (rtcoef.cpp:312-318).
-R3D_HD Cx sqrt_real(double s) { return s >= 0 ? cx(sqrt(s), 0.0) : cx(0.0, sqrt(-s)); }
+R3D_HD Cx sqrt_real(double s) {
+  const double r = sqrt(fabs(s));   // one root, then placed (not one root per branch)
+  return s >= 0 ? cx(r, 0.0) : cx(0.0, r);
+}
 
 }  // namespace r3d
 #endif

@@ -248,12 +248,17 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
 // reached.  Seismometer collection (phonons.cpp:629-631) happens BETWEEN the
 // halves, with the incident state: per lane in step(), wave-cooperatively in
 // the kernel.
-template <int KIND>
+// PART selects what is compiled in: EV_ALL everything; EV_LIGHT everything but the
+// reflection/transmission solve (the caller guarantees the event is not one); EV_RT only
+// that solve (the caller guarantees it is one).  The kernel's two call sites use the
+// halves, which keeps its code -- and its instruction-cache footprint -- smaller.
+enum { EV_ALL = 0, EV_LIGHT = 1, EV_RT = 2 };
+template <int KIND, int PART = EV_ALL>
 R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng, LaneStats& st,
                       const Pending& ev) {
   using Cell = typename CellOf<KIND>::type;
   const Cell& c = T.cells[p.cell];
-  if (ev.face < 0) {
+  if (PART != EV_RT && ev.face < 0) {
     // Scatterer::GetRandomScatteredRelativePhonon, scatterers.cpp:318-363
     st.scatter++;
     if (a.no_deflect) {
@@ -276,7 +281,7 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
   const int nbr = cell_neighbor(c, ev.face);
   const bool adjoin = (fl & F_ADJOIN) != 0;
   bool crossed;
-  if ((fl & F_REFLECT) || (fl & F_DISCON)) {
+  if (PART != EV_LIGHT && (PART == EV_RT || (fl & F_REFLECT) || (fl & F_DISCON))) {
     Iface f;
     f.normal = cell_face_normal(c, ev.face, p.loc);
     f.vR[0] = cell_velocity(c, p.loc, 0), f.vR[1] = cell_velocity(c, p.loc, 1);
@@ -298,6 +303,8 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
 #else
     crossed = full_rt(p, f, rng, rng_key(a.seed));
 #endif
+  } else if (PART == EV_RT) {
+    crossed = true;   // (not reached)
   } else if (fl & F_SMOOTH) {
     crossed = true;   // velocity step below 1e-5 everywhere on this face: plain hand-over
   } else {

@@ -150,8 +150,6 @@ struct KArgs {
   // scheduling knobs (wave-uniform)
   uint32_t rt_batch;         // parked R/T lanes that trigger the solve (<= 1: never park)
   uint32_t refill_min;       // idle lanes that trigger a refill
-  uint32_t scat_batch;       // parked scattering lanes that trigger the table draw (<= 1: never park)
-  uint32_t pad1_;
   // LDS carve-up (bytes from the start of dynamic shared memory)
   uint32_t lds_cells_off;    // 0xFFFFFFFF: cells stay in HBM
   uint32_t lds_scat_off;
