@@ -255,6 +255,44 @@ int    r3d_volume_read(r3d_engine* e, uint32_t* out, int reset);
 /* Device address of the counters, for an RCCL reduction across ranks.        */
 void*  r3d_volume_device_ptr(r3d_engine* e);
 
+/* ---- optional per-event report stream --------------------------------------
+ * The reference's `--reports[=KEYWORDS]` (main.cpp:223-258) writes one text line
+ * per event with the phonon's state at that moment (dataout.cpp:484-520): GEN
+ * after generation (events.cpp:120), SCT after a scatter (phonons.cpp:616), COL
+ * on arrival at a collection face, with the incident state (:630), REF / CEL
+ * after a reflection / hand-over (:643, :659-661), LST / TMO / INV when the
+ * history ends (:550-598, :675).  The engine appends the same records, in
+ * binary, to a buffer in HBM; records of one history appear in the order they
+ * happened (histories interleave).  host: r3dh_write_reports() prints them in
+ * the reference's line format.                                               */
+enum {
+  R3D_RPT_GEN = 1u, R3D_RPT_SCT = 2u, R3D_RPT_REF = 4u, R3D_RPT_COL = 8u,
+  R3D_RPT_CEL = 16u, R3D_RPT_LST = 32u, R3D_RPT_TMO = 64u, R3D_RPT_INV = 128u,
+  R3D_RPT_ALL = 255u
+};
+typedef struct r3d_event {
+  uint64_t id;          /* history id (mSID)                                */
+  double   time, path, amp;
+  double   loc[3];      /* model coordinates                                */
+  double   dir[3];      /* unit vector                                      */
+  uint32_t cell;        /* cell index (the reference prints the address)    */
+  uint32_t moves;       /* mMoveCount                                       */
+  uint8_t  tag;         /* 0 GEN 1 SCT 2 REF 3 COL 4 CEL 5 LST 6 TMO 7 INV  */
+  uint8_t  type;        /* ray type                                         */
+  uint8_t  pad_[6];
+} r3d_event;            /* 96 bytes                                         */
+
+/* Attach an event buffer of `capacity` records for the tags in `mask`
+ * (R3D_RPT_*); mask == 0 or capacity == 0 detaches.  Subsequent runs append;
+ * events beyond the capacity are counted but not stored.                     */
+int      r3d_engine_set_event_log(r3d_engine* e, uint32_t mask, uint64_t capacity);
+/* Events reported since the buffer was attached or last reset (may exceed the
+ * capacity).                                                                 */
+uint64_t r3d_event_log_count(r3d_engine* e);
+/* Copy up to `max` stored records to `out`; returns the number copied, or
+ * (uint64_t)-1 on error.  reset != 0 empties the buffer afterwards.          */
+uint64_t r3d_event_log_read(r3d_engine* e, r3d_event* out, uint64_t max, int reset);
+
 /* Duration in milliseconds of the traversal kernel launches enqueued by the
  * most recent r3d_run / r3d_run_device call on this engine, measured with
  * HIP events on the engine's stream (blocks until they have completed).    */

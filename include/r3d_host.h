@@ -54,6 +54,17 @@ const char* r3dh_params_echo(r3dh_model* m);
 const char* r3dh_write_outputs(r3dh_model* m, const r3d_result* result, const char* outdir,
                                const char* trace_path, const char* mparams_path);
 
+/* --reports keyword list ("ALL_ON", "GEN,SCT,REF", "SCATTERS", ... as on the
+ * reference's command line, main.cpp:223-258) -> R3D_RPT_* mask; (uint32_t)-1 on
+ * an unknown keyword.  The mask the model's own argv asked for:            */
+uint32_t r3dh_report_mask(const char* keywords);
+uint32_t r3dh_model_report_mask(const r3dh_model* m);
+
+/* Print event records in the reference's report-line format
+ * (dataout.cpp:484-520), grouped by history.  path != NULL: write that file and
+ * return ""; path == NULL: return the text.  NULL on error.                 */
+const char* r3dh_write_reports(r3dh_model* m, const r3d_event* events, uint64_t n, const char* path);
+
 const char* r3dh_last_error(void);
 
 #ifdef __cplusplus

@@ -31,8 +31,23 @@ def lib():
         L.r3d_oracle_boundary.argtypes = [C.POINTER(_ffi.ModelDesc), C.c_int, C.c_int, C.POINTER(C.c_double),
                                           C.c_double, C.c_double, C.POINTER(C.c_double)]
         L.r3d_oracle_set_volume.argtypes = [C.POINTER(_ffi.VolumeDesc), C.POINTER(C.c_uint32)]
+        L.r3d_oracle_set_event_log.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
+        L.r3d_oracle_event_count.restype = C.c_uint64
         _lib = L
     return _lib
+
+
+def run_with_events(model, n, mask=_ffi.R3D_RPT_ALL, capacity=1 << 20, first_id=0, seed=0x5EED):
+    """Oracle run that also records the report stream; -> (result, events[structured], n_reported)."""
+    import numpy as np
+    ev = np.zeros(capacity, dtype=_ffi.event_dtype())
+    lib().r3d_oracle_set_event_log(ev.ctypes.data, capacity, mask)
+    try:
+        res = run(model, n, first_id, seed)
+        total = int(lib().r3d_oracle_event_count())
+    finally:
+        lib().r3d_oracle_set_event_log(None, 0, 0)
+    return res, ev[:min(total, capacity)], total
 
 
 def run_with_volume(model, n, vdesc, first_id=0, seed=0x5EED):

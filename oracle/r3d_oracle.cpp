@@ -194,7 +194,14 @@ void volume_count(double t, V loc, int type) {
   g_vol[idx] += 1;
 }
 
+// Per-event report stream (include/r3d.h r3d_event; reference dataout.cpp:484-617): the
+// record the reference prints as one text line, appended in program order.
+r3d_event* g_evlog = nullptr;
+uint64_t g_evlog_cap = 0, g_evlog_count = 0;
+uint32_t g_evlog_mask = 0;
+
 struct Ctx {
+  uint64_t id;   // history id (mSID)
   const r3d_model_desc* m;
   oracle_rng rng;
   r3d_result* out;
@@ -853,6 +860,23 @@ void invalid(Ctx& c, int reason) {
   c.out->invalid_reasons[reason]++;
 }
 
+// DataReporter::output_phonon_dataline's content (dataout.cpp:484-520) as a record.
+// tag: 0 GEN 1 SCT 2 REF 3 COL 4 CEL 5 LST 6 TMO 7 INV.
+void report(const Ctx& c, int tag, const Phonon& p) {
+  if (!g_evlog || !((g_evlog_mask >> tag) & 1u)) return;
+  const uint64_t at = g_evlog_count++;
+  if (at >= g_evlog_cap) return;
+  r3d_event& r = g_evlog[at];
+  std::memset(&r, 0, sizeof r);
+  r.id = c.id;
+  r.time = p.t, r.path = p.path, r.amp = p.amp;
+  r.loc[0] = p.loc.x, r.loc[1] = p.loc.y, r.loc[2] = p.loc.z;
+  V d = from_angles(p.theta, p.phi);
+  r.dir[0] = d.x, r.dir[1] = d.y, r.dir[2] = d.z;
+  r.cell = (uint32_t)p.cell, r.moves = p.moves;
+  r.tag = (uint8_t)tag, r.type = (uint8_t)p.type;
+}
+
 // PhononSource::GenerateRandomPhonon (sources.cpp:156-170) through
 // ShearDislocation::GenerateEventPhonon (events.cpp:111-124), then
 // Phonon::Propagate (phonons.cpp:540-682).  Returns the fate code.
@@ -872,21 +896,23 @@ int run_history(Ctx& c, Phonon& p) {
   p.loc = mk(m.source.loc);
   p.cell = m.source.cell;
   out.events[R3D_EV_GENERATED]++;
+  report(c, 0, p);   // ReportNewEventPhonon, events.cpp:120
 
   // --- propagate ---
   while (true) {
     if (p.t > par.ttl) {
       out.n_timeout++;
+      report(c, 6, p);   // ReportPhononTimeout, phonons.cpp:550
       return 2;
     }
     if ((p.moves % 128) == 127) {  // phonons.cpp:554-584
-      if (std::isnan(p.path)) return invalid(c, R3D_INV_PATH_NAN), 3;
-      if (std::isnan(p.t)) return invalid(c, R3D_INV_TIME_NAN), 3;
-      if (p.path < 0) return invalid(c, R3D_INV_PATH_NEGATIVE), 3;
-      if ((p.t < 0) || (p.recent < 0)) return invalid(c, R3D_INV_TIME_NEGATIVE), 3;
-      if (p.recent == 0) return invalid(c, R3D_INV_STUCK), 3;
-      if (p.recent < par.slow_concern) return invalid(c, R3D_INV_SLOW), 3;
-      if (p.moves > par.loop_concern) return invalid(c, R3D_INV_LOOP_EXCEED), 3;
+      if (std::isnan(p.path)) return report(c, 7, p), invalid(c, R3D_INV_PATH_NAN), 3;
+      if (std::isnan(p.t)) return report(c, 7, p), invalid(c, R3D_INV_TIME_NAN), 3;
+      if (p.path < 0) return report(c, 7, p), invalid(c, R3D_INV_PATH_NEGATIVE), 3;
+      if ((p.t < 0) || (p.recent < 0)) return report(c, 7, p), invalid(c, R3D_INV_TIME_NEGATIVE), 3;
+      if (p.recent == 0) return report(c, 7, p), invalid(c, R3D_INV_STUCK), 3;
+      if (p.recent < par.slow_concern) return report(c, 7, p), invalid(c, R3D_INV_SLOW), 3;
+      if (p.moves > par.loop_concern) return report(c, 7, p), invalid(c, R3D_INV_LOOP_EXCEED), 3;
       p.recent = 0;
     }
     out.events[R3D_EV_ITERATIONS]++;
@@ -894,6 +920,7 @@ int run_history(Ctx& c, Phonon& p) {
     TravelRec travel = path_to_boundary(m, cell, p);
     if (travel.len == INF) {
       out.n_timeout++;
+      report(c, 6, p);   // phonons.cpp:596
       return 2;
     }
     const r3d_scatterer& sc = m.scatterers[cell.scatterer];
@@ -923,15 +950,20 @@ int run_history(Ctx& c, Phonon& p) {
       p.theta = SS.theta, p.phi = SS.phi, p.pol = SS.rot, p.type = rtype;
       out.events[R3D_EV_SCATTER]++;
       volume_count(p.t, p.loc, p.type);   // ReportScatterEvent
+      report(c, 1, p);
       continue;
     }
     move(p, travel);
     const r3d_face& face = cell.faces[travel.face];
-    if (face.flags & R3D_FACE_COLLECT) collect(c, p);
+    if (face.flags & R3D_FACE_COLLECT) {
+      report(c, 3, p);   // ReportPhononCollected: the incident state (phonons.cpp:630)
+      collect(c, p);
+    }
     if (face.flags & R3D_FACE_REFLECT) {
       refraction_full_rt(c, p, travel.face);
       out.events[R3D_EV_REFLECT]++;
       volume_count(p.t, p.loc, p.type);   // ReportReflection
+      report(c, 2, p);
       continue;
     }
     if (face.flags & R3D_FACE_ADJOIN) {
@@ -943,9 +975,11 @@ int run_history(Ctx& c, Phonon& p) {
       else p.cell = face.neighbor;
       out.events[p.cell == old ? R3D_EV_REFLECT : R3D_EV_TRANSFER]++;
       if (p.cell == old) volume_count(p.t, p.loc, p.type);   // ReportReflection
+      report(c, p.cell == old ? 2 : 4, p);   // REF or CEL, phonons.cpp:659-661
       continue;
     }
     out.n_lost++;
+    report(c, 5, p);   // ReportLostPhonon, phonons.cpp:675
     return 1;
   }
 }
@@ -964,6 +998,7 @@ int r3d_oracle_run(const r3d_model_desc* model, uint64_t n, uint64_t first_id, u
   c.out = out;
   for (uint64_t i = 0; i < n; i++) {
     oracle_rng_init(&c.rng, seed, first_id + i);
+    c.id = first_id + i;
     c.n_catch = 0;
     Phonon p;
     int fate = run_history(c, p);
@@ -982,6 +1017,13 @@ int r3d_oracle_run(const r3d_model_desc* model, uint64_t n, uint64_t first_id, u
   }
   return 0;
 }
+
+// Attach (buf != NULL) or detach the per-event report buffer for subsequent runs (single
+// threaded use); r3d_oracle_event_count() = events reported since it was attached.
+void r3d_oracle_set_event_log(r3d_event* buf, uint64_t capacity, uint32_t mask) {
+  g_evlog = buf, g_evlog_cap = buf ? capacity : 0, g_evlog_mask = buf ? mask : 0, g_evlog_count = 0;
+}
+uint64_t r3d_oracle_event_count(void) { return g_evlog_count; }
 
 // Attach (v != NULL) or detach the volumetric scatter-event grid for subsequent runs.
 void r3d_oracle_set_volume(const r3d_volume_desc* v, uint32_t* counters) {

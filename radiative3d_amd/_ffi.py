@@ -81,6 +81,25 @@ class Final(C.Structure):
                 ("fate", C.c_uint8), ("type", C.c_uint8), ("n_catch", C.c_uint16)]
 
 
+class Event(C.Structure):
+    """r3d_event (include/r3d.h): one report-stream record."""
+    _fields_ = [("id", C.c_uint64), ("time", C.c_double), ("path", C.c_double), ("amp", C.c_double),
+                ("loc", C.c_double * 3), ("dir", C.c_double * 3), ("cell", C.c_uint32),
+                ("moves", C.c_uint32), ("tag", C.c_uint8), ("type", C.c_uint8), ("pad_", C.c_uint8 * 6)]
+
+
+R3D_RPT_TAGS = ("GEN", "SCT", "REF", "COL", "CEL", "LST", "TMO", "INV")
+R3D_RPT_ALL = 255
+
+
+def event_dtype():
+    """numpy view of an r3d_event array."""
+    import numpy as np
+    return np.dtype([("id", "<u8"), ("time", "<f8"), ("path", "<f8"), ("amp", "<f8"), ("loc", "<f8", 3),
+                     ("dir", "<f8", 3), ("cell", "<u4"), ("moves", "<u4"), ("tag", "u1"), ("type", "u1"),
+                     ("pad_", "u1", 6)])
+
+
 def _load(path):
     if not os.path.exists(path):
         raise RuntimeError(
@@ -118,6 +137,12 @@ def host_lib():
         L.r3dh_scatterer_dump.argtypes = [C.c_void_p]
         L.r3dh_params_echo.restype = C.c_char_p
         L.r3dh_params_echo.argtypes = [C.c_void_p]
+        L.r3dh_report_mask.restype = C.c_uint32
+        L.r3dh_report_mask.argtypes = [C.c_char_p]
+        L.r3dh_model_report_mask.restype = C.c_uint32
+        L.r3dh_model_report_mask.argtypes = [C.c_void_p]
+        L.r3dh_write_reports.restype = C.c_char_p
+        L.r3dh_write_reports.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p]
         L.r3dh_write_outputs.restype = C.c_char_p
         L.r3dh_write_outputs.argtypes = [C.c_void_p, C.POINTER(Result), C.c_char_p, C.c_char_p, C.c_char_p]
         _host = L
@@ -153,6 +178,12 @@ def hip_lib():
         L.r3d_volume_read.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]
         L.r3d_volume_device_ptr.restype = C.c_void_p
         L.r3d_volume_device_ptr.argtypes = [C.c_void_p]
+        L.r3d_engine_set_event_log.restype = C.c_int
+        L.r3d_engine_set_event_log.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+        L.r3d_event_log_count.restype = C.c_uint64
+        L.r3d_event_log_count.argtypes = [C.c_void_p]
+        L.r3d_event_log_read.restype = C.c_uint64
+        L.r3d_event_log_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
         L.r3d_last_kernel_ms.restype = C.c_double
         L.r3d_last_kernel_ms.argtypes = [C.c_void_p]
         L.r3d_last_error.restype = C.c_char_p

@@ -290,6 +290,28 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
     if (lane == 0 && m) atomicAdd(&s_tally[slot], (unsigned long long)__popcll(m));
   };
   constexpr int kEv = 3 + R3D_INV_NUM;
+  // Report stream (diagnostic kernel only; include/r3d.h r3d_event): the lanes for which
+  // `cond` holds append one record each; the wave claims the slots with one atomic.
+  uint64_t my_id = 0;        // (only read when TRACE)
+  auto report = [&](bool cond, int tag, const Phonon& q) {
+    if (!TRACE || !a.evlog || !((a.evlog_mask >> tag) & 1u)) return;
+    const unsigned long long m = __ballot(cond);
+    if (!m) return;
+    const int first = __ffsll((long long)m) - 1;
+    unsigned long long base = 0;
+    if ((int)lane == first) base = atomicAdd(a.evlog_count, (unsigned long long)__popcll(m));
+    base = __shfl(base, first);
+    const unsigned long long at = base + (unsigned long long)__popcll(m & lane_lt);
+    if (cond && at < a.evlog_cap) {
+      r3d_event* r = reinterpret_cast<r3d_event*>(a.evlog) + at;
+      r->id = my_id;
+      r->time = q.t, r->path = q.path, r->amp = q.amp;
+      r->loc[0] = q.loc.x, r->loc[1] = q.loc.y, r->loc[2] = q.loc.z;
+      r->dir[0] = q.dir.x, r->dir[1] = q.dir.y, r->dir[2] = q.dir.z;
+      r->cell = (uint32_t)q.cell, r->moves = q.moves;
+      r->tag = (uint8_t)tag, r->type = (uint8_t)q.type;
+    }
+  };
 #ifdef R3D_PHASE_TIMING
   __shared__ unsigned long long s_phase[8];
   if (threadIdx.x < 8) s_phase[threadIdx.x] = 0ull;
@@ -299,7 +321,6 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
 
   Phonon p;
   Rng rng;
-  uint64_t my_id = 0;        // (only read when TRACE)
   uint32_t lane_catches = 0; // catches of the current history (only read when TRACE)
   bool alive = false;
   bool parked = false;   // holds a reflection/transmission event in `ev`, waiting for company
@@ -330,13 +351,15 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
       const unsigned long long avail = w_end - w_next;
       const unsigned take = (avail < want) ? (unsigned)avail : want;
       const unsigned rank = (unsigned)__popcll(need & lane_lt);
-      if (!alive && rank < take) {
+      const bool fresh = !alive && rank < take;
+      if (fresh) {
         my_id = a.first_id + w_next + rank;
         rng_init(rng, my_id);
         spray(a, p, rng);
         alive = true;
         lane_catches = 0;
       }
+      report(fresh, 0, p);   // GEN
       if (lane == 0 && take) atomicAdd(&s_tally[kEv + R3D_EV_GENERATED], (unsigned long long)take);
       w_next += take;
       need = __ballot(!alive);
@@ -359,6 +382,7 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
     if (run) fate = step_move<KIND>(a, T, p, rng, st, &reason, ev);
     const bool moved = run && fate == FATE_ALIVE;
     R3D_STAMP(1);  // move
+    report(moved && (ev.flags & F_COLLECT) != 0, 3, p);   // COL: the incident state
 
     // ---- seismometers.  Each arriving lane looks up its own hash cell (the loads of
     //      different lanes overlap); then the wave serves the arrivals that have
@@ -415,6 +439,14 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
     R3D_STAMP(4);  // parked R/T
     // ---- book-keeping: this iteration's events, and lanes whose history ended ----
     const bool died = alive && fate != FATE_ALIVE;
+    if (TRACE && a.evlog) {
+      report(st.scatter != 0, 1, p);    // SCT
+      report(st.reflect != 0, 2, p);    // REF
+      report(st.transfer != 0, 4, p);   // CEL
+      report(died && fate == FATE_LOST, 5, p);
+      report(died && fate == FATE_TIMEOUT, 6, p);
+      report(died && fate == FATE_INVALID, 7, p);
+    }
     tally(st.iterations != 0, kEv + R3D_EV_ITERATIONS);
     tally(st.scatter != 0, kEv + R3D_EV_SCATTER);
     tally(st.collect != 0, kEv + R3D_EV_COLLECT);
@@ -439,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
     }
     if (died) {
       alive = false;
-      if (TRACE) {
+      if (TRACE && a.finals) {   // (the diagnostic kernel also runs for the report stream alone)
         r3d_final* f = reinterpret_cast<r3d_final*>(a.finals) + (my_id - a.first_id);
         f->time = p.t, f->path = p.path, f->amp = p.amp;
         f->loc[0] = p.loc.x, f->loc[1] = p.loc.y, f->loc[2] = p.loc.z;
@@ -533,6 +565,7 @@ struct r3d_engine {
   DevBuf d_energy, d_counts, d_scalars, d_next;
   std::unique_ptr<DevBuf> d_volume;
   size_t volume_len = 0;
+  std::unique_ptr<DevBuf> d_evlog, d_evlog_count;
 
   DevBuf* keep(std::unique_ptr<DevBuf> b) {
     bufs.push_back(std::move(b));
@@ -782,7 +815,7 @@ static int enqueue(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, 
   a.finals = d_finals;
   R3D_HIP_OK(hipMemsetAsync(e->d_next.p, 0, sizeof(unsigned long long), s));
   R3D_HIP_OK(hipEventRecord(e->ev0, s));
-  if (n > 0) R3D_HIP_OK(launch_any(e, a, d_finals != nullptr, s));
+  if (n > 0) R3D_HIP_OK(launch_any(e, a, d_finals != nullptr || a.evlog != nullptr, s));
   R3D_HIP_OK(hipEventRecord(e->ev1, s));
   e->timed = true;
   return 0;
@@ -846,6 +879,45 @@ int r3d_debug_phase_cycles(unsigned long long out[8]) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof zero) != hipSuccess;
 }
 #endif
+
+int r3d_engine_set_event_log(r3d_engine* e, uint32_t mask, uint64_t capacity) {
+  const int fail_value = 1;
+  if (!e) return g_error = "null engine", 1;
+  R3D_HIP_OK(hipSetDevice(e->device));
+  KArgs& a = e->args;
+  a.evlog = nullptr, a.evlog_count = nullptr, a.evlog_cap = 0, a.evlog_mask = 0;
+  e->d_evlog.reset(), e->d_evlog_count.reset();
+  if (mask == 0 || capacity == 0) return 0;
+  auto buf = std::make_unique<DevBuf>(), cnt = std::make_unique<DevBuf>();
+  R3D_HIP_OK(buf->alloc_zero(capacity * sizeof(r3d_event)));
+  R3D_HIP_OK(cnt->alloc_zero(sizeof(unsigned long long)));
+  a.evlog = buf->p, a.evlog_count = reinterpret_cast<unsigned long long*>(cnt->p);
+  a.evlog_cap = capacity, a.evlog_mask = mask & R3D_RPT_ALL;
+  e->d_evlog = std::move(buf), e->d_evlog_count = std::move(cnt);
+  return 0;
+}
+
+uint64_t r3d_event_log_count(r3d_engine* e) {
+  const uint64_t fail_value = ~uint64_t(0);
+  if (!e || !e->d_evlog_count) return 0;
+  R3D_HIP_OK(hipSetDevice(e->device));
+  R3D_HIP_OK(hipDeviceSynchronize());
+  unsigned long long n = 0;
+  R3D_HIP_OK(hipMemcpy(&n, e->d_evlog_count->p, sizeof n, hipMemcpyDeviceToHost));
+  return n;
+}
+
+uint64_t r3d_event_log_read(r3d_engine* e, r3d_event* out, uint64_t max, int reset) {
+  const uint64_t fail_value = ~uint64_t(0);
+  if (!e || !e->d_evlog) return g_error = "no event log attached", fail_value;
+  const uint64_t total = r3d_event_log_count(e);
+  if (total == fail_value) return fail_value;
+  const uint64_t n = std::min<uint64_t>(std::min<uint64_t>(total, e->args.evlog_cap), max);
+  if (n && !out) return g_error = "null output", fail_value;
+  if (n) R3D_HIP_OK(hipMemcpy(out, e->d_evlog->p, n * sizeof(r3d_event), hipMemcpyDeviceToHost));
+  if (reset) R3D_HIP_OK(hipMemset(e->d_evlog_count->p, 0, sizeof(unsigned long long)));
+  return n;
+}
 
 int r3d_engine_set_volume(r3d_engine* e, const r3d_volume_desc* v) {
   const int fail_value = 1;

@@ -147,6 +147,12 @@ struct KArgs {
   uint32_t vol_dim[3], vol_frames;
   double vol_dim_f[3], vol_frames_f;   // the same as doubles, for the bounds test
   double n_bins_f;           // (double)n_bins
+  // optional per-event report buffer (null = off): r3d_event records, see include/r3d.h
+  void* evlog;
+  unsigned long long* evlog_count;
+  uint64_t evlog_cap;
+  uint32_t evlog_mask;
+  uint32_t pad2_;
   // scheduling knobs (wave-uniform)
   uint32_t rt_batch;         // parked R/T lanes that trigger the solve (<= 1: never park)
   uint32_t refill_min;       // idle lanes that trigger a refill

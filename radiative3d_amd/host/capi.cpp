@@ -110,6 +110,41 @@ const char* r3dh_write_outputs(r3dh_model* m, const r3d_result* result, const ch
   return nullptr;
 }
 
+uint32_t r3dh_report_mask(const char* keywords) {
+  try {
+    return ReportMaskFromKeywords(keywords ? keywords : "");
+  } catch (const std::exception& e) {
+    g_error = e.what();
+  }
+  return ~uint32_t(0);
+}
+
+uint32_t r3dh_model_report_mask(const r3dh_model* m) {
+  return m ? r3dh_report_mask(m->mission.Reports.c_str()) : 0;
+}
+
+const char* r3dh_write_reports(r3dh_model* m, const r3d_event* events, uint64_t n, const char* path) {
+  if (!m || (n && !events)) return nullptr;
+  try {
+    // (the lines go through the global coordinate system, which still holds this model's
+    //  mapping only if no other model was built since)
+    if (path) {
+      std::ofstream f(path);
+      if (!f) throw Runtime(std::string("cannot open ") + path);
+      OutputReports(events, (size_t)n, f);
+      m->text.clear();
+    } else {
+      std::ostringstream os;
+      OutputReports(events, (size_t)n, os);
+      m->text = os.str();
+    }
+    return m->text.c_str();
+  } catch (const std::exception& e) {
+    g_error = e.what();
+  }
+  return nullptr;
+}
+
 const char* r3dh_last_error(void) { return g_error.c_str(); }
 
 }  // extern "C"

@@ -34,4 +34,14 @@ void OutputSeismometerOctave(const Model& model, const r3d_result& res, int s, s
 void OutputPostSimSummary(const Model& model, const r3d_result& res, const std::string& outdir,
                           std::ostream& console, std::ostream& trace);
 
+// --reports keywords (reference main.cpp:223-258) -> R3D_RPT_* mask.  `csv` is the keyword
+// list as given ("ALL_ON", "GEN,SCT,REF", "SCATTERS", ...); empty = none.
+uint32_t ReportMaskFromKeywords(const std::string& csv);
+
+// DataReporter::output_phonon_dataline (dataout.cpp:484-520) for every record, grouped by
+// history id in the order the events happened (the reference runs histories one after the
+// other; the engine's buffer interleaves them).  The "cell:" column, a heap address in the
+// reference, carries the cell index.
+void OutputReports(const r3d_event* ev, size_t n, std::ostream& out);
+
 #endif

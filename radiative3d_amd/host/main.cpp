@@ -100,6 +100,8 @@ void run_event_test(const ModelParams& par) {
 struct Shard {
   std::vector<double> energy;
   std::vector<uint64_t> counts;
+  std::vector<r3d_event> events;
+  uint64_t events_reported = 0;
   r3d_result res{};
   std::string error;
 };
@@ -107,7 +109,8 @@ struct Shard {
 // The replacement for Model::RunSimulation()'s loop: shard the id range over the
 // requested GPUs (one engine per device, one host thread each), sum on the host.
 void run_simulation(const Model& model, uint64_t n, uint64_t seed, int gpus, r3d_result& total,
-                    std::vector<double>& energy, std::vector<uint64_t>& counts) {
+                    std::vector<double>& energy, std::vector<uint64_t>& counts, uint32_t report_mask,
+                    std::vector<r3d_event>& events, uint64_t& events_dropped) {
   const r3d_model_desc& d = model.Desc();
   const size_t ne = (size_t)d.n_seismometers * d.params.n_bins * R3D_N_ENERGY;
   const size_t nc = (size_t)d.n_seismometers * d.params.n_bins * R3D_N_COUNT;
@@ -128,7 +131,15 @@ void run_simulation(const Model& model, uint64_t n, uint64_t seed, int gpus, r3d
         sh.error = r3d_last_error();
         return;
       }
-      if (r3d_run(e, cnt, lo, seed, &sh.res)) sh.error = r3d_last_error();
+      // report stream: room for 256 events per history, at most 2^26 records (6.4 GB) per GPU
+      const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(cnt, 1) * 256, uint64_t(1) << 26);
+      if (report_mask && r3d_engine_set_event_log(e, report_mask, cap)) sh.error = r3d_last_error();
+      if (sh.error.empty() && r3d_run(e, cnt, lo, seed, &sh.res)) sh.error = r3d_last_error();
+      if (sh.error.empty() && report_mask) {
+        sh.events_reported = r3d_event_log_count(e);
+        sh.events.resize((size_t)std::min<uint64_t>(sh.events_reported, cap));
+        if (r3d_event_log_read(e, sh.events.data(), sh.events.size(), 0) == ~uint64_t(0)) sh.error = r3d_last_error();
+      }
       r3d_engine_destroy(e);
     });
   }
@@ -140,6 +151,8 @@ void run_simulation(const Model& model, uint64_t n, uint64_t seed, int gpus, r3d
     total.n_lost += sh.res.n_lost, total.n_timeout += sh.res.n_timeout, total.n_invalid += sh.res.n_invalid;
     for (int r = 0; r < R3D_INV_NUM; r++) total.invalid_reasons[r] += sh.res.invalid_reasons[r];
     for (int k = 0; k < R3D_EV_NUM; k++) total.events[k] += sh.res.events[k];
+    events.insert(events.end(), sh.events.begin(), sh.events.end());
+    events_dropped += sh.events_reported - sh.events.size();
   }
 }
 
@@ -168,9 +181,14 @@ int main(int argc, char* argv[]) {
     std::ofstream f(fn.c_str());
     OutputModelParamsOctave(par, f);
   }
-  if (!mission.Reports.empty() && mission.Reports != "INV" && mission.Reports != "ALL_OFF")
-    std::cerr << "Note: per-event report stream (--reports=" << mission.Reports
-              << ") is not produced by the GPU engine.\n";
+  uint32_t report_mask = 0;
+  try {
+    report_mask = ReportMaskFromKeywords(mission.Reports);
+  } catch (std::exception& e) {
+    std::cout << "** Error processing command-line options\n** Message: " << e.what()
+              << "\n** Exiting...\n";
+    return 1;
+  }
   if (mission.bRTCoefTest) run_rtcoef_test(100, 10, 8, 4, 8, 4, 2);
   const char* phase = "while constructing Earth model:";
   try {
@@ -186,8 +204,21 @@ int main(int argc, char* argv[]) {
         r3d_result res;
         std::vector<double> energy;
         std::vector<uint64_t> counts;
+        std::vector<r3d_event> events;
+        uint64_t dropped = 0;
         run_simulation(model, (uint64_t)std::max(0L, par.NumPhonons), mission.Seed,
-                       std::max(1, mission.Gpus), res, energy, counts);
+                       std::max(1, mission.Gpus), res, energy, counts, report_mask, events, dropped);
+        if (report_mask) {   // the reference writes them as they happen: stdout, or --report-file
+          if (mission.ReportFile.empty()) {
+            OutputReports(events.data(), events.size(), std::cout);
+          } else {
+            const std::string fn = mission.OutputDir.empty() ? mission.ReportFile
+                                                             : mission.OutputDir + "/" + mission.ReportFile;
+            std::ofstream f(fn.c_str());
+            OutputReports(events.data(), events.size(), f);
+          }
+          if (dropped) std::cerr << "Note: " << dropped << " report lines did not fit the event buffer.\n";
+        }
         std::cerr << "100% of " << par.NumPhonons << " have been cast.\n";
         std::cout << "@@ __SIMULATION_COMPLETE__" << std::endl;
         // seis_traces_asc.dat is opened in the CWD whatever --output-dir says (dataout.hpp:332)

@@ -153,6 +153,21 @@ class Model:
             raise RuntimeError("write_outputs failed: " + self._lib.r3dh_last_error().decode())
         return txt.decode()
 
+    @property
+    def report_mask(self):
+        """R3D_RPT_* mask asked for by --reports in the model's arguments."""
+        return int(self._lib.r3dh_model_report_mask(self._h))
+
+    def format_reports(self, events, path=None):
+        """Event records (Engine.read_event_log) as the reference's report lines
+        (dataout.cpp:484-520); written to `path`, or returned as text."""
+        import numpy as np
+        ev = np.ascontiguousarray(events, dtype=_ffi.event_dtype())
+        txt = self._lib.r3dh_write_reports(self._h, ev.ctypes.data, len(ev), path.encode() if path else None)
+        if txt is None:
+            raise RuntimeError("write_reports failed: " + self._lib.r3dh_last_error().decode())
+        return txt.decode()
+
     def new_result(self):
         return Result(self.n_seismometers, self.n_bins)
 
@@ -226,6 +241,25 @@ class Engine:
 
     def volume_device_ptr(self):
         return self._lib.r3d_volume_device_ptr(self._e)
+
+    # -- per-event report stream (the reference's --reports) -------------------
+    def set_event_log(self, mask=_ffi.R3D_RPT_ALL, capacity=1 << 20):
+        """Attach an HBM buffer of `capacity` r3d_event records for the tags in `mask`."""
+        if self._lib.r3d_engine_set_event_log(self._e, int(mask), int(capacity)):
+            raise RuntimeError("r3d_engine_set_event_log failed: " + self._lib.r3d_last_error().decode())
+        self._ev_cap = int(capacity) if mask else 0
+
+    def event_log_count(self):
+        return int(self._lib.r3d_event_log_count(self._e))
+
+    def read_event_log(self, reset=False):
+        """Stored records as a numpy structured array (_ffi.event_dtype)."""
+        n = min(self.event_log_count(), self._ev_cap)
+        out = np.zeros(n, dtype=_ffi.event_dtype())
+        got = self._lib.r3d_event_log_read(self._e, out.ctypes.data, n, int(reset))
+        if got == (1 << 64) - 1:
+            raise RuntimeError("r3d_event_log_read failed: " + self._lib.r3d_last_error().decode())
+        return out[:got]
 
     def last_kernel_ms(self):
         return float(self._lib.r3d_last_kernel_ms(self._e))

@@ -122,3 +122,23 @@ def test_main_cli_end_to_end_on_gpu(tmp_path):
     assert (s["CountPS"] == want.counts[100]).all()
     assert np.allclose(s["TracePS"], want.energy[100, :, 3:], rtol=1e-5)
     assert os.path.exists(tmp_path / "seis_traces_asc.dat") and os.path.exists(tmp_path / "out_mparams.octv")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(MAIN), reason="./main not built")
+def test_main_cli_report_file_on_gpu(tmp_path):
+    """--reports / --report-file (reference main.cpp:223-263): the file holds one line per
+    requested event, in the reference's line format, grouped by history."""
+    args = [a for a in halfspace(4)] + ["--num-phonons=500", "--seed=11", f"--output-dir={tmp_path}",
+                                        "--reports=GEN,LST,TMO", "--report-file=reports.dat"]
+    run = subprocess.run([MAIN] + args, capture_output=True, text=True, cwd=tmp_path)
+    assert run.returncode == 0, run.stdout[-2000:]
+    lines = open(tmp_path / "reports.dat").read().splitlines()
+    tags = [l[:3] for l in lines]
+    assert tags.count("GEN") == 500 and tags.count("LST") + tags.count("TMO") == 500 and len(lines) == 1000
+    assert tags[0::2] == ["GEN"] * 500                       # GEN then its history's end, id by id
+    ids = [int(l[4:11]) for l in lines]
+    assert ids == sorted(ids) and ids[0] == 0 and ids[-1] == 499
+    m = Model(halfspace(4))
+    _, ev, _ = O.run_with_events(m, 500, mask=1 | 32 | 64, seed=11)
+    assert m.format_reports(ev).splitlines() == lines
