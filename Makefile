@@ -26,7 +26,7 @@ HOST_SRC := $(HOSTDIR)/ecs.cpp $(HOSTDIR)/grid.cpp $(HOSTDIR)/model.cpp \
             $(HOSTDIR)/models_builtin.cpp $(HOSTDIR)/cmdline.cpp $(HOSTDIR)/dataout.cpp \
             $(HOSTDIR)/capi.cpp
 HOST_HDR := $(wildcard $(HOSTDIR)/*.hpp) include/r3d.h include/r3d_host.h
-ENGINE_SRC := $(CSRC)/r3d_engine.hip
+ENGINE_SRC := $(CSRC)/r3d_engine.hip $(CSRC)/r3d_tables_build.hip
 ENGINE_HDR := $(wildcard $(CSRC)/*.h) include/r3d.h
 
 .PHONY: default all host engine oracle cli clean

@@ -90,6 +90,17 @@ typedef struct r3d_scatterer {
   double        whole_cdf[2][4];
   const double* cdf[4];      /* each n_toa long                             */
   const double* spol;        /* n_toa, S->S polarisation (scatparams.cpp:114)*/
+  /* Build-on-device form.  With cdf[0] == NULL the engine evaluates the tables
+   * itself, in HBM, from the medium's heterogeneity parameters (what
+   * Scatterer::Scatterer does on the host, scatterers.cpp:97-220, with
+   * ScatterParams::GSATO, scatparams.cpp:75-194); whole_cdf, and mfp unless
+   * mfp_fixed, are then outputs -- read them with r3d_engine_scatterer_stats. */
+  double        het[6];      /* nu, eps, a, kappa, el = omega/Vs, gam0 = Vp/Vs
+                                (scatparams.hpp:60-77)                       */
+  double        psdf_numer;  /* 8 pi^1.5 eps^2 a^3 Gamma(kappa+1.5)/Gamma(kappa),
+                                the numerator of PSATO (scatparams.cpp:175-190)*/
+  uint32_t      mfp_fixed;   /* keep mfp[] as given (--overridemfp)          */
+  uint32_t      pad_;
 } r3d_scatterer;
 
 /* Event source (reference events.hpp:57-61, sources.hpp:130-135):
@@ -199,6 +210,15 @@ typedef struct r3d_engine r3d_engine;   /* opaque: tables resident in HBM   */
  * one engine per thread.                                                   */
 r3d_engine* r3d_engine_create(const r3d_model_desc* model, int device);
 void        r3d_engine_destroy(r3d_engine* e);
+
+/* Scatterer s as the engine holds it: out[0..1] = MFP P, S; out[2..3] = dipole
+ * moments P, S (scatterers.cpp:244-259; NaN for host-built tables, whose raw
+ * weights the engine never sees); out[4..7] = totals of the four cumulative
+ * tables.  Returns 0 on success.                                            */
+int r3d_engine_scatterer_stats(const r3d_engine* e, int s, double out[8]);
+/* Copy scatterer s's tables from HBM (n_toa doubles each; any pointer may be
+ * NULL to skip): for parity tests of the build-on-device form.              */
+int r3d_engine_download_scatterer(r3d_engine* e, int s, double* cdf[4], double* spol);
 
 /* Sizes of the result block for this engine's model.                       */
 size_t r3d_energy_len(const r3d_engine* e);   /* doubles                    */

@@ -54,6 +54,12 @@ const char* r3dh_params_echo(r3dh_model* m);
 const char* r3dh_write_outputs(r3dh_model* m, const r3d_result* result, const char* outdir,
                                const char* trace_path, const char* mparams_path);
 
+/* For a model built with --device-tables (scattering tables left to the engine):
+ * record what r3d_engine_scatterer_stats() returned, so that the scatterer dump
+ * and r3dh_scatterer_info show the engine's numbers.  Returns 0 ok.            */
+int r3dh_model_set_scatterer_stats(r3dh_model* m, int s, const double mfp[2], const double dipole[2]);
+int r3dh_model_device_tables(const r3dh_model* m);   /* 1 if built with --device-tables */
+
 /* --reports keyword list ("ALL_ON", "GEN,SCT,REF", "SCATTERS", ... as on the
  * reference's command line, main.cpp:223-258) -> R3D_RPT_* mask; (uint32_t)-1 on
  * an unknown keyword.  The mask the model's own argv asked for:            */

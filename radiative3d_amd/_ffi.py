@@ -37,7 +37,8 @@ class Cell(C.Structure):
 
 class Scatterer(C.Structure):
     _fields_ = [("mfp", C.c_double * 2), ("whole_cdf", (C.c_double * 4) * 2), ("cdf", _dp * 4),
-                ("spol", _dp)]
+                ("spol", _dp), ("het", C.c_double * 6), ("psdf_numer", C.c_double),
+                ("mfp_fixed", C.c_uint32), ("pad_", C.c_uint32)]
 
 
 class Source(C.Structure):
@@ -137,6 +138,10 @@ def host_lib():
         L.r3dh_scatterer_dump.argtypes = [C.c_void_p]
         L.r3dh_params_echo.restype = C.c_char_p
         L.r3dh_params_echo.argtypes = [C.c_void_p]
+        L.r3dh_model_set_scatterer_stats.restype = C.c_int
+        L.r3dh_model_set_scatterer_stats.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        L.r3dh_model_device_tables.restype = C.c_int
+        L.r3dh_model_device_tables.argtypes = [C.c_void_p]
         L.r3dh_report_mask.restype = C.c_uint32
         L.r3dh_report_mask.argtypes = [C.c_char_p]
         L.r3dh_model_report_mask.restype = C.c_uint32
@@ -178,6 +183,10 @@ def hip_lib():
         L.r3d_volume_read.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]
         L.r3d_volume_device_ptr.restype = C.c_void_p
         L.r3d_volume_device_ptr.argtypes = [C.c_void_p]
+        L.r3d_engine_scatterer_stats.restype = C.c_int
+        L.r3d_engine_scatterer_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        L.r3d_engine_download_scatterer.restype = C.c_int
+        L.r3d_engine_download_scatterer.argtypes = [C.c_void_p, C.c_int, C.POINTER(_dp), _dp]
         L.r3d_engine_set_event_log.restype = C.c_int
         L.r3d_engine_set_event_log.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
         L.r3d_event_log_count.restype = C.c_uint64

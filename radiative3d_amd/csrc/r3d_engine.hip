@@ -33,6 +33,7 @@
 #include "../../include/r3d.h"
 #include "r3d_pack.h"
 #include "r3d_step.h"
+#include "r3d_tables_build.h"
 
 namespace r3d {
 
@@ -566,6 +567,12 @@ struct r3d_engine {
   std::unique_ptr<DevBuf> d_volume;
   size_t volume_len = 0;
   std::unique_ptr<DevBuf> d_evlog, d_evlog_count;
+  struct ScatStats {
+    double mfp[2], dipole[2], total[4];
+  };
+  std::vector<ScatStats> scat_stats;
+  std::vector<ScatPtrs> scat_ptrs;   // device addresses of every scatterer's tables
+  uint64_t n_toa = 0;
 
   DevBuf* keep(std::unique_ptr<DevBuf> b) {
     bufs.push_back(std::move(b));
@@ -646,7 +653,8 @@ bool check_model(const r3d_model_desc* m) {
   }
   for (int s = 0; s < m->n_scatterers; s++)
     for (int k = 0; k < 4; k++)
-      if (!m->scatterers[s].cdf[k] || !m->scatterers[s].spol) return g_error = "scatterer table missing", false;
+      if (m->scatterers[s].cdf[0] && (!m->scatterers[s].cdf[k] || !m->scatterers[s].spol))
+        return g_error = "scatterer table missing", false;
   for (int k = 0; k < 3; k++)
     if (!m->source.cdf[k]) return g_error = "source table missing", false;
   return true;
@@ -700,13 +708,79 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
       break;
     default: a.cells = upload_vec(e.get(), pm.sph, &err);
   }
+  e->n_toa = m->n_toa;
+  e->scat_stats.resize(m->n_scatterers);
+  const double* d_toa = nullptr;   // (theta, phi) pairs, only while tables are built here
+  std::unique_ptr<DevBuf> toa_buf;
   for (int s = 0; s < m->n_scatterers; s++) {
-    for (int k = 0; k < 4; k++) {
-      pm.scat_ptrs[s].cdf[k] = upload_doubles(e.get(), m->scatterers[s].cdf[k], m->n_toa, &err);
-      pm.scat_ptrs[s].guide[k] = upload_vec(e.get(), pm.scat_guide[s * 4 + k], &err);
+    const r3d_scatterer& S = m->scatterers[s];
+    r3d_engine::ScatStats& st = e->scat_stats[s];
+    const double nan = std::nan("");
+    if (S.cdf[0]) {   // host-built tables: copy them in
+      for (int k = 0; k < 4; k++) {
+        pm.scat_ptrs[s].cdf[k] = upload_doubles(e.get(), S.cdf[k], m->n_toa, &err);
+        pm.scat_ptrs[s].guide[k] = upload_vec(e.get(), pm.scat_guide[s * 4 + k], &err);
+        st.total[k] = S.cdf[k][m->n_toa - 1];
+      }
+      pm.scat_ptrs[s].spol = upload_doubles(e.get(), S.spol, m->n_toa, &err);
+      st.mfp[0] = S.mfp[0], st.mfp[1] = S.mfp[1], st.dipole[0] = st.dipole[1] = nan;
+      continue;
     }
-    pm.scat_ptrs[s].spol = upload_doubles(e.get(), m->scatterers[s].spol, m->n_toa, &err);
+    // build-on-device form (r3d_tables_build.hip)
+    if (!d_toa) {
+      toa_buf = std::make_unique<DevBuf>();
+      if (hipError_t r = toa_buf->upload(m->toa, m->n_toa * 2 * sizeof(double)); r != hipSuccess) err = r;
+      d_toa = reinterpret_cast<const double*>(toa_buf->p);
+    }
+    double* d_cdf[4];
+    for (int k = 0; k < 4; k++) {
+      auto b = std::make_unique<DevBuf>();
+      if (hipError_t r = b->alloc_zero(m->n_toa * sizeof(double)); r != hipSuccess) err = r;
+      d_cdf[k] = reinterpret_cast<double*>(e->keep(std::move(b))->p);
+    }
+    auto sp = std::make_unique<DevBuf>();
+    if (hipError_t r = sp->alloc_zero(m->n_toa * sizeof(double)); r != hipSuccess) err = r;
+    double* d_spol = reinterpret_cast<double*>(e->keep(std::move(sp))->p);
+    if (err != hipSuccess) break;
+    double cos_sums[4];
+    if (hipError_t r = build_scatterer_tables(S.het, S.psdf_numer, d_toa, m->n_toa, d_cdf, d_spol, st.total,
+                                              cos_sums, nullptr);
+        r != hipSuccess) {
+      err = r;
+      break;
+    }
+    for (int k = 0; k < 4; k++) {
+      auto g = std::make_unique<DevBuf>();
+      if (hipError_t r = g->alloc_zero(((size_t(1) << a.guide_bits) + 1) * sizeof(uint32_t)); r != hipSuccess) err = r;
+      uint32_t* d_guide = reinterpret_cast<uint32_t*>(e->keep(std::move(g))->p);
+      if (err == hipSuccess)
+        if (hipError_t r = build_guide_on_device(d_cdf[k], m->n_toa, a.guide_bits, d_guide, nullptr); r != hipSuccess)
+          err = r;
+      pm.scat_ptrs[s].cdf[k] = d_cdf[k], pm.scat_ptrs[s].guide[k] = d_guide;
+      pm.scat_head[s].total[k] = st.total[k];
+    }
+    pm.scat_ptrs[s].spol = d_spol;
+    // Mean free paths, conversion table and dipole moments from the totals, as the host
+    // builder derives them (scatterers.cpp:172-220, :244-259)
+    const double* tot = st.total;
+    const double n = (double)m->n_toa;
+    st.mfp[0] = S.mfp_fixed ? S.mfp[0] : 1.0 / ((tot[0] + tot[1]) / n);
+    st.mfp[1] = S.mfp_fixed ? S.mfp[1] : 1.0 / ((tot[2] + tot[3]) / n);
+    auto frac = [](double part, double whole) { return whole == 0 ? 0.0 : part / whole; };
+    st.dipole[0] = frac(cos_sums[0], tot[0]) * frac(tot[0], tot[0] + tot[1]) +
+                   frac(cos_sums[1], tot[1]) * frac(tot[1], tot[0] + tot[1]);
+    st.dipole[1] = frac(cos_sums[2], tot[2]) * frac(tot[2], tot[2] + tot[3]) +
+                   frac(cos_sums[3], tot[3]) * frac(tot[3], tot[2] + tot[3]);
+    const double wp[2][4] = {{tot[0], tot[1], 0, 0}, {0, 0, tot[2], tot[3]}};
+    for (int t = 0; t < 2; t++) {
+      pm.scat_head[s].mfp[t] = st.mfp[t];
+      double acc = 0;
+      for (int k = 0; k < 4; k++) pm.scat_head[s].whole[t][k] = (acc += wp[t][k]);
+    }
   }
+  if (err == hipSuccess && d_toa) err = hipDeviceSynchronize();   // guides done before toa_buf goes
+  toa_buf.reset();
+  e->scat_ptrs = pm.scat_ptrs;
   a.scat_head = upload_vec(e.get(), pm.scat_head, &err);
   a.scat_ptrs = upload_vec(e.get(), pm.scat_ptrs, &err);
   a.toa_xyz = upload_vec(e.get(), pm.toa_xyz, &err);
@@ -879,6 +953,25 @@ int r3d_debug_phase_cycles(unsigned long long out[8]) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof zero) != hipSuccess;
 }
 #endif
+
+int r3d_engine_scatterer_stats(const r3d_engine* e, int s, double out[8]) {
+  if (!e || !out || s < 0 || s >= (int)e->scat_stats.size()) return g_error = "scatterer index out of range", 1;
+  const r3d_engine::ScatStats& st = e->scat_stats[s];
+  out[0] = st.mfp[0], out[1] = st.mfp[1], out[2] = st.dipole[0], out[3] = st.dipole[1];
+  for (int k = 0; k < 4; k++) out[4 + k] = st.total[k];
+  return 0;
+}
+
+int r3d_engine_download_scatterer(r3d_engine* e, int s, double* cdf[4], double* spol) {
+  const int fail_value = 1;
+  if (!e || s < 0 || s >= (int)e->scat_ptrs.size()) return g_error = "scatterer index out of range", 1;
+  R3D_HIP_OK(hipSetDevice(e->device));
+  const size_t bytes = e->n_toa * sizeof(double);
+  for (int k = 0; k < 4; k++)
+    if (cdf && cdf[k]) R3D_HIP_OK(hipMemcpy(cdf[k], e->scat_ptrs[s].cdf[k], bytes, hipMemcpyDeviceToHost));
+  if (spol) R3D_HIP_OK(hipMemcpy(spol, e->scat_ptrs[s].spol, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
 
 int r3d_engine_set_event_log(r3d_engine* e, uint32_t mask, uint64_t capacity) {
   const int fail_value = 1;

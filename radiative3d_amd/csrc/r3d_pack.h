@@ -295,6 +295,11 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm) {
       pm.scat_head[s].mfp[t] = S.mfp[t];
       for (int k = 0; k < 4; k++) pm.scat_head[s].whole[t][k] = S.whole_cdf[t][k];
     }
+    if (!S.cdf[0]) {   // build-on-device form: the engine fills head, tables and guides
+      for (int k = 0; k < 4; k++) pm.scat_ptrs[s].cdf[k] = nullptr, pm.scat_ptrs[s].guide[k] = nullptr;
+      pm.scat_ptrs[s].spol = nullptr;
+      continue;
+    }
     for (int k = 0; k < 4; k++) {
       pm.scat_ptrs[s].cdf[k] = S.cdf[k];
       pm.scat_head[s].total[k] = S.cdf[k][m.n_toa - 1];

@@ -1,0 +1,25 @@
+// r3d_tables_build.h -- device-side construction of the scattering tables
+// (implementation and references: r3d_tables_build.hip).
+#ifndef R3D_TABLES_BUILD_H_
+#define R3D_TABLES_BUILD_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace r3d {
+
+// Fill d_cdf[0..3] (GPP, GPS, GSP, GSS; cumulative, n entries each) and d_spol (n) for the
+// heterogeneity parameters het = {nu, eps, a, kappa, el, gam0} over the take-off set d_toa
+// ((theta, phi) pairs).  totals[c] = d_cdf[c][n-1]; cos_sums[c] = sum cos(theta_k) w_c[k]
+// over the raw weights.  Blocks until done.
+hipError_t build_scatterer_tables(const double het[6], double psdf_numer, const double* d_toa, uint64_t n,
+                                  double* d_cdf[4], double* d_spol, double totals[4], double cos_sums[4],
+                                  hipStream_t stream);
+
+// guide[j] = smallest k with total * j / 2^bits <= cdf[k], j = 0 .. 2^bits (asynchronous).
+hipError_t build_guide_on_device(const double* d_cdf, uint64_t n, uint32_t bits, uint32_t* d_guide,
+                                 hipStream_t stream);
+
+}  // namespace r3d
+#endif

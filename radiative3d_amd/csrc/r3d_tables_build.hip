@@ -1,0 +1,223 @@
+// r3d_tables_build.hip -- scattering tables built on the device.
+//
+// What the reference does per scatterer on the host (Scatterer::Scatterer,
+// scatterers.cpp:97-220; ScatterParams::GSATO / XSATO / PSATO,
+// scatparams.cpp:75-194): evaluate the Sato & Fehler scattering coefficients
+// g_PP, g_PS, g_SP, g_SS (eq. 4.52 with the basic patterns of eq. 4.50 and the
+// von-Karman power spectrum) and the S->S polarisation angle at every one of
+// the 20 * 4^degree take-off directions, then integrate each into a cumulative
+// table.  At degree 9 that is 5.2 M directions x 5 arrays per scatterer -- about
+// 2 s of host time for the 7 NSCP scatterers on 16 cores, plus 0.5 s to copy the
+// 1.5 GB result into HBM -- against 0.3 s of kernel time for 1e8 histories.  Here
+// the tables are produced where they are used:
+//   gsato_kernel      one work-item per direction: the four weights + spol, and the
+//                     cos(theta)-weighted block sums the dipole diagnostics need
+//   scan_blocks       inclusive sum inside 4096-element blocks (16 per work-item)
+//   scan_block_sums   one work-item adds up the block totals in order
+//   add_offsets       block offsets added back
+//   guide_kernel      the search guides of r3d_pack.h build_guide, by bisection
+// fp64 throughout; HBM-bound streaming kernels (~0.3 GB of traffic per scatterer).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "r3d_tables_build.h"
+
+namespace r3d {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kItems = 16;                       // per work-item in the scan
+constexpr int kScanBlock = kThreads * kItems;    // elements per block
+
+struct Het {
+  double nu, eps, a, kappa, el, gam0, psdf_numer;
+};
+
+// ScatterParams::PSATO, scatparams.cpp:160-194 (numerator evaluated once on the host)
+__device__ __forceinline__ double psato(const Het& h, double m) {
+  return h.psdf_numer / pow(1. + h.a * h.a * m * m, h.kappa + 1.5);
+}
+
+// ScatterParams::GSATO + XSATO, scatparams.cpp:75-158.  Weights below 1e-30 are zeroed as
+// the reference does.
+__global__ __launch_bounds__(kThreads) void gsato_kernel(Het h, const double* __restrict__ toa, uint64_t n,
+                                                         double* __restrict__ w0, double* __restrict__ w1,
+                                                         double* __restrict__ w2, double* __restrict__ w3,
+                                                         double* __restrict__ spol,
+                                                         double* __restrict__ block_cos /* [blocks][4] */) {
+  const uint64_t k = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  double g[4] = {0, 0, 0, 0}, cz = 0;
+  if (k < n) {
+    const double psi = toa[2 * k], zeta = toa[2 * k + 1];
+    const double g2 = h.gam0 * h.gam0;
+    const double cpsi = cos(psi), c2psi = cos(2. * psi), spsi = sin(psi);
+    const double czeta = cos(zeta), szeta = sin(zeta);
+    const double spsi2 = spsi * spsi;
+    const double xpp = (1. / g2) * (h.nu * (-1. + cpsi + (2. / g2) * spsi2) - 2. + (4. / g2) * spsi2);
+    const double xps = -spsi * (h.nu * (1. - (2. / h.gam0) * cpsi) - (4. / h.gam0) * cpsi);
+    const double xsp = (1. / g2) * spsi * czeta * (h.nu * (1. - (2. / h.gam0) * cpsi) - (4. / h.gam0) * cpsi);
+    const double xss_psi = czeta * (h.nu * (cpsi - c2psi) - 2. * c2psi);
+    const double xss_zeta = szeta * (h.nu * (cpsi - 1.) + 2. * cpsi);
+    const double pi4 = 4. * 3.14159265358979323846;
+    const double el4 = (h.el * h.el) * (h.el * h.el);
+    double m = (2. * h.el / h.gam0) * sin(psi / 2.);
+    g[0] = (el4 / pi4) * (xpp * xpp) * psato(h, m);
+    m = (h.el / h.gam0) * sqrt(1. + g2 - 2. * h.gam0 * cpsi);
+    const double pm = psato(h, m);
+    g[1] = (1. / h.gam0) * (el4 / pi4) * (xps * xps) * pm;
+    g[2] = h.gam0 * (el4 / pi4) * (xsp * xsp) * pm;
+    m = 2. * h.el * sin(psi / 2.);
+    g[3] = (el4 / pi4) * (xss_psi * xss_psi + xss_zeta * xss_zeta) * psato(h, m);
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+      if (g[c] < 1.e-30) g[c] = 0.;
+    w0[k] = g[0], w1[k] = g[1], w2[k] = g[2], w3[k] = g[3];
+    spol[k] = atan2(xss_zeta, xss_psi);
+    cz = cpsi;
+  }
+  // block sums of cos(theta) * weight (dipole moments, scatterers.cpp:244-259)
+  __shared__ double s_part[kThreads / 64][4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    double v = cz * g[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6][c] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double v = 0;
+    for (int wv = 0; wv < kThreads / 64; wv++) v += s_part[wv][threadIdx.x];
+    block_cos[(size_t)blockIdx.x * 4 + threadIdx.x] = v;
+  }
+}
+
+// In-place inclusive sum inside each block of kScanBlock elements; block totals out.
+// grid.y selects the array.
+__global__ __launch_bounds__(kThreads) void scan_blocks(double* const* __restrict__ arrays, uint64_t n,
+                                                        double* __restrict__ block_sums, uint32_t n_blocks) {
+  double* v = arrays[blockIdx.y];
+  const uint64_t base = (uint64_t)blockIdx.x * kScanBlock + (uint64_t)threadIdx.x * kItems;
+  double x[kItems];
+  double run = 0;
+#pragma unroll
+  for (int i = 0; i < kItems; i++) {
+    const uint64_t k = base + i;
+    run += (k < n) ? v[k] : 0.0;
+    x[i] = run;
+  }
+  // Exclusive prefix of the work-items' totals, added up IN ORDER by one work-item: the
+  // table must be non-decreasing to the last bit (engine and oracle bisect it from different
+  // brackets), and with a sequential chain "last element of work-item t" and "base of
+  // work-item t+1" are the same rounded number.  256 additions per 4096 elements.
+  __shared__ double s_run[kThreads];
+  s_run[threadIdx.x] = run;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double acc = 0;
+    for (int t = 0; t < kThreads; t++) {
+      const double r = s_run[t];
+      s_run[t] = acc;
+      acc += r;
+    }
+  }
+  __syncthreads();
+  const double before = s_run[threadIdx.x];
+#pragma unroll
+  for (int i = 0; i < kItems; i++) {
+    const uint64_t k = base + i;
+    if (k < n) v[k] = before + x[i];
+  }
+  if (threadIdx.x == kThreads - 1) block_sums[(size_t)blockIdx.y * n_blocks + blockIdx.x] = before + run;
+}
+
+// Exclusive sum of the block totals, in order (a few hundred to a few thousand entries).
+__global__ void scan_block_sums(double* __restrict__ block_sums, uint32_t n_blocks) {
+  double* s = block_sums + (size_t)blockIdx.x * n_blocks;
+  if (threadIdx.x == 0) {
+    double run = 0;
+    for (uint32_t b = 0; b < n_blocks; b++) {
+      const double t = s[b];
+      s[b] = run;
+      run += t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void add_offsets(double* const* __restrict__ arrays, uint64_t n,
+                                                        const double* __restrict__ block_sums, uint32_t n_blocks) {
+  double* v = arrays[blockIdx.y];
+  const double off = block_sums[(size_t)blockIdx.y * n_blocks + blockIdx.x];
+  if (blockIdx.x == 0) return;
+  const uint64_t base = (uint64_t)blockIdx.x * kScanBlock;
+  for (int i = threadIdx.x; i < kScanBlock; i += kThreads) {
+    const uint64_t k = base + i;
+    if (k < n) v[k] += off;
+  }
+}
+
+// guide[j] = smallest k with total * (j / G) <= cdf[k], j = 0..G (r3d_pack.h build_guide).
+__global__ __launch_bounds__(kThreads) void guide_kernel(const double* __restrict__ cdf, uint64_t n, uint32_t bits,
+                                                         uint32_t* __restrict__ guide) {
+  const uint64_t G = 1ull << bits;
+  const uint64_t j = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (j > G) return;
+  const double r = cdf[n - 1] * ((double)j / (double)G);
+  uint64_t lo = 0, hi = n - 1;   // first k in [0, n-1] with r <= cdf[k], else n-1
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (r <= cdf[mid]) hi = mid;
+    else lo = mid + 1;
+  }
+  guide[j] = (uint32_t)lo;
+}
+
+}  // namespace
+
+hipError_t build_scatterer_tables(const double het[6], double psdf_numer, const double* d_toa, uint64_t n,
+                                  double* d_cdf[4], double* d_spol, double totals[4], double cos_sums[4],
+                                  hipStream_t stream) {
+  if (n == 0) return hipErrorInvalidValue;
+  Het h{het[0], het[1], het[2], het[3], het[4], het[5], psdf_numer};
+  const uint32_t g_blocks = (uint32_t)((n + kThreads - 1) / kThreads);
+  const uint32_t s_blocks = (uint32_t)((n + kScanBlock - 1) / kScanBlock);
+  double *d_cos = nullptr, *d_sums = nullptr;
+  double** d_arrays = nullptr;
+  hipError_t err = hipMalloc(&d_cos, (size_t)g_blocks * 4 * sizeof(double));
+  if (err == hipSuccess) err = hipMalloc(&d_sums, (size_t)s_blocks * 4 * sizeof(double));
+  if (err == hipSuccess) err = hipMalloc(&d_arrays, 4 * sizeof(double*));
+  if (err == hipSuccess) err = hipMemcpyAsync(d_arrays, d_cdf, 4 * sizeof(double*), hipMemcpyHostToDevice, stream);
+  if (err == hipSuccess) {
+    gsato_kernel<<<g_blocks, kThreads, 0, stream>>>(h, d_toa, n, d_cdf[0], d_cdf[1], d_cdf[2], d_cdf[3], d_spol, d_cos);
+    scan_blocks<<<dim3(s_blocks, 4), kThreads, 0, stream>>>(d_arrays, n, d_sums, s_blocks);
+    scan_block_sums<<<4, 64, 0, stream>>>(d_sums, s_blocks);
+    add_offsets<<<dim3(s_blocks, 4), kThreads, 0, stream>>>(d_arrays, n, d_sums, s_blocks);
+    err = hipGetLastError();
+  }
+  std::vector<double> h_cos((size_t)g_blocks * 4);
+  if (err == hipSuccess)
+    err = hipMemcpyAsync(h_cos.data(), d_cos, h_cos.size() * sizeof(double), hipMemcpyDeviceToHost, stream);
+  for (int c = 0; c < 4 && err == hipSuccess; c++)
+    err = hipMemcpyAsync(&totals[c], d_cdf[c] + (n - 1), sizeof(double), hipMemcpyDeviceToHost, stream);
+  if (err == hipSuccess) err = hipStreamSynchronize(stream);
+  if (err == hipSuccess) {
+    for (int c = 0; c < 4; c++) cos_sums[c] = 0;
+    for (uint32_t b = 0; b < g_blocks; b++)
+      for (int c = 0; c < 4; c++) cos_sums[c] += h_cos[(size_t)b * 4 + c];
+  }
+  (void)hipFree(d_cos), (void)hipFree(d_sums), (void)hipFree(d_arrays);
+  return err;
+}
+
+hipError_t build_guide_on_device(const double* d_cdf, uint64_t n, uint32_t bits, uint32_t* d_guide,
+                                 hipStream_t stream) {
+  const uint64_t G = 1ull << bits;
+  guide_kernel<<<(uint32_t)((G + 1 + kThreads - 1) / kThreads), kThreads, 0, stream>>>(d_cdf, n, bits, d_guide);
+  return hipGetLastError();
+}
+
+}  // namespace r3d

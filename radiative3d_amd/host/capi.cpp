@@ -110,6 +110,13 @@ const char* r3dh_write_outputs(r3dh_model* m, const r3d_result* result, const ch
   return nullptr;
 }
 
+int r3dh_model_set_scatterer_stats(r3dh_model* m, int s, const double mfp[2], const double dipole[2]) {
+  if (!m || !mfp || !dipole || s < 0 || s >= (int)m->model->Scatterers().size()) return 1;
+  m->model->SetScattererStats(s, mfp, dipole);
+  return 0;
+}
+int r3dh_model_device_tables(const r3dh_model* m) { return m && m->model->DeviceTables() ? 1 : 0; }
+
 uint32_t r3dh_report_mask(const char* keywords) {
   try {
     return ReportMaskFromKeywords(keywords ? keywords : "");

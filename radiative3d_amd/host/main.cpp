@@ -110,7 +110,7 @@ struct Shard {
 // requested GPUs (one engine per device, one host thread each), sum on the host.
 void run_simulation(const Model& model, uint64_t n, uint64_t seed, int gpus, r3d_result& total,
                     std::vector<double>& energy, std::vector<uint64_t>& counts, uint32_t report_mask,
-                    std::vector<r3d_event>& events, uint64_t& events_dropped) {
+                    std::vector<r3d_event>& events, uint64_t& events_dropped, r3d_engine* engine0) {
   const r3d_model_desc& d = model.Desc();
   const size_t ne = (size_t)d.n_seismometers * d.params.n_bins * R3D_N_ENERGY;
   const size_t nc = (size_t)d.n_seismometers * d.params.n_bins * R3D_N_COUNT;
@@ -126,7 +126,7 @@ void run_simulation(const Model& model, uint64_t n, uint64_t seed, int gpus, r3d
       sh.res.energy = sh.energy.data(), sh.res.counts = sh.counts.data();
       const uint64_t lo = n / gpus * g + std::min<uint64_t>(g, n % gpus);
       const uint64_t cnt = n / gpus + ((uint64_t)g < n % gpus ? 1 : 0);
-      r3d_engine* e = r3d_engine_create(&d, g);
+      r3d_engine* e = (g == 0 && engine0) ? engine0 : r3d_engine_create(&d, g);
       if (!e) {
         sh.error = r3d_last_error();
         return;
@@ -171,7 +171,7 @@ int main(int argc, char* argv[]) {
   }
   if (mission.bHelpMsg) {
     std::cout << "\nOptions follow the Radiative3D manual (doc/MANUAL.md of the reference);\n"
-              << "additional: --seed=<n>  --gpus=<n>\n\n";
+              << "additional: --seed=<n>  --gpus=<n>  --device-tables\n\n";
     return 0;
   }
   OutputModelParams(par, std::cout);
@@ -197,6 +197,16 @@ int main(int argc, char* argv[]) {
       Model model(par);
       phase = "during model retrospective output:";
       if (mission.bDumpGrid) model.GetGridRef().DumpGridToAscii();
+      r3d_engine* engine0 = nullptr;
+      if (model.DeviceTables()) {   // the tables (and so the MFPs the dump prints) are made in HBM
+        engine0 = r3d_engine_create(&model.Desc(), 0);
+        if (!engine0) throw Runtime(r3d_last_error());
+        for (int s = 0; s < model.Desc().n_scatterers; s++) {
+          double st[8];
+          if (r3d_engine_scatterer_stats(engine0, s, st)) throw Runtime(r3d_last_error());
+          model.SetScattererStats(s, st, st + 2);
+        }
+      }
       PrintAllScatteringStats(model, std::cout);
       phase = "during simulation execution:";
       if (mission.bRunSim) {
@@ -207,7 +217,8 @@ int main(int argc, char* argv[]) {
         std::vector<r3d_event> events;
         uint64_t dropped = 0;
         run_simulation(model, (uint64_t)std::max(0L, par.NumPhonons), mission.Seed,
-                       std::max(1, mission.Gpus), res, energy, counts, report_mask, events, dropped);
+                       std::max(1, mission.Gpus), res, energy, counts, report_mask, events, dropped, engine0);
+        engine0 = nullptr;   // (destroyed by its shard)
         if (report_mask) {   // the reference writes them as they happen: stdout, or --report-file
           if (mission.ReportFile.empty()) {
             OutputReports(events.data(), events.size(), std::cout);
@@ -225,6 +236,7 @@ int main(int argc, char* argv[]) {
         std::ofstream trace("seis_traces_asc.dat");
         OutputPostSimSummary(model, res, mission.OutputDir, std::cout, trace);
       }
+      if (engine0) r3d_engine_destroy(engine0);
     }
   } catch (std::exception& e) {
     std::cout << "**\n** Error " << phase << "\n** What: " << e.what() << "\n** Exiting...\n";

@@ -188,6 +188,7 @@ Model::Model(const ModelParams& par, std::ostream* logp) {
   mNumPhonons = par.NumPhonons;
   mOverrideMFP = par.OverrideMFP;
   mNoDeflect = par.NoDeflect;
+  mDeviceTables = par.DeviceTables;
   mMFPOverride[0] = par.MFPOverride[0], mMFPOverride[1] = par.MFPOverride[1];
 
   // The coordinate system is process-global in the reference; start clean.
@@ -269,7 +270,14 @@ Model::Model(const ModelParams& par, std::ostream* logp) {
   mScatDesc.resize(mScatStore.size());
   for (size_t s = 0; s < mScatStore.size(); s++) {
     r3d_scatterer& d = mScatDesc[s];
+    d = r3d_scatterer{};
     for (int t = 0; t < 2; t++) d.mfp[t] = mScatInfo[s].mfp[t];
+    const ScatterParams& sp = mScatParams[s];
+    const double het[6] = {sp.GetNu(), sp.GetEps(), sp.GetA(), sp.GetKappa(), sp.GetL(), sp.GetGam0()};
+    for (int k = 0; k < 6; k++) d.het[k] = het[k];
+    d.psdf_numer = sp.GetPsdfNumer();
+    d.mfp_fixed = mOverrideMFP ? 1u : 0u;
+    if (mDeviceTables) continue;   // build-on-device form: no host tables
     for (int k = 0; k < 4; k++) d.cdf[k] = mScatStore[s]->cdf[k].data();
     d.spol = mScatStore[s]->spol.data();
     // reference scatterers.cpp:172-184: an incoming P can only go to GPP/GPS,
@@ -317,6 +325,16 @@ int Model::ScattererFor(const ScatterParams& requested) {
 
   const size_t n = mTOA.size();
   auto store = std::make_unique<ScatStore>();
+  if (mDeviceTables) {   // the engine evaluates the tables in HBM; only the parameters travel
+    const double nan = std::nan("");
+    ScattererInfo info{par.GetNu(), par.GetEps(), par.GetA(),  par.GetKappa(),
+                       par.GetL(),  par.GetGam0(), {nan, nan},  {nan, nan}};
+    if (mOverrideMFP) info.mfp[0] = mMFPOverride[0], info.mfp[1] = mMFPOverride[1];
+    mScatStore.push_back(std::move(store));
+    mScatParams.push_back(par);
+    mScatInfo.push_back(info);
+    return (int)mScatStore.size() - 1;
+  }
   for (auto& c : store->cdf) c.resize(n);
   store->spol.resize(n);
   parallel_for(n, [&](size_t lo, size_t hi) {

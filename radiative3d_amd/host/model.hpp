@@ -57,6 +57,9 @@ class ModelParams {
   Real MFPOverride[2] = {0, 0};
   bool NoDeflect = false;
   bool OcsRaw = false;
+  // --device-tables (not a reference option): leave the scattering tables to the engine,
+  // which evaluates them in HBM (include/r3d.h r3d_scatterer, build-on-device form).
+  bool DeviceTables = false;
 
   void AddSeismometerByWavelength(EarthCoords::Generic loc, axes_scheme_e ax, Real radius_wl);
   void AddSeismometerFixedRadius(EarthCoords::Generic loc, axes_scheme_e ax, Real radius);
@@ -90,6 +93,13 @@ class Model {
   const Grid& GetGridRef() const { return mGrid; }
   long NumPhonons() const { return mNumPhonons; }
   const std::vector<ScattererInfo>& Scatterers() const { return mScatInfo; }
+  // With --device-tables the mean free paths and dipole moments are the engine's output
+  // (r3d_engine_scatterer_stats): record them for the scatterer dump.
+  void SetScattererStats(int s, const double mfp[2], const double dipole[2]) {
+    for (int t = 0; t < 2; t++) mScatInfo.at(s).mfp[t] = mfp[t], mScatInfo.at(s).dipole[t] = dipole[t];
+    for (int t = 0; t < 2; t++) mScatDesc.at(s).mfp[t] = mfp[t];
+  }
+  bool DeviceTables() const { return mDeviceTables; }
   const std::vector<std::string>& SeisAxesDesc() const { return mSeisAxes; }   // "RTZ" / "ENZ" per seismometer
   const Tensor::Tensor& EventMT() const { return mEventMTUser; }               // as given by the user (NED)
   R3::XYZ EventLoc() const { return mEventLoc; }
@@ -126,7 +136,7 @@ class Model {
   std::vector<std::string> mSeisAxes;
   Tensor::Tensor mEventMTUser;
   R3::XYZ mEventLoc;
-  bool mOverrideMFP = false, mNoDeflect = false;
+  bool mOverrideMFP = false, mNoDeflect = false, mDeviceTables = false;
   Real mMFPOverride[2] = {0, 0};
   r3d_model_desc mDesc{};
 };

@@ -53,6 +53,7 @@ class ScatterParams {
   Real GetA() const { return a; }
   Real GetKappa() const { return kappa; }
   Real GetL() const { return el; }
+  Real GetPsdfNumer() const { return psdf_numer_; }
   Real GetGam0() const { return gam0; }
 
   // Sum of squared parameter differences; scatterers are shared between

@@ -154,6 +154,11 @@ class Model:
         return txt.decode()
 
     @property
+    def device_tables(self):
+        """True if built with --device-tables: the scattering tables are made by the engine."""
+        return bool(self._lib.r3dh_model_device_tables(self._h))
+
+    @property
     def report_mask(self):
         """R3D_RPT_* mask asked for by --reports in the model's arguments."""
         return int(self._lib.r3dh_model_report_mask(self._h))
@@ -189,6 +194,11 @@ class Engine:
         self._e = self._lib.r3d_engine_create(model.desc_p, device)
         if not self._e:
             raise RuntimeError("r3d_engine_create failed: " + self._lib.r3d_last_error().decode())
+        if model.device_tables:   # mean free paths / dipoles are the engine's output
+            for s in range(model.n_scatterers):
+                st = self.scatterer_stats(s)
+                model._lib.r3dh_model_set_scatterer_stats(model._h, s, (C.c_double * 2)(*st[0:2]),
+                                                          (C.c_double * 2)(*st[2:4]))
 
     def close(self):
         if getattr(self, "_e", None):
@@ -241,6 +251,23 @@ class Engine:
 
     def volume_device_ptr(self):
         return self._lib.r3d_volume_device_ptr(self._e)
+
+    # -- scattering tables as the engine holds them ------------------------------
+    def scatterer_stats(self, s):
+        """[mfp_p, mfp_s, dipole_p, dipole_s, total_pp, total_ps, total_sp, total_ss]"""
+        out = (C.c_double * 8)()
+        if self._lib.r3d_engine_scatterer_stats(self._e, s, out):
+            raise IndexError(s)
+        return list(out)
+
+    def download_scatterer(self, s):
+        """(cdf[4, n_toa], spol[n_toa]) copied from HBM."""
+        n = self.model.n_toa
+        cdf = np.zeros((4, n)), np.zeros(n)
+        ptrs = (_ffi._dp * 4)(*[cdf[0][k].ctypes.data_as(_ffi._dp) for k in range(4)])
+        if self._lib.r3d_engine_download_scatterer(self._e, s, ptrs, cdf[1].ctypes.data_as(_ffi._dp)):
+            raise RuntimeError("download failed: " + self._lib.r3d_last_error().decode())
+        return cdf
 
     # -- per-event report stream (the reference's --reports) -------------------
     def set_event_log(self, mask=_ffi.R3D_RPT_ALL, capacity=1 << 20):

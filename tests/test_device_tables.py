@@ -1,0 +1,113 @@
+"""Scattering tables built in HBM (--device-tables; include/r3d.h r3d_scatterer build-on-device
+form, csrc/r3d_tables_build.hip) against the host builder's, and history parity of a run on
+them against the oracle fed the very same (downloaded) tables."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from radiative3d_amd import Model, _ffi
+from tests.configs import CONFIGS
+from tests.conftest import finals_differ
+
+
+def test_device_table_model_carries_parameters_not_tables():
+    host = Model(CONFIGS["crustpinch"](3))
+    dev = Model(CONFIGS["crustpinch"](3) + ["--device-tables"])
+    assert dev.device_tables and not host.device_tables
+    assert dev.n_scatterers == host.n_scatterers == 7
+    for s in range(dev.n_scatterers):
+        d, h = dev.desc.scatterers[s], host.desc.scatterers[s]
+        assert not d.cdf[0] and not d.spol and h.cdf[0] and h.spol
+        info = host.scatterer_info(s)
+        assert list(d.het) == [info[k] for k in ("nu", "eps", "a", "kappa", "el", "gam0")] == list(h.het)
+        assert d.psdf_numer == h.psdf_numer > 0 and d.mfp_fixed == 0
+        assert np.isnan(dev.scatterer_info(s)["mfp_p"])          # unknown until an engine exists
+
+
+class _Patched:
+    """A model description whose scatterers point at tables downloaded from the engine."""
+
+    def __init__(self, model, engine):
+        self._model = model
+        n = model.n_scatterers
+        self._keep = []
+        self._scat = (_ffi.Scatterer * n)()
+        for s in range(n):
+            C.memmove(C.byref(self._scat[s]), C.byref(model.desc.scatterers[s]), C.sizeof(_ffi.Scatterer))
+            cdf, spol = engine.download_scatterer(s)
+            st = engine.scatterer_stats(s)
+            self._keep += [cdf, spol]
+            for k in range(4):
+                self._scat[s].cdf[k] = cdf[k].ctypes.data_as(_ffi._dp)
+            self._scat[s].spol = spol.ctypes.data_as(_ffi._dp)
+            self._scat[s].mfp[0], self._scat[s].mfp[1] = st[0], st[1]
+            tot = st[4:8]
+            for t, w in enumerate(([tot[0], tot[1], 0, 0], [0, 0, tot[2], tot[3]])):
+                acc = 0.0
+                for k in range(4):
+                    acc += w[k]
+                    self._scat[s].whole_cdf[t][k] = acc
+        self._desc = _ffi.ModelDesc()
+        C.memmove(C.byref(self._desc), C.byref(model.desc), C.sizeof(_ffi.ModelDesc))
+        self._desc.scatterers = C.cast(self._scat, C.POINTER(_ffi.Scatterer))
+        self.desc_p = C.pointer(self._desc)
+
+    def new_result(self):
+        return self._model.new_result()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,deg", [("crustpinch", 5), ("lopnor", 4), ("sphere", 4), ("halfspace", 6)])
+def test_device_tables_match_host_and_oracle(name, deg):
+    from oracle import oracle_ffi
+    from radiative3d_amd import Engine
+    host = Model(CONFIGS[name](deg))
+    dev = Model(CONFIGS[name](deg) + ["--device-tables"])
+    e = Engine(dev)
+    n_toa = host.n_toa
+    for s in range(host.n_scatterers):
+        st = e.scatterer_stats(s)
+        info = host.scatterer_info(s)
+        assert st[0] == pytest.approx(info["mfp_p"], rel=1e-11) and st[1] == pytest.approx(info["mfp_s"], rel=1e-11)
+        assert st[2] == pytest.approx(info["dipole_p"], abs=1e-10) and st[3] == pytest.approx(info["dipole_s"], abs=1e-10)
+        assert dev.scatterer_info(s)["mfp_p"] == st[0]            # the model now shows the engine's numbers
+        cdf, spol = e.download_scatterer(s)
+        h = host.desc.scatterers[s]
+        for k in range(4):
+            want = np.ctypeslib.as_array(h.cdf[k], shape=(n_toa,))
+            assert np.all(np.diff(cdf[k]) >= 0)
+            assert np.max(np.abs(cdf[k] - want)) <= 1e-12 * want[-1]
+        want = np.ctypeslib.as_array(h.spol, shape=(n_toa,))
+        assert np.max(np.abs(np.angle(np.exp(1j * (spol - want))))) < 1e-9
+    # a run on the device-built tables == the oracle on those same tables, history for history
+    n = 20000 if name != "sphere" else 4000
+    res_g, fin_g = e.run(n, trace=True)
+    res_o, fin_o = oracle_ffi.run(_Patched(dev, e), n, trace=True)
+    bad = sum(finals_differ(a, b) for a, b in zip(fin_g, fin_o))
+    assert bad <= n * 0.0005
+    if bad == 0:
+        assert np.array_equal(res_g.counts, res_o.counts)
+    assert res_g.events["scatter"] == pytest.approx(res_o.events["scatter"], rel=2e-3)
+    # and statistically the same physics as the host-built model (different rounding in the
+    # tables can move single draws, not the distribution)
+    res_h = Engine(host).run(n)
+    assert res_h.events["scatter"] == pytest.approx(res_g.events["scatter"], rel=0.05, abs=30)
+    assert res_h.n_lost == pytest.approx(res_g.n_lost, rel=0.02, abs=30)
+
+
+@pytest.mark.gpu
+def test_device_tables_build_time_at_degree_9():
+    """The point of the exercise: NSCP TOA degree 9 (5.2 M directions x 7 scatterers)."""
+    import time
+    from radiative3d_amd import Engine
+    t0 = time.perf_counter()
+    dev = Model(CONFIGS["crustpinch"](9) + ["--device-tables"])
+    t1 = time.perf_counter()
+    e = Engine(dev)
+    t2 = time.perf_counter()
+    print(f"\nhost part {t1 - t0:.2f} s, engine create incl. table build {t2 - t1:.2f} s")
+    st = e.scatterer_stats(0)
+    assert 4000 < st[0] < 20000 and (t2 - t1) < 5.0          # SURVEY: NSCP MFP range 4 600 - 18 800 km
+    res = e.run(1_000_000)
+    assert res.events["iterations"] / 1e6 == pytest.approx(27.8, rel=0.02)
