@@ -243,6 +243,17 @@ def main():
                          "events_per_history": {k: round(v, 4) for k, v in ev.items()}},
             "host": {"model_build_s": round(t_build, 2), "table_upload_s": round(t_upload, 2)},
         }
+        # the same model with the scattering tables evaluated in HBM (--device-tables):
+        # what a production run pays before its first history
+        t0 = time.perf_counter()
+        dev_model = Model(crustpinch(args.toa_degree) + ["--device-tables"])
+        t_dev_host = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        dev_engine = Engine(dev_model, device=local_rank)
+        t_dev_engine = time.perf_counter() - t0
+        dev_engine.close()
+        line["host"]["device_tables"] = {"model_build_s": round(t_dev_host, 2),
+                                         "engine_create_s": round(t_dev_engine, 2)}
         if not args.no_cpu_baseline and world == 1:
             note("timing the CPU baseline (oracle) ...")
             line["cpu_baseline"], cpu_parts, per_thread = cpu_baseline(model)
