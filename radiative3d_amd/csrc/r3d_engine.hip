@@ -144,59 +144,90 @@ __device__ __forceinline__ bool bin_cache_add(const BinCache& bc, uint32_t bin, 
   return false;
 }
 
-// Seismometer collection for the arrival held by lane `src`, executed by the
-// whole wave: same tests and same bin updates as collect() in r3d_step.h
-// (reference dataout.cpp:103-216, :545-568), with the candidate receivers
-// [k0, k1) of the arrival's hash cell spread over the 64 lanes.  q_count is the
-// wave-uniform fill of the wave's catch queue.
-template <int KIND>
-__device__ __forceinline__ void collect_wave(const KArgs& a, const Tables<KIND>& T, const Phonon& p,
-                                             double vel_lane, uint32_t k0_lane, uint32_t k1_lane,
-                                             int src_lane, unsigned lane, uint32_t& lane_catches,
-                                             const BinCache& bc, CatchQueue& q, unsigned& q_count) {
-  const int src = __builtin_amdgcn_readfirstlane(src_lane);
-  const V3 loc = bcast(p.loc, src), dir = bcast(p.dir, src);
-  const double t = bcast(p.t, src), amp = bcast(p.amp, src);
-  const double pc = bcast(p.pc, src), ps = bcast(p.ps, src);
-  const double vel = bcast(vel_lane, src);
-  const int type = __builtin_amdgcn_readlane(p.type, src);
-  const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)k0_lane, src);
-  const uint32_t k1 = (uint32_t)__builtin_amdgcn_readlane((int)k1_lane, src);
-  const unsigned long long lane_lt = (1ull << lane) - 1ull;
-  V3 dopm = dir;  // Phonon::DirectionOfMotion of the broadcast phonon
-  if (type != RAY_P) {
-    V3 th, ph;
-    sph_basis(dir, th, ph);
-    dopm = pc * th + ps * ph;
+// Seismometer collection for all of the wave's arrivals at once: same tests and same bin
+// updates as collect() in r3d_step.h (reference dataout.cpp:103-216, :545-568).  Lane l
+// arrives with the candidate receivers [k0, k1) of its hash cell (k0 == k1: none).  The
+// (arrival, candidate) pairs of the whole wave are numbered through a prefix sum of the
+// candidate counts and dealt to the 64 lanes, 64 pairs per pass: a pair's lane finds its
+// arrival by bisection over the prefix sums and fetches the arrival's state from that lane
+// (ds_bpermute).  A typical iteration has 3-4 arrivals with a few candidates each, i.e.
+// one pass, where serving the arrivals one after the other took one pass each.
+// q_count is the wave-uniform fill of the wave's catch queue.
+template <int KIND, bool TRACE>
+__device__ __forceinline__ void collect_pairs(const KArgs& a, const Tables<KIND>& T, const Phonon& p,
+                                              double vel_lane, uint32_t k0, uint32_t k1,
+                                              const uint16_t* lds_items /* or null: a.grid.items */,
+                                              unsigned lane, unsigned long long lane_lt, uint32_t& lane_catches,
+                                              const BinCache& bc, CatchQueue& q, unsigned& q_count) {
+  const uint32_t cnt = k1 - k0;
+  uint32_t incl = cnt;   // inclusive prefix sum over the wave
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = __shfl_up(incl, off);
+    if (lane >= (unsigned)off) incl += y;
   }
-  uint32_t hits = 0;
-  for (uint32_t kb = k0; kb < k1; kb += 64u) {
-    const uint32_t k = kb + lane;
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  const uint32_t excl = incl - cnt;
+  // this lane's arrival record (meaningful where cnt > 0): Phonon::DirectionOfMotion,
+  // squared amplitude, and direction / velocity for the plane-wave arrival correction
+  V3 dopm = p.dir;
+  if (cnt && p.type != RAY_P) {
+    V3 th, ph;
+    sph_basis(p.dir, th, ph);
+    dopm = p.pc * th + p.ps * ph;
+  }
+  const double amp2 = p.amp * p.amp;
+  const double inv_vel = 1.0 / vel_lane;
+  for (uint32_t base = 0; base < total; base += 64u) {
+    const uint32_t j = base + lane;
+    uint32_t src = 0;   // smallest lane whose inclusive sum exceeds j
+#pragma unroll
+    for (uint32_t step = 32u; step; step >>= 1) {
+      const uint32_t v = (uint32_t)__shfl((int)incl, (int)(src + step - 1u));
+      if (v <= j) src += step;
+    }
+    const bool valid = j < total;
+    src = valid ? src : lane;
+    const uint32_t k = (uint32_t)__shfl((int)k0, (int)src) + (j - (uint32_t)__shfl((int)excl, (int)src));
+    const V3 loc = v3(__shfl(p.loc.x, (int)src), __shfl(p.loc.y, (int)src), __shfl(p.loc.z, (int)src));
+    const V3 dir = v3(__shfl(p.dir.x, (int)src), __shfl(p.dir.y, (int)src), __shfl(p.dir.z, (int)src));
+    const V3 dm = v3(__shfl(dopm.x, (int)src), __shfl(dopm.y, (int)src), __shfl(dopm.z, (int)src));
+    const double t = __shfl(p.t, (int)src), a2 = __shfl(amp2, (int)src), iv = __shfl(inv_vel, (int)src);
+    const int type = __shfl(p.type, (int)src);
     bool hit = false;
     uint32_t hit_slot = 0;
     double ex = 0, ey = 0, ez = 0, et = 0;
-    if (k < k1) {
-      const uint32_t s = a.grid.items[k];
+    if (valid) {
+      const uint32_t s = lds_items ? (uint32_t)lds_items[k] : a.grid.items[k];
       const SeisScan& S = T.seis_scan[s];
       const V3 to = v3(S.loc) - loc;
       const double dist = mag(to);
       if (!(dist > S.r_out[type] || dist < S.r_in[type])) {
         double arv = t;
-        if (S.r_in[type] <= 0) arv += dot(to, dir) / vel;
+        if (S.r_in[type] <= 0) arv += dot(to, dir) * iv;
         const double scaled = arv / a.time_per_bin;
         const double fl = floor(scaled);
         if (scaled >= 0.0 && fl < a.n_bins_f) {
           const uint32_t bin = (uint32_t)fl;
           const SeisHit& H = T.seis_hit[s];
-          const double xf = dot(dopm, v3(H.axes[0])), yf = dot(dopm, v3(H.axes[1])), zf = dot(dopm, v3(H.axes[2]));
-          et = (amp * amp) * H.inv_norm[type];
+          const double xf = dot(dm, v3(H.axes[0])), yf = dot(dm, v3(H.axes[1])), zf = dot(dm, v3(H.axes[2]));
+          et = a2 * H.inv_norm[type];
           ex = et * (xf * xf), ey = et * (yf * yf), ez = et * (zf * zf);
           hit_slot = ((s * a.n_bins + bin) << 1) | (uint32_t)type;
           hit = true;
         }
       }
     }
-    hits += (uint32_t)__popcll(__ballot(hit));
+    unsigned long long hm = __ballot(hit);
+    if (!hm) continue;
+    if (TRACE) {   // per-history catch counts for the final records
+      for (unsigned long long r = hm; r; r &= r - 1ull) {
+        const int b = __ffsll((long long)r) - 1;
+        if ((int)lane == __builtin_amdgcn_readlane((int)src, b)) lane_catches++;
+      }
+    } else if (lane == 0) {
+      lane_catches += (uint32_t)__popcll(hm);   // (only the wave's total is tallied)
+    }
     if (bc.on && hit && bin_cache_add(bc, hit_slot >> 1, (uint32_t)type, ex, ey, ez, et)) hit = false;
     const unsigned long long m = __ballot(hit);   // catches the accumulators did not take
     if (m) {
@@ -231,7 +262,6 @@ __device__ __forceinline__ void collect_wave(const KArgs& a, const Tables<KIND>&
       }
     }
   }
-  if ((int)lane == src) lane_catches += hits;
 }
 
 // --------------------------------------------------------------- the kernel --
@@ -252,6 +282,12 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
     copy_words(smem + a.lds_seis_off, a.seis_scan, (size_t)a.n_seis * sizeof(SeisScan));
     if (a.lds_hit_off != 0xFFFFFFFFu)
       copy_words(smem + a.lds_hit_off, a.seis_hit, (size_t)a.n_seis * sizeof(SeisHit));
+    if (a.lds_grid_off != 0xFFFFFFFFu) {   // seismometer hash: offsets as they are, items as u16
+      uint32_t* gs = reinterpret_cast<uint32_t*>(smem + a.lds_grid_off);
+      for (uint32_t i = threadIdx.x; i <= (uint32_t)a.grid.n_cells; i += kBlock) gs[i] = a.grid.start[i];
+      uint16_t* gi = reinterpret_cast<uint16_t*>(gs + a.grid.n_cells + 1);
+      for (uint32_t i = threadIdx.x; i < a.grid_n_items; i += kBlock) gi[i] = (uint16_t)a.grid.items[i];
+    }
     if (a.acc_bits) {   // energies and counts zero, keys empty
       const size_t n = (size_t)1 << a.acc_bits;
       unsigned long long* z = reinterpret_cast<unsigned long long*>(smem + a.lds_acc_off);
@@ -261,6 +297,9 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
     }
     __syncthreads();
   }
+  const bool grid_in_lds = a.lds_grid_off != 0xFFFFFFFFu;   // wave-uniform
+  const uint32_t* lds_gstart = reinterpret_cast<const uint32_t*>(smem + (grid_in_lds ? a.lds_grid_off : 0u));
+  const uint16_t* lds_gitems = reinterpret_cast<const uint16_t*>(lds_gstart + a.grid.n_cells + 1);
   BinCache bc;
   bc.on = a.acc_bits != 0;
   bc.e = reinterpret_cast<double*>(smem + a.lds_acc_off);
@@ -397,18 +436,16 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
       const double fz = (p.loc.z - g.origin[2]) * g.inv_h;
       if (fx >= 0 && fy >= 0 && fz >= 0 && fx < g.dim_f[0] && fy < g.dim_f[1] && fz < g.dim_f[2]) {
         const int cellid = ((int)fz * g.dim[1] + (int)fy) * g.dim[0] + (int)fx;
-        k0 = g.start[cellid], k1 = g.start[cellid + 1];
+        if (grid_in_lds) k0 = lds_gstart[cellid], k1 = lds_gstart[cellid + 1];
+        else k0 = g.start[cellid], k1 = g.start[cellid + 1];
       }
     }
-    unsigned long long arrivals = __ballot(k1 > k0);
 #ifdef R3D_ABLATE_COLLECT  // timing-only developer build
-    arrivals = 0ull;
+    k1 = k0;
 #endif
-    while (arrivals) {
-      const int src = __ffsll((long long)arrivals) - 1;
-      arrivals &= arrivals - 1ull;
-      collect_wave<KIND>(a, T, p, ev.vel, k0, k1, src, lane, st.n_catch, bc, queue, q_count);
-    }
+    if (__any(k1 > k0))
+      collect_pairs<KIND, TRACE>(a, T, p, ev.vel, k0, k1, grid_in_lds ? lds_gitems : nullptr, lane, lane_lt,
+                                 st.n_catch, bc, queue, q_count);
 
     R3D_STAMP(2);  // collect
 
@@ -811,6 +848,16 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   const size_t hit_bytes = (size_t)std::max(1, m->n_seismometers) * sizeof(SeisHit);
   a.lds_hit_off = 0xFFFFFFFFu;
   if (off + hit_bytes + kStaticLds <= 160 * 1024) a.lds_hit_off = (uint32_t)off, off = align16(off + hit_bytes);
+  // the seismometer hash, when it is small (it is for the reference's survey lines and arrays:
+  // a few thousand cells): both levels of the lookup become LDS reads instead of two
+  // dependent global loads in every collecting iteration
+  a.lds_grid_off = 0xFFFFFFFFu, a.grid_n_items = (uint32_t)pm.grid_items.size();
+  {
+    const size_t grid_bytes = ((size_t)a.grid.n_cells + 1) * sizeof(uint32_t) + pm.grid_items.size() * sizeof(uint16_t);
+    if (m->n_seismometers > 0 && m->n_seismometers <= 65535 && grid_bytes <= 40 * 1024 &&
+        off + grid_bytes + kStaticLds + 8192 <= 160 * 1024)
+      a.lds_grid_off = (uint32_t)off, off = align16(off + grid_bytes);
+  }
   // what is left (minus a little slack) goes to the bin accumulators
   a.lds_acc_off = (uint32_t)off, a.acc_bits = 0;
   if (m->n_seismometers > 0) {

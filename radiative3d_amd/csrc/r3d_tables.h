@@ -161,6 +161,8 @@ struct KArgs {
   uint32_t lds_scat_off;
   uint32_t lds_seis_off;
   uint32_t lds_hit_off;
+  uint32_t lds_grid_off;     // seismometer hash (start u32[n_cells+1], items u16[n_items]); 0xFFFFFFFF: in HBM
+  uint32_t grid_n_items;
   uint32_t lds_acc_off;      // bin accumulators (see BinCache in r3d_engine.hip)
   uint32_t acc_bits;         // 2^acc_bits accumulator entries; 0: none
 };
