@@ -267,8 +267,12 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
       const ScatHead& sh = T.scat_head[c.scat];
       const ScatPtrs* sp = a.scat_ptrs + c.scat;   // (indexed in place: a local copy would go to scratch)
       int conv = sample_small(sh.whole[p.type], 4, rng_draw(rng, rng_key(a.seed)));  // GPP GPS GSP GSS
+#ifdef R3D_ABLATE_SCATTER   // timing-only developer build: no table search
+      uint64_t k = (uint64_t)(rng_draw(rng, rng_key(a.seed)) * (double)(a.n_toa - 1));
+#else
       uint64_t k = sample_cdf_guided(sp->cdf[conv], sp->guide[conv], a.guide_bits, sh.total[conv],
                                      rng_draw(rng, rng_key(a.seed)));
+#endif
       double rc = 1.0, rs = 0.0;      // relative polarisation 0 except S->S (scatterers.cpp:341-356)
       if (conv == 3) sincos(sp->spol[k], &rs, &rc);
       scatter_transform(p, v3(a.toa_xyz + 3 * k), rc, rs, (conv & 1) ? RAY_S : RAY_P);
