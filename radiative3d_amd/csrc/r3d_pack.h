@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -124,7 +125,10 @@ inline void build_guide(const double* cdf, uint64_t n, uint32_t bits, std::vecto
 }
 inline uint32_t guide_bits_for(uint64_t n_toa) {
   uint32_t bits = 4;
-  while (bits < 16 && (1ull << (bits + 5)) < n_toa) bits++;   // ~32 entries per bracket, at most 2^16
+  int per = 2, cap = 20;   // ~2^per entries per bracket, at most 2^cap guide entries
+  if (const char* e = getenv("R3D_GUIDE_PER")) per = atoi(e);   // developer tuning
+  if (const char* e = getenv("R3D_GUIDE_CAP")) cap = atoi(e);
+  while ((int)bits < cap && (1ull << (bits + per)) < n_toa) bits++;
   return bits;
 }
 
