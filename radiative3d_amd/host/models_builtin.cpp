@@ -9,9 +9,14 @@
 // node values as the reference's functions:
 //
 //   40      halfspace, two layers          (user_Halfspace_inc.cpp:28-183)
-//   1..4    Lop Nor layered crust+mantle   (user_LopNorCyl_inc.cpp:30-400)
+//   1..4    Lop Nor layered crust+mantle   (user_LopNorCyl_inc.cpp:30-400); with 20 or more
+//           arguments the variant with a Moho transition zone (user_LopNorCylMoho_inc.cpp)
+//   21      Lop Nor, Moho transition, the more gradual velocity profile
+//           (user_LopNorCylMoho2_inc.cpp; do-lopnor-vids.sh)
 //   5..7    North Sea crust pinch, tetra   (user_NSCP_inc.cpp:13-206)
 //   16      whole-Earth spherical shells   (user_SphereEarth_inc.cpp:13-86)
+//   30      two-shell toy sphere           (user_ToySphere_inc.cpp; do-toysphere-vids.sh)
+// Not built in (no run script uses them): 8 crust upthrust, 128 scattering-parameter study.
 //
 // Where the reference prints to stderr and calls exit(1) on a bad argument
 // count, these throw Runtime.
@@ -147,6 +152,105 @@ void build_lopnor(Grid& g, const std::vector<Real>& a) {
                                      grp[r.region]->hs());
 }
 
+// ------------------------------------------- 1..4 with >= 20 args, 21 -----
+// Lop Nor with a Moho transition: 12 tilted sheets (sediments, crust, four "Moho
+// complexity" steps, a four-step mantle ramp) over 17 level mantle sheets.  `gradual`
+// selects the alternative velocity profile of model 21.
+void build_lopnor_moho(Grid& g, const std::vector<Real>& a, bool gradual) {
+  Neakq crust{0.8, 0.05, 0.50, 0.5, kInf};
+  Neakq sedi{0.8, 0.06, 0.25, 0.5, kInf}, mant{0.8, 0.04, 1.0, 0.5, kInf}, moho = crust;
+  Neakq* grp[4] = {&sedi, &crust, &mant, &moho};   // argument order
+  size_t per = 0, groups = 3;  // values per group: nu,eps,a[,k[,Q]]
+  switch (a.size()) {
+    case 0: break;
+    case 9: per = 3; break;
+    case 12: per = 4; break;
+    case 15: per = 5; break;
+    case 20: per = 5, groups = 4; break;
+    default: bad_arg_count();
+  }
+  for (size_t r = 0; r < groups && per; r++) {
+    const Real* v = &a[r * per];
+    grp[r]->nu = v[0], grp[r]->eps = v[1], grp[r]->a = v[2];
+    if (per > 3) grp[r]->k = v[3];
+    if (per > 4) grp[r]->q = v[4];
+  }
+
+  g.SetSize(3, 1, 29);
+  g.SetIndexBase(0);
+  const Real xy[3][2] = {{492.31, -263.65}, {-102.27, 430.84}, {-390.04, -167.18}};
+  // the three sites' depths of the first three sheets; sheets 3..11 step down in 2 km
+  // increments below each site's Moho depth
+  const Real top_z[3][3] = {{1.050, 0.600, 1.457}, {0.563, 0.118, 0.963}, {-18.901, -16.743, -18.812}};
+  const Real mantle_z[17] = {-80.0,  -120.0, -165.0, -210.0, -260.0, -310.0,
+                             -360.0, -410.0, -460.0, -510.0, -560.0, -610.0,
+                             -660.0, -710.0, -760.0, -809.5, -859.0};
+  for (Index k = 0; k < 3; k++) place_sheet(g, k, xy, top_z[k]);
+  for (Index k = 3; k < 12; k++) {
+    static const Real lop[9] = {-38.365, -40.365, -42.365, -44.365, -46.365, -48.365, -50.365, -52.365, -54.365};
+    static const Real mak[9] = {-33.122, -35.122, -37.122, -39.122, -41.122, -43.122, -45.122, -47.122, -49.122};
+    static const Real wus[9] = {-38.587, -40.587, -42.587, -44.587, -46.587, -48.587, -50.587, -52.587, -54.587};
+    const Real z[3] = {lop[k - 3], mak[k - 3], wus[k - 3]};
+    place_sheet(g, k, xy, z);
+  }
+  for (Index k = 0; k < 17; k++) {
+    const Real z[3] = {mantle_z[k], mantle_z[k], mantle_z[k]};
+    place_sheet(g, k + 12, xy, z);
+  }
+
+  // {sheet, region (0 sedi, 1 crust, 2 mantle, 3 Moho zone), Vp, Vs, rho}; a sheet listed
+  // twice is a first-order discontinuity (above, then below).
+  struct Row { Index k; int region; Real vp, vs, rho; };
+  static const Row head[] = {{0, 0, 2.50, 1.20, 2.10}, {1, 0, 2.50, 1.20, 2.10},
+                             {1, 1, 6.13, 3.53, 2.75}, {2, 1, 6.40, 3.63, 2.83}};
+  // the transition zone, sheets 3..11, in the two profiles
+  static const Row steep[] = {
+      {3, 1, 6.80, 3.83, 3.10},    {3, 3, 7.22, 4.01, 3.15},    {4, 3, 7.22, 4.01, 3.15},
+      {4, 3, 7.13, 3.96, 3.13},    {5, 3, 7.13, 3.96, 3.13},    {5, 3, 7.43, 4.11, 3.22},
+      {6, 3, 7.43, 4.11, 3.22},    {6, 3, 7.28, 4.00, 3.15},    {7, 3, 7.28, 4.00, 3.22},
+      {7, 3, 8.000, 4.460, 3.502}, {8, 3, 8.000, 4.460, 3.502}, {8, 3, 8.010, 4.465, 3.502},
+      {9, 3, 8.010, 4.465, 3.502}, {9, 3, 8.020, 4.470, 3.502}, {10, 3, 8.020, 4.470, 3.502},
+      {10, 3, 8.030, 4.475, 3.502}, {11, 3, 8.030, 4.475, 3.502}};
+  static const Row soft[] = {
+      {3, 1, 6.40, 3.63, 3.10},    {3, 3, 7.081, 3.885, 3.15},  {4, 3, 7.081, 3.885, 3.15},
+      {4, 3, 6.991, 3.835, 3.13},  {5, 3, 6.991, 3.835, 3.13},  {5, 3, 7.291, 3.985, 3.22},
+      {6, 3, 7.291, 3.985, 3.22},  {6, 3, 7.141, 3.875, 3.15},  {7, 3, 7.141, 3.875, 3.22},
+      {7, 3, 7.624, 4.183, 3.502}, {8, 3, 7.624, 4.183, 3.502}, {8, 3, 7.728, 4.257, 3.502},
+      {9, 3, 7.728, 4.257, 3.502}, {9, 3, 7.832, 4.331, 3.502}, {10, 3, 7.832, 4.331, 3.502},
+      {10, 3, 7.936, 4.406, 3.502}, {11, 3, 7.936, 4.406, 3.502}};
+  static const Row tail[] = {
+      {11, 2, 8.040, 4.480, 3.502},   {12, 2, 8.040, 4.480, 3.502},   {12, 2, 8.045, 4.490, 3.502},
+      {13, 2, 8.0505, 4.5000, 3.4268}, {14, 2, 8.1750, 4.5090, 3.3711}, {15, 2, 8.3007, 4.5184, 3.3243},
+      {16, 2, 8.4822, 4.6094, 3.3663}, {17, 2, 8.6650, 4.6964, 3.4110}, {18, 2, 8.8476, 4.7832, 3.4577},
+      {19, 2, 9.0302, 4.8702, 3.5068}, {19, 2, 9.3601, 5.0806, 3.9317}, {20, 2, 9.5280, 5.1864, 3.9273},
+      {21, 2, 9.6962, 5.2922, 3.9233}, {22, 2, 9.8640, 5.3989, 3.9218}, {23, 2, 10.0320, 5.5047, 3.9206},
+      {24, 2, 10.2000, 5.6104, 3.9201}, {24, 2, 10.7909, 5.9607, 4.2387}, {25, 2, 10.9222, 6.0898, 4.2986},
+      {26, 2, 11.0553, 6.2100, 4.3565}, {27, 2, 11.1355, 6.2424, 4.4118}, {28, 2, 11.2228, 6.2799, 4.4650}};
+  auto put = [&](const Row& r) {
+    g.WNode(0, 0, r.k).SetAttributes(VpVs(r.vp, r.vs), r.rho, grp[r.region]->qq(), grp[r.region]->hs());
+  };
+  for (const Row& r : head) put(r);
+  if (gradual) for (const Row& r : soft) put(r);
+  else for (const Row& r : steep) put(r);
+  for (const Row& r : tail) put(r);
+}
+
+// ---------------------------------------------------------------- 30 ------
+// Toy sphere: a "mantle" shell over a "core" ball, fixed scattering parameters.
+void build_toy_sphere(Grid& g, const std::vector<Real>&) {
+  const HetSpec hs = HSneak(0.8, 0.01, 4.00, 0.8);
+  const Q q = QmQk(1000);
+  g.SetSize(1, 1, 3);
+  g.SetIndexBase(0);
+  g.SetMapping(Grid::GC_RAE, Grid::GC_SPHERICAL);
+  const Real depth[3] = {0, -4000.0, -6371.0};
+  for (Index k = 0; k < 3; k++) g.WNode(0, 0, k).SetLocation(0, 0, depth[k]);
+  struct Row { Index k; Real vp, vs, rho; };
+  static const Row rows[] = {{0, 5.00, 2.60, 3.60}, {1, 9.00, 6.00, 4.00},
+                             {1, 10.00, 8.00, 4.20}, {2, 14.00, 12.00, 4.90}};
+  for (const Row& r : rows) g.WNode(0, 0, r.k).SetAttributes(VpVs(r.vp, r.vs), r.rho, q, hs);
+}
+
 // --------------------------------------------------------------- 5..7 -----
 void build_crustpinch(Grid& g, const std::vector<Real>& a) {
   // Layer groups: sediments, crust, pinched crust, Moho transition, mantle.
@@ -269,11 +373,21 @@ __attribute__((weak)) void Grid::ConstructGridManual(int Selection,
   }
   switch (Selection) {
     case 1: case 2: case 3: case 4:
-      if (args.size() >= 20)
-        throw Runtime("Lop Nor Moho variant is not among the built-in models; "
-                      "link the user model file that defines it.");
-      std::cout << head << "Selected Lop Nor Baseline Model (Layered).\n";
-      build_lopnor(*this, args);
+      if (args.size() >= 20) {
+        std::cout << head << "Selected Lop Nor Moho Model (Layered).\n";
+        build_lopnor_moho(*this, args, false);
+      } else {
+        std::cout << head << "Selected Lop Nor Baseline Model (Layered).\n";
+        build_lopnor(*this, args);
+      }
+      break;
+    case 21:
+      std::cout << head << "Selected Lop Nor Moho Model Alt2 (Layered).\n";
+      build_lopnor_moho(*this, args, true);
+      break;
+    case 30:
+      std::cout << head << "Selected Spherical Toy Model (Spherical).\n";
+      build_toy_sphere(*this, args);
       break;
     case 5: case 6: case 7:
       std::cout << head << "Selected North Sea Crust Pinch Model (Tetra WCG).\n";

@@ -45,4 +45,25 @@ def sphere(deg=9, source_depth=-10):
             "--seis-p2p=0,90,0,12000,90,0,20.0,20.0,400.0,160").split()
 
 
-CONFIGS = {"halfspace": halfspace, "crustpinch": crustpinch, "lopnor": lopnor, "sphere": sphere}
+def toysphere_vids(deg=4):
+    """do-toysphere-vids.sh:21-60: model 30, pinned mean free paths, scattering without
+    deflection, raw output coordinates (a ray-path video run)."""
+    return ("--grid-compiled=30 --model-args=0.8,0.01,0.5,0.2,50,0.8,0.01,0.5,0.3,1000,0.8,0.01,0.7,0.5,300 "
+            "--source=SDR,22.5,90,0 --source-loc=0,0,-10 --frequency=2.0 --timetolive=6000 "
+            f"--binsize=60.0 --toa-degree={deg} --overridemfp=50,40 --nodeflect --ocsraw "
+            "--seis-p2p=0,0,0,1000,0,0,1.0,2.0,40.0,16 --seis-p2p=0,90,0,1000,90,0,1.0,2.0,40.0,16").split()
+
+
+def lopnor_vids(deg=4):
+    """do-lopnor-vids.sh:21-100 with event=eq: model 21 (Moho transition, gradual profile),
+    Earth-flattened, four scattering regions, pinned mean free paths, no deflection."""
+    return ("--grid-compiled=21 --flatten --range=1200 "
+            "--model-args=0.8,0.01,0.5,0.2,50,0.8,0.01,0.5,0.3,1000,0.8,0.01,0.7,0.5,300,0.8,0.02,0.5,0.5,2000 "
+            "--source=SDR,125,40,90,0.0 --source-loc=425.54,-169.53,-31.02 --frequency=2.0 --timetolive=350 "
+            f"--binsize=10.0 --toa-degree={deg} --overridemfp=1,1 --nodeflect "
+            "--seis-p2p=425.54,-169.53,0.98,-390.04,-167.18,1.457,1.0,2.0,40.0,16 "
+            "--seis-p2p=425.54,-169.53,0.98,-102.27,430.84,0.60,1.0,2.0,40.0,16").split()
+
+
+CONFIGS = {"halfspace": halfspace, "crustpinch": crustpinch, "lopnor": lopnor, "sphere": sphere,
+           "toysphere_vids": toysphere_vids, "lopnor_vids": lopnor_vids}

@@ -45,7 +45,7 @@ def check_against_oracle(engine, n, first_id=0, seed=0x5EED, allow_frac=0.0005):
 
 
 @pytest.mark.parametrize("name,n", [("halfspace", 50000), ("crustpinch", 20000), ("lopnor", 20000),
-                                    ("sphere", 3000)])
+                                    ("sphere", 3000), ("toysphere_vids", 2000), ("lopnor_vids", 2000)])
 def test_engine_matches_oracle_history_by_history(engines, name, n):
     check_against_oracle(engines(name), n)
 

@@ -50,11 +50,23 @@ def build(lib, args):
     return h
 
 
-@pytest.mark.parametrize("name", ["halfspace", "crustpinch", "lopnor", "sphere"])
+MOHO20 = ("0.8,0.06,0.25,0.5,250,0.8,0.05,0.5,0.5,1000,0.8,0.04,1.0,0.5,2000,"
+          "0.7,0.03,0.4,0.3,1500")
+EXTRA = {
+    "lopnor-moho": ["--grid-compiled=1", "--model-args=" + MOHO20, "--toa-degree=2", "--range=1200", "--flatten"],
+    "lopnor-moho-alt2": ["--grid-compiled=21", "--model-args=" + MOHO20, "--toa-degree=2", "--range=1200"],
+    "lopnor-moho-alt2-defaults": ["--grid-compiled=21", "--toa-degree=2", "--range=1200"],
+    "lopnor-moho-alt2-15": ["--grid-compiled=21", "--toa-degree=2", "--range=1200",
+                            "--model-args=" + ",".join(MOHO20.split(",")[:15])],
+    "toysphere": ["--grid-compiled=30", "--toa-degree=2", "--source-loc=0,0,-500"],
+}
+
+
+@pytest.mark.parametrize("name", ["halfspace", "crustpinch", "lopnor", "sphere"] + sorted(EXTRA))
 def test_builtin_models_equal_the_users_definitions(user_lib, name):
     """Same do-script arguments through the reference's user_*_inc.cpp and through
     the built-in table-driven definitions: identical grids and identical cell tables."""
-    args = CONFIGS[name](2)
+    args = EXTRA[name] if name in EXTRA else CONFIGS[name](2)
     builtin = _ffi.host_lib()
     hu, hb = build(user_lib, args), build(builtin, args)
     assert user_lib.r3dh_grid_dump(hu) == builtin.r3dh_grid_dump(hb)
