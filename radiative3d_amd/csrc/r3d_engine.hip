@@ -72,6 +72,10 @@ __device__ unsigned long long g_phase_cycles[8];
 #endif
 
 // ---------------------------------------------------- wave-level helpers ----
+// number of set bits of m below this lane
+__device__ __forceinline__ unsigned rank_in(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
 __device__ __forceinline__ double bcast(double v, int src) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
@@ -157,7 +161,7 @@ template <int KIND, bool TRACE>
 __device__ __forceinline__ void collect_pairs(const KArgs& a, const Tables<KIND>& T, const Phonon& p,
                                               double vel_lane, uint32_t k0, uint32_t k1,
                                               const uint16_t* lds_items /* or null: a.grid.items */,
-                                              unsigned lane, unsigned long long lane_lt, uint32_t& lane_catches,
+                                              unsigned lane, uint32_t& lane_catches,
                                               const BinCache& bc, CatchQueue& q, unsigned& q_count) {
   const uint32_t cnt = k1 - k0;
   uint32_t incl = cnt;   // inclusive prefix sum over the wave
@@ -232,7 +236,7 @@ __device__ __forceinline__ void collect_pairs(const KArgs& a, const Tables<KIND>
     const unsigned long long m = __ballot(hit);   // catches the accumulators did not take
     if (m) {
       if (hit) {
-        const unsigned at = q_count + (unsigned)__popcll(m & lane_lt);
+        const unsigned at = q_count + rank_in(m);
         q.slot[at] = hit_slot;
         q.e[0][at] = ex, q.e[1][at] = ey, q.e[2][at] = ez, q.e[3][at] = et;
       }
@@ -307,7 +311,6 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
   bc.cnt = bc.key + ((size_t)1 << a.acc_bits);
   bc.mask = (1u << a.acc_bits) - 1u, bc.shift = 32u - a.acc_bits;
   const unsigned lane = threadIdx.x & 63u;
-  const unsigned long long lane_lt = (1ull << lane) - 1ull;
   Tables<KIND> T;
   T.cells = LDS_CELLS ? reinterpret_cast<const Cell*>(smem + a.lds_cells_off)
                       : reinterpret_cast<const Cell*>(a.cells);
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
     unsigned long long base = 0;
     if ((int)lane == first) base = atomicAdd(a.evlog_count, (unsigned long long)__popcll(m));
     base = __shfl(base, first);
-    const unsigned long long at = base + (unsigned long long)__popcll(m & lane_lt);
+    const unsigned long long at = base + (unsigned long long)rank_in(m);
     if (cond && at < a.evlog_cap) {
       r3d_event* r = reinterpret_cast<r3d_event*>(a.evlog) + at;
       r->id = my_id;
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
       const unsigned want = (unsigned)__popcll(need);
       const unsigned long long avail = w_end - w_next;
       const unsigned take = (avail < want) ? (unsigned)avail : want;
-      const unsigned rank = (unsigned)__popcll(need & lane_lt);
+      const unsigned rank = rank_in(need);
       const bool fresh = !alive && rank < take;
       if (fresh) {
         my_id = a.first_id + w_next + rank;
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
     k1 = k0;
 #endif
     if (__any(k1 > k0))
-      collect_pairs<KIND, TRACE>(a, T, p, ev.vel, k0, k1, grid_in_lds ? lds_gitems : nullptr, lane, lane_lt,
+      collect_pairs<KIND, TRACE>(a, T, p, ev.vel, k0, k1, grid_in_lds ? lds_gitems : nullptr, lane,
                                  st.n_catch, bc, queue, q_count);
 
     R3D_STAMP(2);  // collect

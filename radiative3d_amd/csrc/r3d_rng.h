@@ -24,8 +24,10 @@ namespace r3d {
 struct Rng {
   uint32_t id_lo, id_hi;   // history id = Philox counter words 0,1
   uint32_t k;              // next draw index
-  uint32_t w2, w3;         // second half of the current Philox block
 };
+// (The second half of a block is not cached between draws: lanes of a wave sit at
+//  different parities of k, so a draw site runs the ten rounds for the wave whether or not
+//  this lane would have had its words at hand -- and the cache cost two registers.)
 struct RngKey {            // the run's seed: the same for every history, so not kept per lane
   uint32_t k0, k1;
 };
@@ -64,21 +66,14 @@ R3D_HD double u01_from_words(uint32_t hi, uint32_t lo) {
 R3D_HD void rng_init(Rng& g, uint64_t id) {
   g.id_lo = (uint32_t)id, g.id_hi = (uint32_t)(id >> 32);
   g.k = 0;
-  g.w2 = g.w3 = 0;
 }
 
 R3D_HD double rng_draw(Rng& g, RngKey key) {
-  double u;
-  if ((g.k & 1u) == 0) {
-    uint32_t w[4];
-    philox4x32_10(g.id_lo, g.id_hi, g.k >> 1, 0u, key.k0, key.k1, w);
-    g.w2 = w[2], g.w3 = w[3];
-    u = u01_from_words(w[0], w[1]);
-  } else {
-    u = u01_from_words(g.w2, g.w3);
-  }
+  uint32_t w[4];
+  philox4x32_10(g.id_lo, g.id_hi, g.k >> 1, 0u, key.k0, key.k1, w);
+  const bool second = (g.k & 1u) != 0;
   g.k++;
-  return u;
+  return u01_from_words(second ? w[2] : w[0], second ? w[3] : w[1]);
 }
 
 }  // namespace r3d
