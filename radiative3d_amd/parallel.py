@@ -40,21 +40,26 @@ class DeviceResult:
         n = model.n_seismometers * model.n_bins
         self.model = model
         self.energy = torch.zeros(max(1, n) * _ffi.R3D_N_ENERGY, dtype=torch.float64, device=device)
-        self.counts = torch.zeros(max(1, n) * _ffi.R3D_N_COUNT, dtype=torch.int64, device=device)
-        self.scalars = torch.zeros(_ffi.R3D_N_SCALARS, dtype=torch.int64, device=device)
+        # the integer outputs share one buffer, so the reduction is two collectives, not three
+        n_counts = max(1, n) * _ffi.R3D_N_COUNT
+        self._ints = torch.zeros(n_counts + _ffi.R3D_N_SCALARS, dtype=torch.int64, device=device)
+        self.counts = self._ints[:n_counts]
+        self.scalars = self._ints[n_counts:]
 
     def zero_(self):
-        self.energy.zero_(), self.counts.zero_(), self.scalars.zero_()
+        self.energy.zero_(), self._ints.zero_()
 
     def add_(self, other):
-        self.energy.add_(other.energy), self.counts.add_(other.counts), self.scalars.add_(other.scalars)
+        self.energy.add_(other.energy), self._ints.add_(other._ints)
         return self
 
     def pointers(self):
         return self.energy.data_ptr(), self.counts.data_ptr(), self.scalars.data_ptr()
 
     def allreduce_(self):
-        allreduce_result_(self.energy, self.counts, self.scalars)
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(self.energy, op=dist.ReduceOp.SUM)
+            dist.all_reduce(self._ints, op=dist.ReduceOp.SUM)
         return self
 
     def to_result(self):

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 import emul_ffi as E
 from radiative3d_amd import Model, _ffi
-from radiative3d_amd.parallel import allreduce_result_, shard_range
+from radiative3d_amd.parallel import DeviceResult, allreduce_result_, shard_range
 from tests.configs import lopnor
 
 
@@ -32,8 +32,16 @@ def _worker(rank, world, port, n, out_path):
     counts = torch.from_numpy(res.counts.astype(np.int64).reshape(-1))
     scalars = torch.from_numpy(res.scalars().astype(np.int64))
     dist.barrier()
+    # bench.py's object: result block in (here: host) tensors, per-step buffer reduced and added
+    total, step = DeviceResult(model, "cpu"), DeviceResult(model, "cpu")
+    step.energy.copy_(energy), step.counts.copy_(counts), step.scalars.copy_(scalars)
+    total.add_(step.allreduce_())
     allreduce_result_(energy, counts, scalars)
+    assert torch.equal(total.counts, counts) and torch.equal(total.scalars, scalars)
+    assert torch.allclose(total.energy, energy, rtol=1e-14, atol=0)
     if rank == 0:
+        back = total.to_result()
+        assert back.n_lost + back.n_timeout + back.n_invalid == n
         np.savez(out_path, energy=energy.numpy(), counts=counts.numpy(), scalars=scalars.numpy())
     dist.destroy_process_group()
 
