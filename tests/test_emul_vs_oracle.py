@@ -75,3 +75,11 @@ def test_strong_contrast_interface_and_liquid_layer(models):
     ro, _ = compare(m, 5000)
     assert ro.events["rtsolve"] > ro.events["collect"]
     compare(models("sphere", 4, ["--source-loc=0,0,-3000"]), 150)
+
+
+def test_deep_source_in_the_spherical_earth():
+    """BASELINE config 4: do-spherical.sh with the source 600 km deep."""
+    from radiative3d_amd import Model
+    from tests.configs import sphere
+    ro, re = compare(Model(sphere(4, source_depth=-600)), 300)
+    assert ro.n_timeout == 300
