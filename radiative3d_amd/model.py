@@ -263,11 +263,11 @@ class Engine:
     def download_scatterer(self, s):
         """(cdf[4, n_toa], spol[n_toa]) copied from HBM."""
         n = self.model.n_toa
-        cdf = np.zeros((4, n)), np.zeros(n)
-        ptrs = (_ffi._dp * 4)(*[cdf[0][k].ctypes.data_as(_ffi._dp) for k in range(4)])
-        if self._lib.r3d_engine_download_scatterer(self._e, s, ptrs, cdf[1].ctypes.data_as(_ffi._dp)):
+        cdf, spol = np.zeros((4, n)), np.zeros(n)
+        ptrs = (_ffi._dp * 4)(*[cdf[k].ctypes.data_as(_ffi._dp) for k in range(4)])
+        if self._lib.r3d_engine_download_scatterer(self._e, s, ptrs, spol.ctypes.data_as(_ffi._dp)):
             raise RuntimeError("download failed: " + self._lib.r3d_last_error().decode())
-        return cdf
+        return cdf, spol
 
     # -- per-event report stream (the reference's --reports) -------------------
     def set_event_log(self, mask=_ffi.R3D_RPT_ALL, capacity=1 << 20):
