@@ -49,7 +49,7 @@ $(LIBDIR)/libr3d_host.so: $(HOST_SRC) $(HOST_HDR)
 
 $(LIBDIR)/libr3d_hip.so: $(ENGINE_SRC) $(ENGINE_HDR)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(ENGINE_SRC)
+	$(HIPCC) $(HIPFLAGS) -shared -pthread -o $@ $(ENGINE_SRC)
 
 oracle/libr3d_oracle.so: oracle/r3d_oracle.cpp oracle/philox.h include/r3d.h
 	$(CXX) $(CXXFLAGS) -shared -o $@ oracle/r3d_oracle.cpp

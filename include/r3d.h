@@ -242,6 +242,14 @@ int r3d_run_device(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,
                    double* d_energy, uint64_t* d_counts, uint64_t* d_scalars,
                    r3d_final* d_finals, void* stream);
 
+/* The seam in one call: engines on devices 0 .. n_gpus-1, the id
+ * range [first_id, first_id + n) cut into n_gpus contiguous shards run concurrently
+ * (one host thread per device), and the shards' results ADDED into *out on the
+ * host.  Equals r3d_run on one engine for the same ids (integers exactly, energies
+ * to summation order).  Returns 0 on success.                                 */
+int r3d_run_model(const r3d_model_desc* model, uint64_t n, uint64_t first_id, uint64_t seed,
+                  int n_gpus, r3d_result* out);
+
 /* Like r3d_run, additionally returning the per-history final records
  * (finals[i] for id first_id + i; caller-allocated, n entries).            */
 int r3d_run_traced(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,

@@ -28,6 +28,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/r3d.h"
@@ -1024,6 +1025,49 @@ static int run_host(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,
 
 int r3d_run(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, r3d_result* out) {
   return run_host(e, n, first_id, seed, out, nullptr);
+}
+
+int r3d_run_model(const r3d_model_desc* model, uint64_t n, uint64_t first_id, uint64_t seed, int n_gpus,
+                  r3d_result* out) {
+  if (!model || !out || !out->energy || !out->counts) return g_error = "null argument", 1;
+  if (n_gpus < 1) return g_error = "n_gpus must be at least 1 (the engine has no CPU path)", 1;
+  const size_t ne = (size_t)model->n_seismometers * model->params.n_bins * R3D_N_ENERGY;
+  const size_t nc = (size_t)model->n_seismometers * model->params.n_bins * R3D_N_COUNT;
+  struct Shard {
+    std::vector<double> energy;
+    std::vector<uint64_t> counts;
+    r3d_result res{};
+    std::string error;
+  };
+  std::vector<Shard> shards(n_gpus);
+  std::vector<std::thread> pool;
+  for (int g = 0; g < n_gpus; g++) {
+    pool.emplace_back([&, g] {
+      Shard& sh = shards[g];
+      sh.energy.assign(std::max<size_t>(ne, 1), 0.0), sh.counts.assign(std::max<size_t>(nc, 1), 0);
+      sh.res.energy = sh.energy.data(), sh.res.counts = sh.counts.data();
+      const uint64_t lo = n / n_gpus * g + std::min<uint64_t>(g, n % n_gpus);
+      const uint64_t cnt = n / n_gpus + ((uint64_t)g < n % n_gpus ? 1 : 0);
+      r3d_engine* e = r3d_engine_create(model, g);
+      if (!e) {
+        sh.error = g_error;   // (thread-local: this thread's message)
+        return;
+      }
+      if (r3d_run(e, cnt, first_id + lo, seed, &sh.res)) sh.error = g_error;
+      r3d_engine_destroy(e);
+    });
+  }
+  for (auto& t : pool) t.join();
+  for (const Shard& sh : shards)
+    if (!sh.error.empty()) return g_error = sh.error, 1;
+  for (const Shard& sh : shards) {
+    for (size_t i = 0; i < ne; i++) out->energy[i] += sh.energy[i];
+    for (size_t i = 0; i < nc; i++) out->counts[i] += sh.counts[i];
+    out->n_lost += sh.res.n_lost, out->n_timeout += sh.res.n_timeout, out->n_invalid += sh.res.n_invalid;
+    for (int r = 0; r < R3D_INV_NUM; r++) out->invalid_reasons[r] += sh.res.invalid_reasons[r];
+    for (int k = 0; k < R3D_EV_NUM; k++) out->events[k] += sh.res.events[k];
+  }
+  return 0;
 }
 
 int r3d_run_traced(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, r3d_result* out,

@@ -177,6 +177,17 @@ class Model:
         return Result(self.n_seismometers, self.n_bins)
 
 
+def run_model(model, n, first_id=0, seed=0x5EED, n_gpus=1):
+    """r3d_run_model: the whole seam in one call, sharded over `n_gpus` devices."""
+    lib = _ffi.hip_lib()
+    res = model.new_result()
+    c = res._as_c()
+    if lib.r3d_run_model(model.desc_p, n, first_id, seed, n_gpus, C.byref(c)):
+        raise RuntimeError("r3d_run_model failed: " + lib.r3d_last_error().decode())
+    res._from_c(c)
+    return res
+
+
 def volume_desc(origin, cell_size, dims, n_frames, frame_dt):
     v = _ffi.VolumeDesc()
     for k in range(3):

@@ -142,3 +142,20 @@ def test_full_size_crustpinch_properties():
     assert a.energy.sum() == pytest.approx(b.energy.sum(), rel=0.02)
     # small-sample oracle comparison on the big tables too
     check_against_oracle(e, 3000, first_id=123456789)
+
+
+def test_one_call_seam_equals_engine_run(engines):
+    """r3d_run_model (SURVEY.md 8(b)'s one-call form) on one device == Engine.run; asking for
+    a device that is not there fails with a message instead of running on the host."""
+    from radiative3d_amd import run_model
+    e = engines("lopnor")
+    want = e.run(7000, first_id=11, seed=99)
+    got = run_model(e.model, 7000, first_id=11, seed=99, n_gpus=1)
+    assert (got.counts == want.counts).all() and got.events == want.events
+    assert (got.n_lost, got.n_timeout, got.n_invalid) == (want.n_lost, want.n_timeout, want.n_invalid)
+    assert np.allclose(got.energy, want.energy, rtol=1e-12, atol=1e-300)
+    import torch
+    with pytest.raises(RuntimeError, match="device index out of range"):
+        run_model(e.model, 100, n_gpus=torch.cuda.device_count() + 1)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        run_model(e.model, 100, n_gpus=0)
