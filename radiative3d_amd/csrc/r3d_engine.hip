@@ -29,6 +29,7 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/r3d.h"
@@ -282,9 +283,16 @@ __device__ __forceinline__ void collect_pairs(const KArgs& a, const Tables<KIND>
 }
 
 // --------------------------------------------------------------- the kernel --
-template <int KIND, bool LDS_CELLS, bool TRACE>
+// RES: which of the small tables are staged in LDS.  RES_ALL: the cell records and the
+// scatterer / receiver tables (layered and spherical models: a few dozen cells);
+// RES_TABLES: the tables only (tetra models: the cell records come through L1 / L2);
+// RES_NONE: neither (models with thousands of scatterers or receivers, whose tables
+// alone would not fit the CU's 160 KB).
+enum { RES_ALL = 0, RES_TABLES = 1, RES_NONE = 2 };
+template <int KIND, int RES, bool TRACE>
 __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
   using Cell = typename CellOf<KIND>::type;
+  constexpr bool LDS_CELLS = (RES == RES_ALL), LDS_TABLES = (RES != RES_NONE);
   extern __shared__ __align__(16) unsigned char smem[];
 
   // ---- stage the small tables in LDS ----
@@ -295,8 +303,10 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
       for (size_t i = threadIdx.x; i < bytes / 8; i += kBlock) d[i] = s[i];
     };
     if (LDS_CELLS) copy_words(smem + a.lds_cells_off, a.cells, (size_t)a.n_cells * sizeof(Cell));
-    copy_words(smem + a.lds_scat_off, a.scat_head, (size_t)a.n_scat * sizeof(ScatHead));
-    copy_words(smem + a.lds_seis_off, a.seis_scan, (size_t)a.n_seis * sizeof(SeisScan));
+    if (LDS_TABLES) {
+      copy_words(smem + a.lds_scat_off, a.scat_head, (size_t)a.n_scat * sizeof(ScatHead));
+      copy_words(smem + a.lds_seis_off, a.seis_scan, (size_t)a.n_seis * sizeof(SeisScan));
+    }
     if (a.lds_hit_off != 0xFFFFFFFFu)
       copy_words(smem + a.lds_hit_off, a.seis_hit, (size_t)a.n_seis * sizeof(SeisHit));
     if (a.lds_grid_off != 0xFFFFFFFFu) {   // seismometer hash: offsets as they are, items as u16
@@ -327,8 +337,8 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
   Tables<KIND> T;
   T.cells = LDS_CELLS ? reinterpret_cast<const Cell*>(smem + a.lds_cells_off)
                       : reinterpret_cast<const Cell*>(a.cells);
-  T.scat_head = reinterpret_cast<const ScatHead*>(smem + a.lds_scat_off);
-  T.seis_scan = reinterpret_cast<const SeisScan*>(smem + a.lds_seis_off);
+  T.scat_head = LDS_TABLES ? reinterpret_cast<const ScatHead*>(smem + a.lds_scat_off) : a.scat_head;
+  T.seis_scan = LDS_TABLES ? reinterpret_cast<const SeisScan*>(smem + a.lds_seis_off) : a.seis_scan;
   T.seis_hit = (a.lds_hit_off != 0xFFFFFFFFu) ? reinterpret_cast<const SeisHit*>(smem + a.lds_hit_off)
                                               : a.seis_hit;
 
@@ -631,7 +641,7 @@ using namespace r3d;
 struct r3d_engine {
   int device = 0;
   int kind = 0;
-  bool lds_cells = false;
+  int res = RES_ALL;   // which tables live in LDS (see propagate_kernel)
   int n_seis = 0;
   uint32_t n_bins = 0;
   KArgs args{};
@@ -679,35 +689,50 @@ const double* upload_doubles(r3d_engine* e, const double* src, size_t n, hipErro
   return reinterpret_cast<const double*>(e->keep(std::move(b))->p);
 }
 
-template <int KIND, bool LDS_CELLS>
-hipError_t launch(r3d_engine* e, const KArgs& a, bool trace, hipStream_t s) {
-  if (trace)
-    hipLaunchKernelGGL((propagate_kernel<KIND, LDS_CELLS, true>), dim3(e->grid_blocks), dim3(kBlock),
-                       e->lds_bytes, s, a);
-  else
-    hipLaunchKernelGGL((propagate_kernel<KIND, LDS_CELLS, false>), dim3(e->grid_blocks), dim3(kBlock),
-                       e->lds_bytes, s, a);
-  return hipGetLastError();
-}
-
-hipError_t launch_any(r3d_engine* e, const KArgs& a, bool trace, hipStream_t s) {
+// Call f(kind, res) with the engine's cell kind and table residency as compile-time constants.
+template <class F>
+hipError_t with_kernel(const r3d_engine* e, F&& f) {
+  auto by_res = [&](auto kind) {
+    switch (e->res) {
+      case RES_ALL: return f(kind, std::integral_constant<int, RES_ALL>{});
+      case RES_TABLES: return f(kind, std::integral_constant<int, RES_TABLES>{});
+      default: return f(kind, std::integral_constant<int, RES_NONE>{});
+    }
+  };
   switch (e->kind) {
-    case R3D_CELL_CYLINDER:
-      return e->lds_cells ? launch<CELL_CYL, true>(e, a, trace, s) : launch<CELL_CYL, false>(e, a, trace, s);
-    case R3D_CELL_TETRA:
-      return e->lds_cells ? launch<CELL_TET, true>(e, a, trace, s) : launch<CELL_TET, false>(e, a, trace, s);
-    default:
-      return e->lds_cells ? launch<CELL_SPH, true>(e, a, trace, s) : launch<CELL_SPH, false>(e, a, trace, s);
+    case R3D_CELL_CYLINDER: return by_res(std::integral_constant<int, CELL_CYL>{});
+    case R3D_CELL_TETRA: return by_res(std::integral_constant<int, CELL_TET>{});
+    default: return by_res(std::integral_constant<int, CELL_SPH>{});
   }
 }
 
-template <int KIND, bool LDS_CELLS>
-hipError_t set_lds_attr(size_t bytes) {
-  hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_kernel<KIND, LDS_CELLS, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (r != hipSuccess) return r;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_kernel<KIND, LDS_CELLS, true>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+hipError_t launch_any(r3d_engine* e, const KArgs& a, bool trace, hipStream_t s) {
+  return with_kernel(e, [&](auto kind, auto res) {
+    constexpr int K = decltype(kind)::value, R = decltype(res)::value;
+    if (trace)
+      hipLaunchKernelGGL((propagate_kernel<K, R, true>), dim3(e->grid_blocks), dim3(kBlock), e->lds_bytes, s, a);
+    else
+      hipLaunchKernelGGL((propagate_kernel<K, R, false>), dim3(e->grid_blocks), dim3(kBlock), e->lds_bytes, s, a);
+    return hipGetLastError();
+  });
+}
+
+hipError_t set_lds_attr(const r3d_engine* e) {
+  return with_kernel(e, [&](auto kind, auto res) {
+    constexpr int K = decltype(kind)::value, R = decltype(res)::value;
+    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_kernel<K, R, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
+    if (r != hipSuccess) return r;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_kernel<K, R, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
+  });
+}
+
+hipError_t blocks_per_cu(const r3d_engine* e, int* per_cu) {
+  return with_kernel(e, [&](auto kind, auto res) {
+    constexpr int K = decltype(kind)::value, R = decltype(res)::value;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, propagate_kernel<K, R, false>, kBlock, e->lds_bytes);
+  });
 }
 
 bool check_model(const r3d_model_desc* m) {
@@ -878,17 +903,28 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   // ---- LDS carve-up and launch geometry ----
   auto align16 = [](size_t x) { return (x + 15) & ~size_t(15); };
   size_t off = 0;
-  e->lds_cells = cell_bytes <= 48 * 1024;
-  a.lds_cells_off = 0xFFFFFFFFu;
-  if (e->lds_cells) a.lds_cells_off = (uint32_t)off, off = align16(off + cell_bytes);
-  a.lds_scat_off = (uint32_t)off, off = align16(off + (size_t)m->n_scatterers * sizeof(ScatHead));
-  a.lds_seis_off = (uint32_t)off, off = align16(off + (size_t)std::max(1, m->n_seismometers) * sizeof(SeisScan));
-  // the kernel also has ~37 KB of static LDS (catch queues, tallies); the receiver "hit"
-  // records go to LDS only if everything still fits in the CU's 160 KB
+  // static LDS of the kernel: the waves' catch queues and the block's tallies
   const size_t kStaticLds = sizeof(CatchQueue) * kWaves + 1024;
+  const size_t scat_bytes = (size_t)m->n_scatterers * sizeof(ScatHead);
+  const size_t scan_bytes = (size_t)std::max(1, m->n_seismometers) * sizeof(SeisScan);
+  // The scatterer heads and the receiver scan records go to LDS unless they would leave
+  // less than 16 KB for everything else (thousands of scatterers or receivers); the cell
+  // records go with them when they are small (layered and spherical models).
+  const bool tables_fit = scat_bytes + scan_bytes + kStaticLds + 16 * 1024 <= 160 * 1024;
+  const bool cells_fit = tables_fit && cell_bytes <= 48 * 1024 &&
+                         cell_bytes + scat_bytes + scan_bytes + kStaticLds + 16 * 1024 <= 160 * 1024;
+  e->res = cells_fit ? RES_ALL : tables_fit ? RES_TABLES : RES_NONE;
+  a.lds_cells_off = a.lds_scat_off = a.lds_seis_off = 0xFFFFFFFFu;
+  if (cells_fit) a.lds_cells_off = (uint32_t)off, off = align16(off + cell_bytes);
+  if (tables_fit) {
+    a.lds_scat_off = (uint32_t)off, off = align16(off + scat_bytes);
+    a.lds_seis_off = (uint32_t)off, off = align16(off + scan_bytes);
+  }
+  // the receiver "hit" records go to LDS only if everything still fits in the CU's 160 KB
   const size_t hit_bytes = (size_t)std::max(1, m->n_seismometers) * sizeof(SeisHit);
   a.lds_hit_off = 0xFFFFFFFFu;
-  if (off + hit_bytes + kStaticLds <= 160 * 1024) a.lds_hit_off = (uint32_t)off, off = align16(off + hit_bytes);
+  if (tables_fit && off + hit_bytes + kStaticLds + 8192 <= 160 * 1024)
+    a.lds_hit_off = (uint32_t)off, off = align16(off + hit_bytes);
   // the seismometer hash, when it is small (it is for the reference's survey lines and arrays:
   // a few thousand cells): both levels of the lookup become LDS reads instead of two
   // dependent global loads in every collecting iteration
@@ -910,36 +946,17 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   }
   e->lds_bytes = off;
   if (e->lds_bytes + kStaticLds > 160 * 1024) {
-    g_error = "model's receiver scan table exceeds the 160 KB of LDS per CU";
+    g_error = "internal error: LDS carve-up exceeds the 160 KB of a CU";
     return nullptr;
   }
   hipDeviceProp_t prop;
   R3D_HIP_OK(hipGetDeviceProperties(&prop, device));
-  if (e->lds_bytes > 64 * 1024) {
-    hipError_t r;
-    switch (e->kind) {
-      case R3D_CELL_CYLINDER: r = e->lds_cells ? set_lds_attr<CELL_CYL, true>(e->lds_bytes) : set_lds_attr<CELL_CYL, false>(e->lds_bytes); break;
-      case R3D_CELL_TETRA: r = e->lds_cells ? set_lds_attr<CELL_TET, true>(e->lds_bytes) : set_lds_attr<CELL_TET, false>(e->lds_bytes); break;
-      default: r = e->lds_cells ? set_lds_attr<CELL_SPH, true>(e->lds_bytes) : set_lds_attr<CELL_SPH, false>(e->lds_bytes);
-    }
-    R3D_HIP_OK(r);
-  }
+  if (e->lds_bytes > 64 * 1024) R3D_HIP_OK(set_lds_attr(e.get()));
   // persistent grid: exactly the workgroups that can be resident at once (register- and
   // LDS-limited), so every block is running while there is work and none queues behind
   int per_cu = 1;
-  {
-    hipError_t r;
-#define R3D_OCC(K, L) \
-  hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, propagate_kernel<K, L, false>, kBlock, e->lds_bytes)
-    switch (e->kind) {
-      case R3D_CELL_CYLINDER: r = e->lds_cells ? R3D_OCC(CELL_CYL, true) : R3D_OCC(CELL_CYL, false); break;
-      case R3D_CELL_TETRA: r = e->lds_cells ? R3D_OCC(CELL_TET, true) : R3D_OCC(CELL_TET, false); break;
-      default: r = e->lds_cells ? R3D_OCC(CELL_SPH, true) : R3D_OCC(CELL_SPH, false);
-    }
-#undef R3D_OCC
-    R3D_HIP_OK(r);
-    per_cu = std::max(1, std::min(per_cu, 8));
-  }
+  R3D_HIP_OK(blocks_per_cu(e.get(), &per_cu));
+  per_cu = std::max(1, std::min(per_cu, 8));
   e->grid_blocks = prop.multiProcessorCount * per_cu;
 
   // ---- result scratch, work counter, stream, events ----

@@ -159,3 +159,16 @@ def test_one_call_seam_equals_engine_run(engines):
         run_model(e.model, 100, n_gpus=torch.cuda.device_count() + 1)
     with pytest.raises(RuntimeError, match="no CPU path"):
         run_model(e.model, 100, n_gpus=0)
+
+
+def test_thousands_of_receivers_tables_in_hbm():
+    """4500 receivers: the scan table (252 KB) cannot live in a CU's LDS, so the engine runs the
+    kernel variant that reads the scatterer / receiver tables from HBM; results as ever."""
+    args = [a for a in halfspace(4) if not a.startswith("--seis-p2p")] + [
+        "--seis-p2p=0,0,0,183.85,183.85,0,2.737,0.105,10.0,1500",
+        "--seis-p2p=0,0,0,260,0,0,2.737,0.105,10.0,1500",
+        "--seis-p2p=0,0,0,240.21,-99.5,0,2.737,0.105,10.0,1500"]
+    m = Model(args)
+    assert m.n_seismometers == 4500
+    rg, ro = check_against_oracle(Engine(m), 20000)
+    assert rg.events["catch"] > 100
