@@ -742,6 +742,11 @@ bool check_model(const r3d_model_desc* m) {
   if (m->n_scatterers <= 0 || !m->scatterers) return g_error = "model has no scatterers", false;
   if (m->n_toa == 0 || !m->toa) return g_error = "model has no take-off angles", false;
   if (m->params.n_bins == 0) return g_error = "zero time bins", false;
+  // index widths of the device layout: guides and samplers hold take-off indices in 32 bits,
+  // a catch's (seismometer, bin, type) travels as one 32-bit word
+  if (m->n_toa >= (uint64_t(1) << 32)) return g_error = "more than 2^32 take-off angles", false;
+  if ((uint64_t)std::max(0, m->n_seismometers) * m->params.n_bins >= (uint64_t(1) << 31))
+    return g_error = "seismometers x time bins must stay below 2^31", false;
   if (m->source.cell < 0 || m->source.cell >= m->n_cells) return g_error = "source cell out of range", false;
   const int want_faces = m->cell_kind == R3D_CELL_CYLINDER ? 3 : m->cell_kind == R3D_CELL_TETRA ? 4 : 2;
   for (int i = 0; i < m->n_cells; i++) {
