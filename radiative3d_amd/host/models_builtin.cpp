@@ -4,9 +4,9 @@
 // reference selects a model (reference user.cpp:59-134).  The reference keeps
 // one hand-written function per model in user_*_inc.cpp; those files remain
 // the user's and still compile against this library's grid.hpp.  What is
-// built in here are table-driven definitions of the four benchmark models
-// named by BASELINE.json, with the same selection codes, argument lists and
-// node values as the reference's functions:
+// built in here are table-driven definitions of every model the reference's
+// dispatcher knows, with the same selection codes, argument lists and node
+// values as the reference's functions:
 //
 //   40      halfspace, two layers          (user_Halfspace_inc.cpp:28-183)
 //   1..4    Lop Nor layered crust+mantle   (user_LopNorCyl_inc.cpp:30-400); with 20 or more
@@ -16,7 +16,8 @@
 //   5..7    North Sea crust pinch, tetra   (user_NSCP_inc.cpp:13-206)
 //   16      whole-Earth spherical shells   (user_SphereEarth_inc.cpp:13-86)
 //   30      two-shell toy sphere           (user_ToySphere_inc.cpp; do-toysphere-vids.sh)
-// Not built in (no run script uses them): 8 crust upthrust, 128 scattering-parameter study.
+//   8       crust upthrust, tetra          (user_Upthrust_inc.cpp)
+//   128     scattering-parameter study, 42 layers  (user.cpp:207-309)
 //
 // Where the reference prints to stderr and calls exit(1) on a bad argument
 // count, these throw Runtime.
@@ -328,6 +329,183 @@ void build_crustpinch(Grid& g, const std::vector<Real>& a) {
   }
 }
 
+// ----------------------------------------------------------------- 8 ------
+// Crust upthrust: the NSCP fan (15 ranges x 6 azimuths) with ten sheets.  Across the six
+// "active" range columns the Moho transition is thrust upwards (or downwards) by up to
+// thrust_l on the near side and thrust_r on the far side, ramping as (step/2)^gamma; where
+// the displaced transition overlaps the undisplaced one, two interpolated sheets carry
+// the layering through.  The columns are built per active-region step m = 0..5 from an
+// eight-sheet plumb line.
+struct Mat {
+  Real vp, vs, rho;
+  const Neakq* grp;
+};
+struct PlumbSheet {
+  Real z;
+  Mat above, below;   // equal where the sheet is not a discontinuity
+  bool jump;
+};
+struct ColumnSheet {
+  Real z;
+  Mat above, below;
+  bool jump;
+};
+Mat blend(Real w_above, const Mat& a, const Mat& b, const Neakq* grp) {
+  const Real w_below = 1 - w_above;
+  return Mat{w_above * a.vp + w_below * b.vp, w_above * a.vs + w_below * b.vs,
+             w_above * a.rho + w_below * b.rho, grp};
+}
+// Sheet n (0..9) of the column at active-region step m (0..5).
+ColumnSheet upthrust_sheet(const PlumbSheet pl[8], Real thrust_l, Real thrust_r, Real gamma, Index m,
+                           Index n) {
+  auto plain = [&](Index k, Real dz) {
+    return ColumnSheet{pl[k].z + dz, pl[k].above, pl[k].below, pl[k].jump};
+  };
+  if (n < 2 || n > 5) return plain(n > 5 ? n - 2 : n, 0);   // above and below the transition
+  const bool near_side = m < 3;
+  Real frac = near_side ? ((Real)m) / 2.0 : ((Real)(5 - m)) / 2.0;
+  frac = std::pow(frac, gamma);
+  const Real shift = near_side ? thrust_l * frac : thrust_r * frac;
+  // the displaced copy of the transition's two sheets: below the originals on the near
+  // side (sheets 4, 5), above them on the far side (sheets 2, 3)
+  if ((n < 4) != near_side) {
+    ColumnSheet c = plain(n < 4 ? n : n - 2, 0);
+    c.z += shift;
+    return c;
+  }
+  // the other two sheets interpolate between the layer above and the layer below
+  const Real thick = pl[2].z - pl[3].z;
+  const Real z_above = near_side ? pl[1].z : pl[3].z + shift;
+  const Real z_below = near_side ? pl[2].z + shift : pl[4].z;
+  const Real z_mid = (z_above + z_below) / 2;
+  Real z;
+  if (m == 2) z = pl[n].z + thrust_r;
+  else if (m == 3) z = pl[n - 2].z + thrust_l;
+  else z = z_mid + ((n == 2 || n == 4) ? 0.5 * thick : -0.5 * thick);
+  const Mat& top = near_side ? pl[1].below : pl[3].below;
+  const Mat& bottom = near_side ? pl[2].above : pl[4].above;
+  const Real w_above = (z_below - z) / (z_below - z_above);
+  const Mat mixed = blend(w_above, top, bottom, top.grp);
+  return ColumnSheet{z, mixed, mixed, false};
+}
+
+void build_upthrust(Grid& g, const std::vector<Real>& a) {
+  Neakq dflt{0.8, 0.01, 4.00, 0.8, 200};
+  Neakq sedi = dflt, crust = dflt, active = dflt, moho = dflt, mant = dflt;
+  Real sedi_thick = 2.0, crust_thick = 30.0, moho_thick = 10.0;
+  Real thrust_l = -10, thrust_r = 0, gamma = 1.0, shear = 0;
+  switch (a.size()) {
+    case 0:
+      break;
+    case 32:
+      thrust_l = a[28], thrust_r = a[29], gamma = a[30], shear = a[31];
+      [[fallthrough]];
+    case 28:
+      sedi_thick = a[25], crust_thick = a[26], moho_thick = a[27];
+      [[fallthrough]];
+    case 25:
+      sedi = neakq_at(a, 0), crust = neakq_at(a, 5), active = neakq_at(a, 10);
+      moho = neakq_at(a, 15), mant = neakq_at(a, 20);
+      break;
+    default:
+      bad_arg_count();
+  }
+
+  const Count nR = 15, nAz = 6, nZ = 10;
+  const Index first_active = 5;
+  const Count n_active = 6;
+  const Real azi_far[nAz] = {45.0, 56.25, 78.75, 101.25, 123.75, 135.0};
+  const Real azi_near[nAz] = {5.0, 39.00, 73.00, 107.00, 141.00, 175.0};
+  const Real range[nR] = {-120, -60, 60, 120, 220, 310, 365, 418, 422, 475, 530, 650, 770, 890, 1020};
+
+  auto plumb = [&](const Neakq* cr, PlumbSheet pl[8]) {
+    const Mat se0{4.50, 2.60, 2.20, &sedi}, se1{4.52, 2.61, 2.21, &sedi};
+    const Mat cr1{6.20, 3.58, 2.80, cr}, cr2{6.24, 3.60, 2.82, cr}, mo2{7.70, 4.44, 3.39, &moho};
+    const Mat ma3{8.00, 4.46, 3.40, &mant}, ma4a{8.040, 4.48, 3.50, &mant}, ma4b{8.045, 4.49, 3.50, &mant};
+    const Mat ma5{8.051, 4.50, 3.43, &mant}, ma6{8.301, 4.52, 3.32, &mant}, ma7{8.848, 4.78, 3.46, &mant};
+    const PlumbSheet sheets[8] = {{0.0, se0, se0, false},
+                                  {-sedi_thick, se1, cr1, true},
+                                  {-(sedi_thick + crust_thick), cr2, mo2, true},
+                                  {-(sedi_thick + crust_thick + moho_thick), ma3, ma3, false},
+                                  {-80, ma4a, ma4b, true},
+                                  {-120, ma5, ma5, false},
+                                  {-210, ma6, ma6, false},
+                                  {-360, ma7, ma7, false}};
+    for (int k = 0; k < 8; k++) pl[k] = sheets[k];
+  };
+  PlumbSheet pl_plain[8], pl_active[8];
+  plumb(&crust, pl_plain);
+  plumb(&active, pl_active);
+
+  g.SetSize(nR, nAz, nZ);
+  g.SetIndexBase(0);
+  g.SetMapping(Grid::GC_RAE, Grid::GC_CURVED);
+  for (Index ir = 0; ir < nR; ir++) {
+    Index m = (ir > first_active) ? ir - first_active : 0;
+    m = (m < n_active) ? m : n_active - 1;
+    const bool in_active = (ir >= first_active && ir < first_active + n_active - 1);
+    const PlumbSheet* pl = in_active ? pl_active : pl_plain;
+    Real tl = thrust_l, tr = thrust_r, sh = shear;
+    if (thrust_r < thrust_l) {          // thrust from the far side: mirror the ramp
+      m = (n_active - 1) - m;
+      tl = thrust_r, tr = thrust_l, sh = -shear;
+    } else if (thrust_r == thrust_l) {
+      m = 0, sh = 0;
+    }
+    for (Index k = 0; k < nZ; k++) {
+      const ColumnSheet c = upthrust_sheet(pl, tl, tr, gamma, m, k);
+      for (Index ja = 0; ja < nAz; ja++) {
+        const Real az = (ir == 0)   ? azi_far[nAz - 1 - ja]
+                        : (ir == 1) ? azi_near[nAz - 1 - ja]
+                        : (ir == 2) ? azi_near[ja]
+                                    : azi_far[ja];
+        GridNode& node = g.WNode(ir, ja, k);
+        node.SetLocation(range[ir], az, c.z);
+        node.SetAttributes(VpVs(c.above.vp, c.above.vs), c.above.rho, c.above.grp->qq(), c.above.grp->hs());
+        if (c.jump)
+          node.SetAttributes(VpVs(c.below.vp, c.below.vs), c.below.rho, c.below.grp->qq(), c.below.grp->hs());
+        // shear across the thrust: the transition's sheets slide in range at the two
+        // middle steps of the ramp
+        if ((m == 2 || m == 3) && (k == 2 || k == 3)) node.AdjustLocation(-sh, 0, 0);
+        else if ((m == 2 || m == 3) && (k == 4 || k == 5)) node.AdjustLocation(+sh, 0, 0);
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------- 128 ------
+// Scattering-parameter study: 42 layers 10 km thick, each varying one of nu, eps, a, kappa,
+// the S wavenumber (through the velocity scale) or the Vp/Vs ratio about a common default.
+void build_scat_params_study(Grid& g, const std::vector<Real>&) {
+  const Real nu = 0.8, eps = 0.05, corr = 1.0, kap = 0.3, vs = 4.0, rho = 1.0;
+  const Real vp = vs * 1.7321;
+  const Q q = QmQk(kInf);
+  const Count per = 7, sheets = per * 6 + 1;
+  g.SetSize(3, 1, sheets);
+  g.SetIndexBase(0);
+  for (Index k = 0; k < sheets; k++) {
+    const Real depth = -1.0 * 10 * k;
+    g.WNode(0, 0, k).SetLocation(0.0, 0.0, depth);
+    g.WNode(1, 0, k).SetLocation(1.0, 0.0, depth);
+    g.WNode(2, 0, k).SetLocation(0.0, 1.0, depth);
+  }
+  const Real nus[per] = {0.3, 0.5, 0.7, 0.9, 1.1, 1.3, 1.5};
+  const Real epss[per] = {0.01, 0.02, 0.03, 0.04, 0.05, 0.06, 0.07};
+  const Real corrs[per] = {0.3, 0.6, 0.8, 1.0, 1.2, 1.5, 1.8};
+  const Real kaps[per] = {0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.8};
+  const Real scales[per] = {1.5, 1.3, 1.1, 1.0, 0.9, 0.7, 0.5};
+  const Real ratios[per] = {1.3321, 1.5321, 1.6321, 1.7321, 1.8321, 1.9321, 2.1321};
+  Index k = 0;
+  for (Real v : nus) g.WNode(0, 0, k++).SetAttributes(VpVs(vp, vs), rho, q, HSneak(v, eps, corr, kap));
+  for (Real v : epss) g.WNode(0, 0, k++).SetAttributes(VpVs(vp, vs), rho, q, HSneak(nu, v, corr, kap));
+  for (Real v : corrs) g.WNode(0, 0, k++).SetAttributes(VpVs(vp, vs), rho, q, HSneak(nu, eps, v, kap));
+  for (Real v : kaps) g.WNode(0, 0, k++).SetAttributes(VpVs(vp, vs), rho, q, HSneak(nu, eps, corr, v));
+  const HetSpec hs = HSneak(nu, eps, corr, kap);
+  for (Real v : scales) g.WNode(0, 0, k++).SetAttributes(VpVs(v * vp, v * vs), rho, q, hs);
+  for (Real v : ratios) g.WNode(0, 0, k++).SetAttributes(VpVs(v * vs, vs), rho, q, hs);
+  g.WNode(0, 0, k++).SetAttributes(VpVs(vp, vs), rho, q, hs);
+}
+
 // ---------------------------------------------------------------- 16 ------
 void build_sphere_earth(Grid& g, const std::vector<Real>&) {
   const Real q = 2000;
@@ -388,6 +566,14 @@ __attribute__((weak)) void Grid::ConstructGridManual(int Selection,
     case 30:
       std::cout << head << "Selected Spherical Toy Model (Spherical).\n";
       build_toy_sphere(*this, args);
+      break;
+    case 8:
+      std::cout << head << "Selected Crust Upthrust Model (Tetra WCG).\n";
+      build_upthrust(*this, args);
+      break;
+    case 128:
+      std::cout << head << "Selected Scatter Params Study (Layered).\n";
+      build_scat_params_study(*this, args);
       break;
     case 5: case 6: case 7:
       std::cout << head << "Selected North Sea Crust Pinch Model (Tetra WCG).\n";

@@ -52,6 +52,8 @@ def build(lib, args):
 
 MOHO20 = ("0.8,0.06,0.25,0.5,250,0.8,0.05,0.5,0.5,1000,0.8,0.04,1.0,0.5,2000,"
           "0.7,0.03,0.4,0.3,1500")
+NSCP25 = ("0.8,0.01,0.20,0.2,200,0.8,0.01,0.20,0.3,1500,0.8,0.02,0.30,0.3,1200,"
+          "0.8,0.01,0.20,0.4,1500,0.8,0.01,0.20,0.5,900")
 EXTRA = {
     "lopnor-moho": ["--grid-compiled=1", "--model-args=" + MOHO20, "--toa-degree=2", "--range=1200", "--flatten"],
     "lopnor-moho-alt2": ["--grid-compiled=21", "--model-args=" + MOHO20, "--toa-degree=2", "--range=1200"],
@@ -59,6 +61,12 @@ EXTRA = {
     "lopnor-moho-alt2-15": ["--grid-compiled=21", "--toa-degree=2", "--range=1200",
                             "--model-args=" + ",".join(MOHO20.split(",")[:15])],
     "toysphere": ["--grid-compiled=30", "--toa-degree=2", "--source-loc=0,0,-500"],
+    "upthrust-defaults": ["--grid-compiled=8", "--toa-degree=2"],
+    "upthrust-32": ["--grid-compiled=8", "--toa-degree=2", "--model-args=" + NSCP25 + ",2.5,28,9,-12,-3,1.5,4"],
+    "upthrust-reversed": ["--grid-compiled=8", "--toa-degree=2", "--model-args=" + NSCP25 + ",2,30,10,-2,-9,0.7,3"],
+    "upthrust-level": ["--grid-compiled=8", "--toa-degree=2", "--model-args=" + NSCP25 + ",2,30,10,-5,-5,1,2"],
+    "upthrust-28": ["--grid-compiled=8", "--toa-degree=2", "--model-args=" + NSCP25 + ",3,25,8"],
+    "scat-params-study": ["--grid-compiled=128", "--toa-degree=2", "--range=300", "--source-loc=0,0,-5"],
 }
 
 
@@ -77,13 +85,11 @@ def test_builtin_models_equal_the_users_definitions(user_lib, name):
     user_lib.r3dh_model_free(hu), builtin.r3dh_model_free(hb)
 
 
-@pytest.mark.parametrize("args,cells", [
-    (["--grid-compiled=8", "--toa-degree=1"], None),             # crust upthrust (tetra)
-    (["--grid-compiled=30", "--toa-degree=1"], None),            # toy sphere
-    (["--grid-compiled=21", "--toa-degree=1", "--range=1200"], None),  # Lop Nor Moho alt 2
-])
-def test_other_user_models_build(user_lib, args, cells):
-    h = build(user_lib, args)
-    d = user_lib.r3dh_model_desc(h).contents
-    assert d.n_cells > 0 and d.n_scatterers > 0
-    user_lib.r3dh_model_free(h)
+def test_every_selector_of_the_users_dispatcher_is_built_in(user_lib):
+    """user.cpp:69-125: 1-4, 5-7, 8, 16, 21, 30, 40, 128 (32764 is a deliberate trap)."""
+    builtin = _ffi.host_lib()
+    for sel in (1, 2, 3, 4, 5, 6, 7, 8, 16, 21, 30, 40, 128):
+        args = [f"--grid-compiled={sel}", "--toa-degree=1", "--range=600", "--source-loc=0,0,-5"]
+        hu, hb = build(user_lib, args), build(builtin, args)
+        assert user_lib.r3dh_grid_dump(hu) == builtin.r3dh_grid_dump(hb), sel
+        user_lib.r3dh_model_free(hu), builtin.r3dh_model_free(hb)
