@@ -65,5 +65,17 @@ def lopnor_vids(deg=4):
             "--seis-p2p=425.54,-169.53,0.98,-102.27,430.84,0.60,1.0,2.0,40.0,16").split()
 
 
+def upthrust(deg=4):
+    """Model 8 (crust upthrust, tetra) with the crust-pinch run's source and arrays
+    (no reference run script uses it; user_Upthrust_inc.cpp argument pattern of 32)."""
+    return ("--grid-compiled=8 "
+            "--model-args=0.8,0.01,0.20,0.2,200,0.8,0.01,0.20,0.3,1500,0.8,0.02,0.30,0.3,1200,"
+            "0.8,0.01,0.20,0.4,1500,0.8,0.01,0.20,0.5,900,2.0,30.0,10.0,-12,-3,1.5,4 "
+            "--source=SDR,22.5,90,0 --source-loc=0,0,-10 --frequency=2.0 --timetolive=600 "
+            f"--binsize=2.00 --toa-degree={deg} "
+            "--seis-p2p=0,67.5,0,950,67.5,0,1.0,2.0,40.0,40 "
+            "--seis-p2p=0,112.5,0,950,112.5,0,1.0,2.0,40.0,40").split()
+
+
 CONFIGS = {"halfspace": halfspace, "crustpinch": crustpinch, "lopnor": lopnor, "sphere": sphere,
-           "toysphere_vids": toysphere_vids, "lopnor_vids": lopnor_vids}
+           "toysphere_vids": toysphere_vids, "lopnor_vids": lopnor_vids, "upthrust": upthrust}

@@ -26,7 +26,7 @@ def compare(model, n, first_id=0, seed=0x5EED, allow=0):
 
 
 @pytest.mark.parametrize("name,n", [("halfspace", 20000), ("crustpinch", 4000), ("lopnor", 4000),
-                                    ("sphere", 400), ("toysphere_vids", 500), ("lopnor_vids", 300)])
+                                    ("sphere", 400), ("toysphere_vids", 500), ("lopnor_vids", 300), ("upthrust", 4000)])
 def test_kernel_code_matches_oracle_history_by_history(models, name, n):
     compare(models(name), n)
 
