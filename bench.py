@@ -179,17 +179,32 @@ def main():
     n = args.histories
     seed = 0x5EED
 
+    # A lone batch ends in a drain phase: the work counter is exhausted and ever fewer lanes
+    # still carry a history (the longest NSCP histories are ~40 times the mean), about 8 of a
+    # lone 1e7-history launch's 25 ms.  The steps therefore form a carry chain
+    # (r3d_run_device_carry): the histories still in flight when a step's ids run out stay in
+    # the engine and are resumed by the next step's launch, and one flush launch after the
+    # last step runs the stragglers to their end.  Results do not depend on it.
     step_res = DeviceResult(model, device)
 
-    def step(i):
+    def step(i, events=None):
         # every step and every rank gets its own disjoint id range; a step ends with the
-        # whole-job bins of that step (summed over ranks) added to the running total
+        # whole-job bins of that launch (summed over ranks) added to the running total
         first = (i * world + rank) * n
         step_res.zero_()
-        engine.run_device(n, first, seed, *step_res.pointers(), stream=stream.cuda_stream)
+        if events is not None:
+            events[0].record(stream)
+        engine.run_device(n, first, seed, *step_res.pointers(), stream=stream.cuda_stream, carry="carry")
+        if events is not None:
+            events[1].record(stream)
         step_res.allreduce_()     # no-op at world == 1
         result.add_(step_res)
-        return engine
+
+    def flush():
+        step_res.zero_()
+        engine.run_device(0, 0, seed, *step_res.pointers(), stream=stream.cuda_stream, carry="final")
+        step_res.allreduce_()
+        result.add_(step_res)
 
     def sync():
         if under_launcher:
@@ -198,22 +213,21 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    flush()
     sync()
     result.zero_()
     sync()
-    kernel_ms = []
+    # per-launch kernel durations: HIP events on the launch stream, recorded around each
+    # launch and read after the timed region
+    kernel_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                     for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
-        kernel_ms.append(None)
+        step(args.warmup + i, kernel_events[i])
+    flush()
     sync()
     elapsed = time.perf_counter() - t0
-    # per-launch kernel durations from HIP events on the launch stream: measured in a
-    # second, untimed pass so that reading the events does not serialise the timed loop
-    for i in range(args.steps):
-        step(args.warmup + args.steps + i)
-        kernel_ms[i] = engine.last_kernel_ms()
-    sync()
+    kernel_ms = [a.elapsed_time(b) for a, b in kernel_events]
     if under_launcher:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -238,7 +252,9 @@ def main():
                                    "480 seismometers x 300 bins",
                        "histories_per_gpu_per_step": n, "toa_degree": args.toa_degree,
                        "cells": model.n_cells, "scatterers": model.n_scatterers,
-                       "parallelism": f"history-id shards x{world}, one all-reduce of the bins per step"},
+                       "parallelism": f"history-id shards x{world}, one all-reduce of the bins per step; "
+                                      "steps chained (unfinished histories carried into the next "
+                                      "step's launch, one flush launch at the end, inside the timed region)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": recorded_hbm_traffic(args.toa_degree, n),

@@ -238,6 +238,10 @@ int r3d_run(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,
  * stream).  d_scalars holds 3 + R3D_INV_NUM + R3D_EV_NUM uint64 counters in
  * the order n_lost, n_timeout, n_invalid, invalid_reasons[], events[].
  * Asynchronous: returns after enqueueing.  d_finals may be NULL.           */
+/* (Up to 16 r3d_run_device launches of one engine may be in flight at a time, on
+ * different streams and into different buffers: a batch ends in a drain phase in
+ * which ever fewer lanes still carry a history -- the longest histories are ~40
+ * times the mean -- and the next batch's workgroups fill the CUs it frees.)      */
 int r3d_run_device(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,
                    double* d_energy, uint64_t* d_counts, uint64_t* d_scalars,
                    r3d_final* d_finals, void* stream);
@@ -249,6 +253,19 @@ int r3d_run_device(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,
  * to summation order).  Returns 0 on success.                                 */
 int r3d_run_model(const r3d_model_desc* model, uint64_t n, uint64_t first_id, uint64_t seed,
                   int n_gpus, r3d_result* out);
+
+/* r3d_run_device for a CHAIN of batches (same engine, same seed, launches in stream
+ * order).  A batch ends in a drain phase in which ever fewer lanes still carry a
+ * history, and the longest histories are ~40 times the mean: ~8 of the 25 ms of a
+ * 1e7-history NSCP launch.  With final == 0 the histories still in flight when the
+ * batch's ids run out stay in the engine (HBM) and are resumed by its next carry
+ * launch, so every launch runs full; final != 0 also runs everything carried to its
+ * end (n may be 0: flush only).  The SUM over the chain's launches equals r3d_run on
+ * the union of their id ranges (integers exactly, energies to summation order); a
+ * single launch's buffers hold what that launch executed.                     */
+int r3d_run_device_carry(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,
+                         double* d_energy, uint64_t* d_counts, uint64_t* d_scalars,
+                         void* stream, int final);
 
 /* Like r3d_run, additionally returning the per-history final records
  * (finals[i] for id first_id + i; caller-allocated, n entries).            */

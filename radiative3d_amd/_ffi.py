@@ -183,6 +183,9 @@ def hip_lib():
         L.r3d_volume_read.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int]
         L.r3d_volume_device_ptr.restype = C.c_void_p
         L.r3d_volume_device_ptr.argtypes = [C.c_void_p]
+        L.r3d_run_device_carry.restype = C.c_int
+        L.r3d_run_device_carry.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.r3d_run_model.restype = C.c_int
         L.r3d_run_model.argtypes = [C.POINTER(ModelDesc), C.c_uint64, C.c_uint64, C.c_uint64, C.c_int,
                                     C.POINTER(Result)]

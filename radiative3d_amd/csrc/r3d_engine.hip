@@ -283,6 +283,20 @@ __device__ __forceinline__ void collect_pairs(const KArgs& a, const Tables<KIND>
 }
 
 // --------------------------------------------------------------- the kernel --
+// A batch ends in a drain phase: the work counter is exhausted, ever fewer lanes still
+// carry a history, and the longest histories are ~40 times the mean -- about 8 of a lone
+// 1e7-history NSCP launch's 25 ms.  With carry-over a wave that finds the counter
+// exhausted parks each unfinished history in its work-item's own slot in HBM and exits;
+// the engine's next launch resumes it in the same work-item before handing out new ids.
+// Histories are keyed by id and draw from per-history counters, so which launch runs
+// which part of a history changes no result.
+struct CarrySlot {
+  Phonon p;
+  Rng rng;
+  Pending ev;
+  uint32_t state;   // 0 empty, 1 in flight, 3 in flight and parked on a reflection/transmission
+};
+
 // RES: which of the small tables are staged in LDS.  RES_ALL: the cell records and the
 // scatterer / receiver tables (layered and spherical models: a few dozen cells);
 // RES_TABLES: the tables only (tetra models: the cell records come through L1 / L2);
@@ -394,6 +408,17 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
   ev.vel = 0.0, ev.face = -1, ev.flags = 0u;
   unsigned long long w_next = 0, w_end = 0;  // wave-uniform: ids this wave still owns
   bool drained = false;                      // wave-uniform: the global counter ran out
+  const size_t gtid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (a.carry_in) {   // resume the history this work-item parked at the end of the previous launch
+    CarrySlot* c = reinterpret_cast<CarrySlot*>(a.carry_in) + gtid;
+    const uint32_t state = c->state;
+    if (state) {
+      p = c->p, rng = c->rng, ev = c->ev;
+      alive = true, parked = (state & 2u) != 0;
+      my_id = ((uint64_t)rng.id_hi << 32) | rng.id_lo;
+      c->state = 0u;
+    }
+  }
 
   for (;;) {
     // ---- refill idle lanes from the wave's id range.  A refill costs a dependent
@@ -403,15 +428,23 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
     const bool refill_now = (unsigned)__popcll(need) >= a.refill_min || need == ~0ull;
     while (refill_now && need != 0ull && !drained) {
       if (w_next == w_end) {
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(a.next, (unsigned long long)kChunk);
-        base = __shfl(base, 0);
+        // claim ids: 256 at a time while the batch is far from its end, tapering to 64 so
+        // that no wave sits on unstarted histories while others have run dry
+        unsigned long long base = 0, chunk = kChunk;
+        if (lane == 0) {
+          const unsigned long long seen = __hip_atomic_load(a.next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long left = (seen < a.n) ? a.n - seen : 0ull;
+          const unsigned long long share = left / (2ull * gridDim.x * kWaves);   // per wave, halved
+          chunk = (share >= kChunk) ? kChunk : (share >= 128ull ? 128ull : 64ull);
+          base = atomicAdd(a.next, chunk);
+        }
+        base = __shfl(base, 0), chunk = __shfl(chunk, 0);
         if (base >= a.n) {
           drained = true;
           break;
         }
         w_next = base;
-        w_end = (base + kChunk < a.n) ? base + kChunk : a.n;
+        w_end = (base + chunk < a.n) ? base + chunk : a.n;
       }
       const unsigned want = (unsigned)__popcll(need);
       const unsigned long long avail = w_end - w_next;
@@ -429,6 +462,14 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
       if (lane == 0 && take) atomicAdd(&s_tally[kEv + R3D_EV_GENERATED], (unsigned long long)take);
       w_next += take;
       need = __ballot(!alive);
+    }
+    if (drained && a.carry_out) {   // no ids left: park what is in flight for the next launch
+      if (alive) {
+        CarrySlot* c = reinterpret_cast<CarrySlot*>(a.carry_out) + gtid;
+        c->p = p, c->rng = rng, c->ev = ev;
+        c->state = parked ? 3u : 1u;
+      }
+      break;
     }
     if (!__any(alive)) break;  // every lane idle and nothing left to hand out
     R3D_STAMP(0);  // refill
@@ -652,6 +693,13 @@ struct r3d_engine {
   bool timed = false;
   std::vector<std::unique_ptr<DevBuf>> bufs;
   DevBuf d_energy, d_counts, d_scalars, d_next;
+  // launches on different streams may be in flight together (a caller overlapping one
+  // batch's drain with the next batch): each takes its own work counter from a small ring
+  static constexpr unsigned kCounters = 16;
+  unsigned launch_seq = 0;
+  std::unique_ptr<DevBuf> d_carry;   // CarrySlot per work-item of the grid (r3d_run_device_carry)
+  bool carry_pending = false;
+  uint64_t carry_seed = 0;
   std::unique_ptr<DevBuf> d_volume;
   size_t volume_len = 0;
   std::unique_ptr<DevBuf> d_evlog, d_evlog_count;
@@ -968,7 +1016,7 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   R3D_HIP_OK(e->d_energy.alloc_zero((size_t)std::max(1, e->n_seis) * e->n_bins * R3D_N_ENERGY * sizeof(double)));
   R3D_HIP_OK(e->d_counts.alloc_zero((size_t)std::max(1, e->n_seis) * e->n_bins * R3D_N_COUNT * sizeof(uint64_t)));
   R3D_HIP_OK(e->d_scalars.alloc_zero(R3D_N_SCALARS * sizeof(uint64_t)));
-  R3D_HIP_OK(e->d_next.alloc_zero(sizeof(unsigned long long)));
+  R3D_HIP_OK(e->d_next.alloc_zero(r3d_engine::kCounters * sizeof(unsigned long long)));
   R3D_HIP_OK(hipStreamCreate(&e->stream));
   R3D_HIP_OK(hipEventCreate(&e->ev0));
   R3D_HIP_OK(hipEventCreate(&e->ev1));
@@ -984,22 +1032,40 @@ void r3d_engine_destroy(r3d_engine* e) {
 size_t r3d_energy_len(const r3d_engine* e) { return e ? (size_t)e->n_seis * e->n_bins * R3D_N_ENERGY : 0; }
 size_t r3d_counts_len(const r3d_engine* e) { return e ? (size_t)e->n_seis * e->n_bins * R3D_N_COUNT : 0; }
 
+// carry: 0 none, 1 resume carried histories and park the unfinished ones, 2 resume and finish all
 static int enqueue(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, double* d_energy,
-                   uint64_t* d_counts, uint64_t* d_scalars, r3d_final* d_finals, hipStream_t s) {
+                   uint64_t* d_counts, uint64_t* d_scalars, r3d_final* d_finals, hipStream_t s,
+                   int carry = 0) {
   const int fail_value = 1;
   if (!e) return g_error = "null engine", 1;
   if (!d_energy || !d_counts || !d_scalars) return g_error = "null result buffer", 1;
   R3D_HIP_OK(hipSetDevice(e->device));
   KArgs a = e->args;
   a.n = n, a.first_id = first_id, a.seed = seed;
-  a.next = reinterpret_cast<unsigned long long*>(e->d_next.p);
+  a.next = reinterpret_cast<unsigned long long*>(e->d_next.p) + (e->launch_seq++ % r3d_engine::kCounters);
   a.energy = d_energy;
   a.counts = reinterpret_cast<unsigned long long*>(d_counts);
   a.scalars = reinterpret_cast<unsigned long long*>(d_scalars);
   a.finals = d_finals;
-  R3D_HIP_OK(hipMemsetAsync(e->d_next.p, 0, sizeof(unsigned long long), s));
+  a.carry_in = a.carry_out = nullptr;
+  bool must_launch = n > 0;
+  if (carry) {
+    if (d_finals) return g_error = "final records and carry-over cannot be combined", 1;
+    if (e->carry_pending && seed != e->carry_seed)
+      return g_error = "carried histories were started under another seed", 1;
+    if (!e->d_carry) {
+      auto buf = std::make_unique<DevBuf>();
+      R3D_HIP_OK(buf->alloc_zero((size_t)e->grid_blocks * kBlock * sizeof(CarrySlot)));
+      e->d_carry = std::move(buf);
+    }
+    if (e->carry_pending) a.carry_in = e->d_carry->p, must_launch = true;
+    if (carry == 1) a.carry_out = e->d_carry->p;
+    e->carry_pending = (carry == 1) && (n > 0 || e->carry_pending);
+    e->carry_seed = seed;
+  }
+  R3D_HIP_OK(hipMemsetAsync(a.next, 0, sizeof(unsigned long long), s));
   R3D_HIP_OK(hipEventRecord(e->ev0, s));
-  if (n > 0) R3D_HIP_OK(launch_any(e, a, d_finals != nullptr || a.evlog != nullptr, s));
+  if (must_launch) R3D_HIP_OK(launch_any(e, a, d_finals != nullptr || a.evlog != nullptr, s));
   R3D_HIP_OK(hipEventRecord(e->ev1, s));
   e->timed = true;
   return 0;
@@ -1011,6 +1077,12 @@ int r3d_run_device(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, 
   // default stream is, so later work queued there is ordered after the kernel.
   return enqueue(e, n, first_id, seed, d_energy, d_counts, d_scalars, d_finals,
                  reinterpret_cast<hipStream_t>(stream));
+}
+
+int r3d_run_device_carry(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, double* d_energy,
+                         uint64_t* d_counts, uint64_t* d_scalars, void* stream, int final) {
+  return enqueue(e, n, first_id, seed, d_energy, d_counts, d_scalars, nullptr,
+                 reinterpret_cast<hipStream_t>(stream), final ? 2 : 1);
 }
 
 static int run_host(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, r3d_result* out,

@@ -153,6 +153,10 @@ struct KArgs {
   uint64_t evlog_cap;
   uint32_t evlog_mask;
   uint32_t pad2_;
+  // optional carry-over of unfinished histories between launches (null = off): one CarrySlot
+  // per work-item of the grid, see r3d_engine.hip
+  void* carry_in;
+  void* carry_out;
   // scheduling knobs (wave-uniform)
   uint32_t rt_batch;         // parked R/T lanes that trigger the solve (<= 1: never park)
   uint32_t refill_min;       // idle lanes that trigger a refill

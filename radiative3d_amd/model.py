@@ -237,11 +237,17 @@ class Engine:
         res._from_c(c)
         return (res, finals) if trace else res
 
-    def run_device(self, n, first_id, seed, d_energy, d_counts, d_scalars, stream=None):
+    def run_device(self, n, first_id, seed, d_energy, d_counts, d_scalars, stream=None, carry=None):
         """Asynchronous, device-resident accumulate (pointers are raw device
-        addresses, e.g. tensor.data_ptr())."""
-        rc = self._lib.r3d_run_device(self._e, n, first_id, seed, d_energy, d_counts, d_scalars,
-                                      None, stream)
+        addresses, e.g. tensor.data_ptr()).  carry: None (a self-contained launch),
+        "carry" (one of a chain: unfinished histories stay in the engine for its next
+        launch) or "final" (resume and finish everything carried); see r3d_run_device_carry."""
+        if carry is not None:
+            rc = self._lib.r3d_run_device_carry(self._e, n, first_id, seed, d_energy, d_counts, d_scalars,
+                                                stream, 1 if carry == "final" else 0)
+        else:
+            rc = self._lib.r3d_run_device(self._e, n, first_id, seed, d_energy, d_counts, d_scalars,
+                                          None, stream)
         if rc:
             raise RuntimeError("r3d_run_device failed: " + self._lib.r3d_last_error().decode())
 

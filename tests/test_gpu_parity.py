@@ -191,3 +191,39 @@ def test_invalid_phonons_are_reported_like_the_oracle(engines):
     ev = e.read_event_log()
     e.set_event_log(mask=0, capacity=0)
     assert len(ev) == rg.n_invalid and set(ev["tag"]) == {7}
+
+
+@pytest.mark.parametrize("name,n,parts", [("crustpinch", 400000, 4), ("lopnor", 300000, 3), ("sphere", 20000, 5)])
+def test_carry_chain_equals_one_run(engines, name, n, parts):
+    """r3d_run_device_carry: a chain of launches that hand their unfinished histories to the
+    next launch, then a flush, sums to exactly what one self-contained run of the same ids
+    gives; the pieces themselves differ (a launch holds what it executed)."""
+    e = engines(name)
+    want = e.run(n, first_id=5, seed=77)
+    total, step = DeviceResult(e.model, "cuda:0"), DeviceResult(e.model, "cuda:0")
+    per = n // parts
+    first_piece = None
+    for k in range(parts):
+        step.zero_()
+        e.run_device(per, 5 + k * per, 77, *step.pointers(), carry="carry")
+        torch.cuda.synchronize()
+        if k == 0:
+            first_piece = step.to_result()
+        total.add_(step)
+    step.zero_()
+    e.run_device(n - per * parts, 5 + per * parts, 77, *step.pointers(), carry="final")   # flush (n may be 0)
+    torch.cuda.synchronize()
+    total.add_(step)
+    got = total.to_result()
+    assert (got.counts == want.counts).all() and got.events == want.events
+    assert (got.n_lost, got.n_timeout, got.n_invalid) == (want.n_lost, want.n_timeout, want.n_invalid)
+    assert np.allclose(got.energy, want.energy, rtol=1e-11, atol=1e-300)
+    # the first launch started `per` histories but left some unfinished for the second
+    assert first_piece.events["generated"] == per
+    assert first_piece.n_lost + first_piece.n_timeout + first_piece.n_invalid < per
+    # a chain under another seed is refused while histories are pending
+    e.run_device(1000, 10**9, 77, *step.pointers(), carry="carry")
+    with pytest.raises(RuntimeError, match="another seed"):
+        e.run_device(1000, 10**9 + 1000, 78, *step.pointers(), carry="carry")
+    e.run_device(0, 0, 77, *step.pointers(), carry="final")
+    torch.cuda.synchronize()
