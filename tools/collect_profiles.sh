@@ -37,32 +37,6 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_
   i=$((i+1))
   timeout -k 10 400 rocprofv3 --pmc $set -d $out/pmc$i -o pmc --output-format csv -- $B > $out/pmc$i.log 2>&1
 done
-python3 - $out <<'PY'
-import csv, glob, json, sys, collections
-out = sys.argv[1]
-res = {}
-kern = None
-for f in sorted(glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True)):
-    acc = collections.defaultdict(lambda: collections.defaultdict(float))
-    for row in csv.DictReader(open(f)):
-        if "propagate_kernel" not in row["Kernel_Name"]:
-            continue
-        acc[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
-        if kern is None:
-            kern = {k: row[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size",
-                                        "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count") if k in row}
-    for name, per in acc.items():
-        v = list(per.values())
-        res[name] = {"dispatches": len(v), "mean_per_dispatch": sum(v) / len(v), "min": min(v), "max": max(v)}
-res["_kernel"] = kern
-if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
-    res["hbm_traffic_bytes_per_launch"] = 1024.0 * (res["FETCH_SIZE"]["mean_per_dispatch"] + res["WRITE_SIZE"]["mean_per_dispatch"])
-res["_note"] = ("rocprofv3 --pmc passes of `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline` (one pass per "
-                "counter group, no tracing). FETCH_SIZE / WRITE_SIZE are in KiB per dispatch (one dispatch = 1e7 "
-                "histories). The gfx950 x2 FETCH_SIZE correction of MI355X_MICROARCH.md applies to wide coalesced "
-                "streams only; this kernel's reads are 8-16 B gathers, so the value is left uncorrected.")
-json.dump(res, open(out + "/pmc_counters_bench_nscp_deg9.json", "w"), indent=1)
-print(json.dumps({k: v for k, v in res.items() if k.startswith("hbm") or k == "_kernel"}, indent=1))
-PY
+python3 tools/pmc_summary.py $out
 head -3 $out/kernel_stats_bench_nscp_deg9.csv
 tail -1 $out/bench_line_under_rocprofv3.json | cut -c1-300
