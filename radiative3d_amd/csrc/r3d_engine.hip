@@ -60,12 +60,12 @@ constexpr unsigned kRefillMin = R3D_REFILL_MIN;   // idle lanes that trigger a r
 #endif
 constexpr unsigned kRtBatch = R3D_RT_BATCH;      // parked R/T lanes that trigger the solve (<= 1: no parking)
 #ifndef R3D_MOVES_PER_ITER
-#define R3D_MOVES_PER_ITER 2
+#define R3D_MOVES_PER_ITER 3
 #endif
-// Moves a lane may make per loop iteration (see the loop).  Measured at TOA degree 9, 1 -> 2
-// moves: NSCP 26.0 -> 24.9 ms, Halfspace 6.5 -> 5.5 ms, LopNor unchanged, SphereEarth 60.8 ->
-// 66 ms (few plain hand-overs there, and the loop costs registers): the spherical kernel
-// keeps one move per iteration.
+// Moves a lane may make per loop iteration (see the loop).  Measured at TOA degree 9 on chained
+// launches, 1 / 2 / 3 / 4 moves: NSCP 19.5 / 16.8 / 16.4 / 16.5 ms per 1e7; LopNor flat; on
+// self-contained launches SphereEarth 60.8 -> 66 ms with 2 (few plain hand-overs there, and the
+// loop costs registers): the spherical kernel keeps one move per iteration.
 constexpr int kMovesPerIterLayeredTetra = R3D_MOVES_PER_ITER;
 #ifndef R3D_MOVE_AGAIN_MIN
 #define R3D_MOVE_AGAIN_MIN 16
