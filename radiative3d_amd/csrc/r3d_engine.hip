@@ -429,10 +429,11 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
     while (refill_now && need != 0ull && !drained) {
       if (w_next == w_end) {
         // claim ids: 256 at a time while the batch is far from its end, tapering to 64 so
-        // that no wave sits on unstarted histories while others have run dry
+        // that no wave sits on unstarted histories while others have run dry (judged from
+        // where this wave's previous claim ended: no extra look at the counter)
         unsigned long long base = 0, chunk = kChunk;
         if (lane == 0) {
-          const unsigned long long seen = __hip_atomic_load(a.next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long seen = w_end;   // (where this wave's previous claim ended: a lower bound)
           const unsigned long long left = (seen < a.n) ? a.n - seen : 0ull;
           const unsigned long long share = left / (2ull * gridDim.x * kWaves);   // per wave, halved
           chunk = (share >= kChunk) ? kChunk : (share >= 128ull ? 128ull : 64ull);
