@@ -304,7 +304,7 @@ struct CarrySlot {
 // alone would not fit the CU's 160 KB).
 enum { RES_ALL = 0, RES_TABLES = 1, RES_NONE = 2 };
 template <int KIND, int RES, bool TRACE>
-__global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
+__device__ __forceinline__ void propagate_body(const KArgs& a) {
   using Cell = typename CellOf<KIND>::type;
   constexpr bool LDS_CELLS = (RES == RES_ALL), LDS_TABLES = (RES != RES_NONE);
   extern __shared__ __align__(16) unsigned char smem[];
@@ -643,6 +643,17 @@ __global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
     atomicAdd(a.scalars + threadIdx.x, s_tally[threadIdx.x]);
 }
 
+// The traversal kernel, and the same body under a second name for the flush launch of a carry
+// chain (no new ids, only the histories carried over), so that profiles list the two apart.
+template <int KIND, int RES, bool TRACE>
+__global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
+  propagate_body<KIND, RES, TRACE>(a);
+}
+template <int KIND, int RES>
+__global__ __launch_bounds__(kBlock) void drain_kernel(const KArgs a) {
+  propagate_body<KIND, RES, false>(a);
+}
+
 // ------------------------------------------------------------------- engine --
 thread_local std::string g_error;
 
@@ -755,10 +766,12 @@ hipError_t with_kernel(const r3d_engine* e, F&& f) {
   }
 }
 
-hipError_t launch_any(r3d_engine* e, const KArgs& a, bool trace, hipStream_t s) {
+hipError_t launch_any(r3d_engine* e, const KArgs& a, bool trace, hipStream_t s, bool drain_only = false) {
   return with_kernel(e, [&](auto kind, auto res) {
     constexpr int K = decltype(kind)::value, R = decltype(res)::value;
-    if (trace)
+    if (drain_only && !trace)
+      hipLaunchKernelGGL((drain_kernel<K, R>), dim3(e->grid_blocks), dim3(kBlock), e->lds_bytes, s, a);
+    else if (trace)
       hipLaunchKernelGGL((propagate_kernel<K, R, true>), dim3(e->grid_blocks), dim3(kBlock), e->lds_bytes, s, a);
     else
       hipLaunchKernelGGL((propagate_kernel<K, R, false>), dim3(e->grid_blocks), dim3(kBlock), e->lds_bytes, s, a);
@@ -771,6 +784,9 @@ hipError_t set_lds_attr(const r3d_engine* e) {
     constexpr int K = decltype(kind)::value, R = decltype(res)::value;
     hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_kernel<K, R, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
+    if (r != hipSuccess) return r;
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(&drain_kernel<K, R>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
     if (r != hipSuccess) return r;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_kernel<K, R, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
@@ -1066,7 +1082,8 @@ static int enqueue(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, 
   }
   R3D_HIP_OK(hipMemsetAsync(a.next, 0, sizeof(unsigned long long), s));
   R3D_HIP_OK(hipEventRecord(e->ev0, s));
-  if (must_launch) R3D_HIP_OK(launch_any(e, a, d_finals != nullptr || a.evlog != nullptr, s));
+  if (must_launch)
+    R3D_HIP_OK(launch_any(e, a, d_finals != nullptr || a.evlog != nullptr, s, /*drain_only*/ carry == 2 && n == 0));
   R3D_HIP_OK(hipEventRecord(e->ev1, s));
   e->timed = true;
   return 0;

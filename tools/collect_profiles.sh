@@ -12,18 +12,18 @@ B="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/trace -o bench --output-format csv -- $B > $out/bench_line_under_rocprofv3.json 2> $out/trace.log
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats_bench_nscp_deg9.csv
 cp $(find $out/trace -name "*domain_stats.csv" | head -1) $out/domain_stats_bench_nscp_deg9.csv 2>/dev/null || true
-# per-launch durations of the traversal kernel, in launch order: with --steps 5 --warmup 1 the
-# sequence is 1 warm-up step, its flush, 5 timed steps, their flush (bench.py chains the steps:
-# r3d_run_device_carry); the flush launches run only the stragglers
+# per-launch durations of the traversal kernel, in launch order (bench.py chains the steps,
+# r3d_run_device_carry: step launches are propagate_kernel, the flush launches that run only the
+# stragglers are drain_kernel)
 python3 - $out <<'PY'
 import csv, glob, json, sys
 out = sys.argv[1]
 f = sorted(glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True))[0]
-rows = [r for r in csv.DictReader(open(f)) if "propagate_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(f)) if "propagate_kernel" in r["Kernel_Name"] or "drain_kernel" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ms = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
-kinds = ["warmup step", "flush"] + ["timed step"] * (len(ms) - 3) + ["flush"] if len(ms) >= 4 else ["?"] * len(ms)
-steps = [m for m, k in zip(ms, kinds) if k.endswith("step")]
+kinds = ["flush" if "drain_kernel" in r["Kernel_Name"] else "step" for r in rows]
+steps = [m for m, k in zip(ms, kinds) if k == "step"]
 flushes = [m for m, k in zip(ms, kinds) if k == "flush"]
 json.dump({"launches_ms": [{"kind": k, "ms": round(m, 4)} for m, k in zip(ms, kinds)],
            "step_launch_avg_ms": sum(steps) / max(1, len(steps)),

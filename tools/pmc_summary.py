@@ -1,7 +1,7 @@
 """Summarise the rocprofv3 --pmc passes of tools/collect_profiles.sh (DIR/pmc*/): per-dispatch
-counter values of the traversal kernel, in dispatch order.  bench.py chains its steps
-(r3d_run_device_carry), so with --steps 5 --warmup 1 the dispatches are: warm-up step, flush,
-5 timed steps, flush; the step launches and the flush launches are averaged separately."""
+counter values of the traversal kernel.  bench.py chains its steps (r3d_run_device_carry): the
+step launches are propagate_kernel dispatches, the chain's flush launches (stragglers only)
+drain_kernel dispatches; they are averaged separately."""
 import collections
 import csv
 import glob
@@ -12,7 +12,10 @@ out = sys.argv[1]
 res, kern = {}, None
 for f in sorted(glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    drain = collections.defaultdict(lambda: collections.defaultdict(float))
     for row in csv.DictReader(open(f)):
+        if "drain_kernel" in row["Kernel_Name"]:
+            drain[row["Counter_Name"]][int(row["Dispatch_Id"])] += float(row["Counter_Value"])
         if "propagate_kernel" not in row["Kernel_Name"]:
             continue
         acc[row["Counter_Name"]][int(row["Dispatch_Id"])] += float(row["Counter_Value"])
@@ -20,10 +23,9 @@ for f in sorted(glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=Tr
             kern = {k: row[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size",
                                         "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count") if k in row}
     for name, per in acc.items():
-        v = [per[k] for k in sorted(per)]
-        flush = [v[1], v[-1]] if len(v) >= 4 else []
-        steps = [x for i, x in enumerate(v) if not (len(v) >= 4 and i in (1, len(v) - 1))]
-        res[name] = {"dispatches": len(v), "step_launches": len(steps),
+        steps = [per[k] for k in sorted(per)]
+        flush = list(drain[name].values())
+        res[name] = {"dispatches": len(steps) + len(flush), "step_launches": len(steps),
                      "mean_per_dispatch": sum(steps) / len(steps), "min": min(steps), "max": max(steps),
                      "flush_launch_mean": (sum(flush) / len(flush)) if flush else None}
 res["_kernel"] = kern
