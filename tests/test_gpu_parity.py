@@ -227,3 +227,44 @@ def test_carry_chain_equals_one_run(engines, name, n, parts):
         e.run_device(1000, 10**9 + 1000, 78, *step.pointers(), carry="carry")
     e.run_device(0, 0, 77, *step.pointers(), carry="final")
     torch.cuda.synchronize()
+
+
+def test_launches_in_flight_on_two_streams(engines):
+    """Self-contained r3d_run_device launches of one engine on different streams, into
+    different buffers, may overlap (each takes its own work counter): same sums as one run."""
+    e = engines("crustpinch")
+    n, parts = 240000, 6
+    want = e.run(n, first_id=0, seed=5)
+    streams = [torch.cuda.Stream("cuda:0") for _ in range(2)]
+    bufs = [DeviceResult(e.model, "cuda:0") for _ in range(2)]
+    per = n // parts
+    for k in range(parts):
+        with torch.cuda.stream(streams[k % 2]):
+            e.run_device(per, k * per, 5, *bufs[k % 2].pointers(), stream=streams[k % 2].cuda_stream)
+    torch.cuda.synchronize()
+    got = bufs[0].add_(bufs[1]).to_result()
+    assert (got.counts == want.counts).all() and got.events == want.events
+    assert np.allclose(got.energy, want.energy, rtol=1e-11, atol=1e-300)
+
+
+def test_report_stream_over_a_carry_chain(engines):
+    """Histories that span two launches of a chain keep their event order in the report buffer."""
+    e = engines("lopnor")
+    n = 6000
+    _, ev_o, total = O.run_with_events(e.model, n, capacity=1 << 20)
+    e.set_event_log(capacity=1 << 20)
+    buf = DeviceResult(e.model, "cuda:0")
+    for k in range(3):
+        e.run_device(n // 3, k * (n // 3), 0x5EED, *buf.pointers(), carry="carry")
+    e.run_device(0, 0, 0x5EED, *buf.pointers(), carry="final")
+    torch.cuda.synchronize()
+    ev_g = e.read_event_log(reset=True)
+    e.set_event_log(mask=0, capacity=0)
+    assert len(ev_g) == total
+
+    def by_history(ev):
+        order = np.argsort(ev["id"], kind="stable")
+        return ev[order]
+    a, b = by_history(ev_o), by_history(ev_g)
+    assert np.array_equal(a["id"], b["id"]) and np.array_equal(a["tag"], b["tag"])
+    assert np.array_equal(a["moves"], b["moves"]) and np.allclose(a["time"], b["time"], rtol=1e-9, atol=1e-9)
