@@ -148,3 +148,21 @@ def test_main_cli_report_file_on_gpu(tmp_path):
         assert num.sub("#", a).split() == num.sub("#", b).split(), (a, b)
         va, vb = [float(x) for x in num.findall(a)], [float(x) for x in num.findall(b)]
         assert np.allclose(va, vb, rtol=1e-5, atol=1e-9), (a, b)
+
+
+@pytest.mark.gpu
+def test_plain_c_example_runs_on_gpu(tmp_path):
+    """examples/run_model.c: model from option tokens, r3d_run_model, the reference's files."""
+    exe = str(tmp_path / "run_model")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(repo, "radiative3d_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(repo, "include"),
+                           os.path.join(repo, "examples", "run_model.c"), "-L", lib, "-lr3d_host", "-lr3d_hip",
+                           "-L/opt/rocm/lib", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe, "1", str(tmp_path)] + halfspace(4) + ["--num-phonons=50K", "--seed=3"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = Model(halfspace(4))
+    want = O.run(m, 50000, seed=3)
+    assert f"lost {want.n_lost} timeout {want.n_timeout} invalid {want.n_invalid}" in out.stdout
+    assert os.path.exists(tmp_path / "seis_000.octv") and os.path.exists(tmp_path / "seis_traces_asc.dat")
