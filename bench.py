@@ -136,6 +136,9 @@ def main():
     ap.add_argument("--histories", type=int, default=10_000_000, help="histories per GPU per step")
     ap.add_argument("--toa-degree", type=int, default=9)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--self-contained", action="store_true",
+                    help="every step a self-contained launch that drains its own stragglers "
+                         "(default: steps chained, one flush launch at the end of the timed region)")
     args = ap.parse_args()
 
     import torch
@@ -194,13 +197,16 @@ def main():
         step_res.zero_()
         if events is not None:
             events[0].record(stream)
-        engine.run_device(n, first, seed, *step_res.pointers(), stream=stream.cuda_stream, carry="carry")
+        engine.run_device(n, first, seed, *step_res.pointers(), stream=stream.cuda_stream,
+                          carry=None if args.self_contained else "carry")
         if events is not None:
             events[1].record(stream)
         step_res.allreduce_()     # no-op at world == 1
         result.add_(step_res)
 
     def flush():
+        if args.self_contained:
+            return
         step_res.zero_()
         engine.run_device(0, 0, seed, *step_res.pointers(), stream=stream.cuda_stream, carry="final")
         step_res.allreduce_()
@@ -253,8 +259,9 @@ def main():
                        "histories_per_gpu_per_step": n, "toa_degree": args.toa_degree,
                        "cells": model.n_cells, "scatterers": model.n_scatterers,
                        "parallelism": f"history-id shards x{world}, one all-reduce of the bins per step; "
-                                      "steps chained (unfinished histories carried into the next "
-                                      "step's launch, one flush launch at the end, inside the timed region)"},
+                                      + ("every step a self-contained launch" if args.self_contained else
+                                         "steps chained (unfinished histories carried into the next "
+                                         "step's launch, one flush launch at the end, inside the timed region)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": recorded_hbm_traffic(args.toa_degree, n),
