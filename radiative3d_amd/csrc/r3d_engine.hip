@@ -1,22 +1,25 @@
 // r3d_engine.hip -- the MI355X (gfx950) phonon-transport engine: persistent
 // traversal kernel + the C-ABI of include/r3d.h.
 //
-// Kernel design (one phonon per work-item, 64-wide wavefronts):
-//   * persistent grid: a few workgroups per CU; each WAVE pulls chunks of
+// Kernel design (one phonon per work-item, 64-wide wavefronts; DESIGN.md section 4):
+//   * persistent grid, one 768-thread workgroup per CU; each WAVE pulls chunks of
 //     history ids from one global counter (one atomic per 256 histories) and
 //     deals them to its lanes with a ballot + prefix-popcount, so a lane whose
-//     history ended is refilled at the next iteration and the wave stays full
-//     until the id range is exhausted;
-//   * every iteration all live lanes run the same sequence: boundary search ->
-//     free-path draw -> advance; only the event handling after it (scatter /
-//     collect / reflect-transmit / bend) diverges;
-//   * small read-only tables (cells of layered and spherical models, the
-//     scatterer heads, the seismometer scan records) are staged in LDS once
+//     history ended is refilled within a few iterations and the wave stays full
+//     until the id range is exhausted; what is still in flight then can be carried
+//     into the engine's next launch instead of draining the GPU (CarrySlot);
+//   * every iteration all running lanes do the same thing: boundary search ->
+//     free-path draw -> advance (up to three times when a move ends in a plain
+//     hand-over); then the receivers, the light events, and -- for the lanes that
+//     parked for it -- the reflection / transmission solve;
+//   * small read-only tables (cells of layered and spherical models, scatterer
+//     heads, receiver scan / hit records, the receiver hash) are staged in LDS once
 //     per workgroup; tetra cells (0.6 MB for the crust-pinch model), CDFs
 //     (GBs at TOA degree 9) and bins stay in HBM / L2;
-//   * bins are accumulated with native fp64 / u64 global atomics;
+//   * bins are accumulated through per-workgroup LDS accumulators and per-wave
+//     catch queues into native fp64 / u64 global atomics;
 //   * RNG is counter-based Philox keyed by history id (r3d_rng.h): results are
-//     independent of lane, wave, launch geometry and GPU count.
+//     independent of lane, wave, launch geometry, launch boundaries and GPU count.
 //
 // The product has no CPU path: without a HIP device every entry point fails
 // with an error message.
@@ -517,9 +520,8 @@ __device__ __forceinline__ void propagate_body(const KArgs& a) {
     R3D_STAMP(1);  // move
     report(moved && (ev.flags & F_COLLECT) != 0, 3, p);   // COL: the incident state
 
-    // ---- seismometers.  Each arriving lane looks up its own hash cell (the loads of
-    //      different lanes overlap); then the wave serves the arrivals that have
-    //      candidate receivers one at a time, 64 candidates per pass ----
+    // ---- seismometers.  Each arriving lane looks up its own hash cell; the wave then deals
+    //      all (arrival, candidate receiver) pairs to its lanes, 64 per pass (collect_pairs) ----
     uint32_t k0 = 0, k1 = 0;
     if (moved && (ev.flags & F_COLLECT)) {
       st.collect++;
