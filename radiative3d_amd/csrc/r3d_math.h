@@ -29,6 +29,36 @@ R3D_HD double pos_inf() { return __builtin_inf(); }
 inline double rsqrt(double x) { return 1.0 / sqrt(x); }   // device builds use the HIP intrinsic
 #endif
 
+// Square root and reciprocal square root for the hot path.  The device library's versions
+// spend half of their ~20 instructions on re-scaling for subnormal and huge arguments, which
+// the quantities here (squared lengths of O(1) vectors, 1 - cos^2) never are: v_rsq_f64 plus
+// Newton steps gives the same result to an ulp in 8 resp. 12 instructions, and the traversal
+// kernel is bound by instruction issue.  0 -> 0 resp. inf (NaN through the Newton step, as
+// every caller selects around a zero argument); negative -> NaN.  On the host: libm.
+R3D_HD double frsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  y = __builtin_fma(y, __builtin_fma(-h * y, y, 0.5), y);
+  y = __builtin_fma(y, __builtin_fma(-h * y, y, 0.5), y);
+  return y;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+R3D_HD double fsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(x);
+  y = __builtin_fma(y, __builtin_fma(-0.5 * x * y, y, 0.5), y);   // 1 / sqrt(x) to ~2^-50
+  double g = x * y;
+  const double d = __builtin_fma(-g, g, x);                       // residual of g^2 against x
+  g = __builtin_fma(d, 0.5 * y, g);
+  return (x == 0.0) ? 0.0 : g;
+#else
+  return sqrt(x);
+#endif
+}
+
 struct V3 {
   double x, y, z;
 };
@@ -43,10 +73,10 @@ R3D_HD V3 cross(V3 a, V3 b) {
   return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 R3D_HD double mag2(V3 a) { return dot(a, a); }
-R3D_HD double mag(V3 a) { return sqrt(mag2(a)); }
+R3D_HD double mag(V3 a) { return fsqrt(mag2(a)); }
 R3D_HD bool is_zero(V3 a) { return a.x == 0 && a.y == 0 && a.z == 0; }
 R3D_HD V3 unit(V3 a) {
-  double s = rsqrt(mag2(a));
+  double s = frsqrt(mag2(a));
   return s * a;
 }
 R3D_HD V3 unit_else(V3 a, V3 fallback) {  // reference geom_r3.hpp:127-132
@@ -61,9 +91,9 @@ R3D_HD V3 unit_else(V3 a, V3 fallback) {  // reference geom_r3.hpp:127-132
 // rescaled to sqrt(1 - z^2).  `v` must already be (very nearly) unit length.
 R3D_HD V3 through_angles(V3 v) {
   double h2 = v.x * v.x + v.y * v.y;
-  double st = sqrt(fmax(0.0, 1.0 - v.z * v.z));
+  double st = fsqrt(fmax(0.0, 1.0 - v.z * v.z));
   if (h2 == 0) return v3(st, 0.0, v.z);  // atan2(0,0) = 0
-  double s = st * rsqrt(h2);
+  double s = st * frsqrt(h2);
   return v3(s * v.x, s * v.y, v.z);
 }
 
@@ -71,8 +101,8 @@ R3D_HD V3 through_angles(V3 v) {
 // geom_r3.cpp:222-224).
 R3D_HD void sph_basis(V3 d, V3& th_hat, V3& ph_hat) {
   double h2 = d.x * d.x + d.y * d.y;
-  double st = sqrt(h2);
-  double ih = (h2 != 0) ? rsqrt(h2) : 0.0;
+  double st = fsqrt(h2);
+  double ih = (h2 != 0) ? frsqrt(h2) : 0.0;
   double cp = (h2 != 0) ? d.x * ih : 1.0, sp = d.y * ih;
   th_hat = v3(d.z * cp, d.z * sp, -st);
   ph_hat = v3(-sp, cp, 0.0);
@@ -113,7 +143,7 @@ R3D_HD double norm(Cx a) { return a.re * a.re + a.im * a.im; }  // squared modul
 // sqrt of the real number s as a complex number (principal branch):
 // post-critical cosines come out purely imaginary (rtcoef.cpp:312-318).
 R3D_HD Cx sqrt_real(double s) {
-  const double r = sqrt(fabs(s));   // one root, then placed (not one root per branch)
+  const double r = fsqrt(fabs(s));   // one root, then placed (not one root per branch)
   return s >= 0 ? cx(r, 0.0) : cx(0.0, r);
 }
 

@@ -61,7 +61,7 @@ R3D_HD void set_pol(Phonon& p, V3 pdom, V3 d) {
   sph_basis(d, th, ph);
   const double x = dot(pdom, th), y = dot(pdom, ph);
   const double h2 = x * x + y * y;
-  const double ih = rsqrt(h2);
+  const double ih = frsqrt(h2);
   p.pc = (h2 == 0) ? 1.0 : x * ih;   // atan2(0, 0) = 0
   p.ps = (h2 == 0) ? 0.0 : y * ih;
 }
@@ -143,7 +143,7 @@ R3D_HD TetArc tet_arc(const CellTet& c, const Phonon& p) {
   // (media.hpp:574-580), i.e. centre = loc + R tz' v1 - R tx' v3.
   const double px = -A.R * tzp, pz = A.R * txp;
   A.center = p.loc + ((-px) * A.v1 + (-pz) * A.v3);
-  double h = 1.0 / sqrt(px * px + pz * pz);
+  double h = frsqrt(px * px + pz * pz);
   A.s0 = px * h, A.c0 = pz * h;
   return A;
 }
@@ -163,12 +163,12 @@ R3D_HD Gcad tet_face_arc(const double n[3], double dplane, const TetArc& A, doub
   const double inf = pos_inf();
   V3 nn = v3(n);
   const double rx = dot(nn, A.v1), rz = dot(nn, A.v3);      // in-plane components of the face normal
-  const double ir = rsqrt(rx * rx + rz * rz);
+  const double ir = frsqrt(rx * rx + rz * rz);
   const double sb = rx * ir, cb = rz * ir;                  // sin, cos of the bisector angle
   const double ratio = ((dplane - dot(nn, A.center)) * ir) * inv_R;   // cos q
   const bool front = cb > 0;            // bisector within (-pi/2, pi/2)
   const bool crosses = (ratio < 1) & (ratio > -1);
-  const double sq = sqrt(fmax(0.0, 1.0 - ratio * ratio));   // sin q > 0 when the circle crosses the plane
+  const double sq = fsqrt(fmax(0.0, 1.0 - ratio * ratio));   // sin q > 0 when the circle crosses the plane
   const double se = sb * ratio + cb * sq, ce = cb * ratio - sb * sq;   // entry = bis + q
   const double sx = sb * ratio - cb * sq, cx = cb * ratio + sb * sq;   // exit  = bis - q
   // an angle is inside (-pi/2, pi/2) iff its cosine is positive; which infinity
@@ -536,7 +536,7 @@ R3D_HD bool bend(Phonon& p, V3 fnorm, double veli, double velo) {
   if (sino >= 1.0) {
     transfer = false, sino = sini, coso = -1.0 * dot(fnorm, p.dir);
   } else {
-    transfer = true, coso = sqrt(1.0 - sino * sino);
+    transfer = true, coso = fsqrt(1.0 - sino * sino);
   }
   V3 out = sino * fpara + coso * fnorm;
   const V3 nd = through_angles(unit(out));   // outdir.ThetaHat()/PhiHat() go through Theta()/Phi()
