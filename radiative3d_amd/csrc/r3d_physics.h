@@ -83,7 +83,7 @@ R3D_HD double cylwall_exit(double rad2, V3 loc, V3 dir) {
   double B = 2 * (loc.x * dir.x + loc.y * dir.y);
   double urad = B * B - 4 * A * C;
   if (urad < 0) return -pos_inf();
-  return (sqrt(urad) - B) / (2 * A);
+  return (fsqrt(urad) - B) / (2 * A);
 }
 // reference RCUCylinder::GetPathToBoundary, media.cpp:236-330.  Face ids:
 // 0 top, 1 bottom, 2 lateral wall (phonon is lost there).
@@ -258,7 +258,7 @@ R3D_HD double sph_linear_exit(double radius, V3 loc, V3 dir) {
   double midpt = -dot(loc, dir);
   double urad = radius * radius + midpt * midpt - mag2(loc);
   if (urad <= 0) return outward ? -pos_inf() : pos_inf();
-  double sq = sqrt(urad);
+  double sq = fsqrt(urad);
   if (outward) return midpt + sq;
   if (midpt <= 0) return pos_inf();
   return midpt - sq;
@@ -292,10 +292,10 @@ R3D_HD SphArc sph_arc(const CellSph& c, const double ec[3], const Phonon& p) {
   if (sini > 1.0) sini = 1.0;
   double cosi = dot(w3, p.dir);
   double r2 = mag2(p.loc);
-  const double G = sini * sqrt(r2) / (c.c[t] + c.a[t] * r2);
+  const double G = sini * fsqrt(r2) / (c.c[t] + c.a[t] * r2);
   const double TwoGA = 2. * G * c.a[t];
   const double urad = 1. - (2. * TwoGA * G * c.c[t]);
-  double bottom = (urad > 1) ? (1. - sqrt(urad)) / TwoGA : 0;
+  double bottom = (urad > 1) ? (1. - fsqrt(urad)) / TwoGA : 0;
   A.radius = (c.zero_rad2[t] / bottom - bottom) / 2.0;
   A.rad2 = A.radius * A.radius;
   A.center = p.loc + ((A.radius * cosi) * w1 + (-A.radius * sini) * w3);
@@ -307,10 +307,10 @@ R3D_HD SphArc sph_arc(const CellSph& c, const double ec[3], const Phonon& p) {
     A.u1 = p.dir;
   }
   A.S2 = mag2(A.center);
-  double S = sqrt(A.S2);
+  double S = fsqrt(A.S2);
   A.TwoSQ = 2 * S * A.radius;
   double cz = (A.S2 + A.radius * A.radius - c.zero_rad2[t]) / A.TwoSQ;
-  double sz = sqrt(1 - cz * cz);
+  double sz = fsqrt(1 - cz * cz);
   A.CotZetaBy2 = (1 + cz) / sz;
   A.timeCoef = -1 / (c.a[t] * S * sz);
   V3 cl = p.loc - A.center;
