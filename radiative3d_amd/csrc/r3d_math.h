@@ -59,6 +59,19 @@ R3D_HD double fsqrt(double x) {
 #endif
 }
 
+// arcsin for |x| <= 0.5: x + x t P(t) / Q(t), t = x^2 -- the classical rational
+// approximation (fdlibm e_asin.c, error below one ulp on this interval).  Used where a small
+// angle is known by its sine and the sign of its cosine (the arc length of a tetra leg):
+// a third of the instructions of the general atan2.
+R3D_HD double asin_small(double x) {
+  const double t = x * x;
+  const double p = t * (1.66666666666666657415e-01 + t * (-3.25565818622400915405e-01 + t * (2.01212532134862925881e-01 +
+                   t * (-4.00555345006794114027e-02 + t * (7.91534994289814532176e-04 + t * 3.47933107596021167570e-05)))));
+  const double q = 1.0 + t * (-2.40339491173441421878e+00 + t * (2.02094576023350569471e+00 +
+                   t * (-6.88283971605453293030e-01 + t * 7.70381505559019352791e-02)));
+  return x + x * (p / q);
+}
+
 struct V3 {
   double x, y, z;
 };

@@ -230,7 +230,9 @@ R3D_HD TetExit tet_exit(const CellTet& c, const TetArc& A) {
 // and cosine (both angles lie in [-pi/2, pi/2]).
 R3D_HD double tet_exit_length(const TetArc& A, const TetExit& e) {
   if (!(e.s > -pos_inf() && e.s < pos_inf())) return e.s;   // +-inf (NaN propagates)
-  return A.R * atan2(e.s * A.c0 - e.c * A.s0, e.c * A.c0 + e.s * A.s0);
+  const double sd = e.s * A.c0 - e.c * A.s0, cd = e.c * A.c0 + e.s * A.s0;   // sine, cosine of the arc angle
+  if (cd > 0 && fabs(sd) <= 0.5) return A.R * asin_small(sd);   // (the usual case: a leg spans a few degrees)
+  return A.R * atan2(sd, cd);
 }
 // reference Tetra::AdvanceLength (media.cpp:442-499) + Phonon::Move.  (s1, c1)
 // are the sine / cosine of the end angle: the exit's own for a boundary leg,
