@@ -297,6 +297,20 @@ def main():
             gpu_mom = batch_moments(g_e, g_c)
             cpu_mom = batch_moments([p.energy / per_thread for p in cpu_parts], [p.counts for p in cpu_parts])
             line["envelope"] = envelope_agreement(gpu_mom, cpu_mom, n_batch * nb, per_thread * len(cpu_parts))
+            # calibration of the statistic: the same comparison with the CPU sample replaced by an
+            # independent GPU sample of the CPU sample's batch structure (both sides the same code).
+            # With few, unequal batches and heavy-tailed bins it sits above 1; the GPU-vs-CPU figure
+            # is to be read against it.
+            c_e, c_c = [], []
+            for b in range(len(cpu_parts)):
+                step_res.zero_()
+                engine.run_device(per_thread, (1 << 52) + b * per_thread, seed, *step_res.pointers(),
+                                  stream=stream.cuda_stream)
+                torch.cuda.synchronize()
+                r = step_res.to_result()
+                c_e.append(r.energy / per_thread), c_c.append(r.counts)
+            twin = envelope_agreement(gpu_mom, batch_moments(c_e, c_c), n_batch * nb, per_thread * len(cpu_parts))
+            line["envelope"]["rms_sigma_gpu_vs_gpu_same_batches"] = twin["rms_sigma"]
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
