@@ -507,7 +507,10 @@ __device__ __forceinline__ void propagate_body(const KArgs& a) {
         if (++rep >= kMovesPerIter) break;
         const bool again = go && fate == FATE_ALIVE && ev.face >= 0 && (ev.flags & F_SMOOTH) != 0 &&
                            (ev.flags & F_ADJOIN) != 0 && (ev.flags & (F_COLLECT | F_REFLECT | F_DISCON)) == 0;
-        if ((unsigned)__popcll(__ballot(again)) < kMoveAgainMin) break;
+        // worth it for kMoveAgainMin lanes of a full wave -- or for half of the lanes that moved, in
+        // a wave that is running thin (the drain of a launch, the flush of a chain)
+        const unsigned n_again = (unsigned)__popcll(__ballot(again)), n_went = (unsigned)__popcll(__ballot(go));
+        if (n_again < kMoveAgainMin && 2u * n_again < n_went) break;
         tally(st.iterations != 0, kEv + R3D_EV_ITERATIONS);   // the move just made ...
         st.iterations = 0;
         tally(again, kEv + R3D_EV_TRANSFER);                  // ... and the hand-over taken here
