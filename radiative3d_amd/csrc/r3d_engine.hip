@@ -563,8 +563,11 @@ __device__ __forceinline__ void propagate_body(const KArgs& a) {
     R3D_STAMP(3);  // light events
     if (kPark) {
       const unsigned n_parked = (unsigned)__popcll(__ballot(parked));
-      const bool any_running = __any(alive && !parked && fate == FATE_ALIVE);
-      if (n_parked >= a.rt_batch || (n_parked > 0 && !any_running)) {
+      // (in a wave that is running thin -- the drain of a launch, the flush of a chain -- a third
+      //  of the lanes still alive is company enough: waiting for rt_batch there would stretch
+      //  the longest histories, which are what the drain waits for)
+      const unsigned n_alive = (unsigned)__popcll(__ballot(alive && fate == FATE_ALIVE));
+      if (n_parked >= a.rt_batch || (n_parked > 0 && 3u * n_parked >= n_alive)) {
         if (parked) {
           fate = step_event<KIND, EV_RT>(a, T, p, rng, st, ev);
           parked = false;
