@@ -145,7 +145,7 @@ def main():
     import torch.distributed as dist
     from radiative3d_amd import Engine, Model
     from radiative3d_amd.parallel import DeviceResult
-    from tests.configs import crustpinch
+    from radiative3d_amd.configs import crustpinch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

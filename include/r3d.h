@@ -210,6 +210,14 @@ typedef struct r3d_engine r3d_engine;   /* opaque: tables resident in HBM   */
  * one engine per thread.                                                   */
 r3d_engine* r3d_engine_create(const r3d_model_desc* model, int device);
 void        r3d_engine_destroy(r3d_engine* e);
+/* Checked form of destroy: waits for the engine's launches, and REFUSES (returns
+ * nonzero, engine left intact) while histories carried over by r3d_run_device_carry
+ * are still in it -- their tallies and bins would be lost; flush with final != 0
+ * first.  r3d_engine_destroy drops them and leaves a note in r3d_last_error.
+ * Every entry point makes the engine's device current for its own work and
+ * restores the caller's current device before it returns.                    */
+int         r3d_engine_close(r3d_engine* e);
+int         r3d_engine_carry_pending(const r3d_engine* e);   /* 1 if a chain awaits its flush */
 
 /* Scatterer s as the engine holds it: out[0..1] = MFP P, S; out[2..3] = dipole
  * moments P, S (scatterers.cpp:244-259; NaN for host-built tables, whose raw
@@ -299,6 +307,10 @@ size_t r3d_volume_len(const r3d_engine* e);            /* counters (0 if none) *
 int    r3d_volume_read(r3d_engine* e, uint32_t* out, int reset);
 /* Device address of the counters, for an RCCL reduction across ranks.        */
 void*  r3d_volume_device_ptr(r3d_engine* e);
+/* The same grid in CALLER-OWNED device memory (r3d_volume_len counters, zeroed
+ * by the caller; e.g. a torch tensor that is reduced over RCCL afterwards, as
+ * r3d_run_device does for the bins).  v == NULL detaches.                    */
+int    r3d_engine_set_volume_buffer(r3d_engine* e, const r3d_volume_desc* v, uint32_t* d_counters);
 
 /* ---- optional per-event report stream --------------------------------------
  * The reference's `--reports[=KEYWORDS]` (main.cpp:223-258) writes one text line
@@ -338,10 +350,16 @@ uint64_t r3d_event_log_count(r3d_engine* e);
  * (uint64_t)-1 on error.  reset != 0 empties the buffer afterwards.          */
 uint64_t r3d_event_log_read(r3d_engine* e, r3d_event* out, uint64_t max, int reset);
 
-/* Duration in milliseconds of the traversal kernel launches enqueued by the
- * most recent r3d_run / r3d_run_device call on this engine, measured with
- * HIP events on the engine's stream (blocks until they have completed).    */
-double r3d_last_kernel_ms(r3d_engine* e);
+/* Duration in milliseconds of the traversal kernel launch enqueued by the
+ * most recent r3d_run / r3d_run_device[_carry] call on this engine, measured
+ * with HIP events on the stream it was launched on (blocks until it has
+ * completed).  Launches are numbered from 1 in enqueue order: r3d_launch_count
+ * is the number so far, r3d_kernel_ms reads any of the 16 most recent (each has
+ * its own event pair, so overlapping launches on several streams are timed
+ * separately); -1 for a launch that is not on record.                        */
+double   r3d_last_kernel_ms(r3d_engine* e);
+uint64_t r3d_launch_count(const r3d_engine* e);
+double   r3d_kernel_ms(r3d_engine* e, uint64_t launch);
 
 /* Number of scalar counters r3d_run_device expects.                         */
 #define R3D_N_SCALARS (3 + R3D_INV_NUM + R3D_EV_NUM)

@@ -201,6 +201,16 @@ def hip_lib():
         L.r3d_event_log_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
         L.r3d_last_kernel_ms.restype = C.c_double
         L.r3d_last_kernel_ms.argtypes = [C.c_void_p]
+        L.r3d_launch_count.restype = C.c_uint64
+        L.r3d_launch_count.argtypes = [C.c_void_p]
+        L.r3d_kernel_ms.restype = C.c_double
+        L.r3d_kernel_ms.argtypes = [C.c_void_p, C.c_uint64]
+        L.r3d_engine_close.restype = C.c_int
+        L.r3d_engine_close.argtypes = [C.c_void_p]
+        L.r3d_engine_carry_pending.restype = C.c_int
+        L.r3d_engine_carry_pending.argtypes = [C.c_void_p]
+        L.r3d_engine_set_volume_buffer.restype = C.c_int
+        L.r3d_engine_set_volume_buffer.argtypes = [C.c_void_p, C.POINTER(VolumeDesc), C.c_void_p]
         L.r3d_last_error.restype = C.c_char_p
         L.r3d_version.restype = C.c_char_p
         _hip = L

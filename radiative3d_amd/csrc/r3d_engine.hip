@@ -674,6 +674,27 @@ thread_local std::string g_error;
     }                                                                                 \
   } while (0)
 
+// Entry points make the engine's device current for their own calls and restore the caller's
+// on return: a host program (or torch) whose current device differs from the engine's keeps it.
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t status;
+  explicit DeviceGuard(int device) {
+    status = hipGetDevice(&prev);
+    if (status != hipSuccess) prev = -1;
+    if (prev == device) prev = -1;   // nothing to switch, nothing to restore
+    else status = hipSetDevice(device);
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define R3D_ON_DEVICE(dev)          \
+  DeviceGuard guard__(dev);         \
+  R3D_HIP_OK(guard__.status)
+
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
@@ -709,18 +730,21 @@ struct r3d_engine {
   size_t lds_bytes = 0;
   int grid_blocks = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool timed = false;
   std::vector<std::unique_ptr<DevBuf>> bufs;
   DevBuf d_energy, d_counts, d_scalars, d_next;
   // launches on different streams may be in flight together (a caller overlapping one
   // batch's drain with the next batch): each takes its own work counter from a small ring
   static constexpr unsigned kCounters = 16;
   unsigned launch_seq = 0;
+  // ... and its own pair of timing events, so that r3d_kernel_ms(e, launch) reads the launch
+  // it names and not whichever recorded last
+  hipEvent_t ev0[kCounters] = {}, ev1[kCounters] = {};
+  uint64_t launches = 0;   // launches enqueued so far; launch id k used slot (k - 1) % kCounters
   std::unique_ptr<DevBuf> d_carry;   // CarrySlot per work-item of the grid (r3d_run_device_carry)
   bool carry_pending = false;
   uint64_t carry_seed = 0;
   std::unique_ptr<DevBuf> d_volume;
+  void* volume_ext = nullptr;   // caller-owned counters (r3d_engine_set_volume_buffer)
   size_t volume_len = 0;
   std::unique_ptr<DevBuf> d_evlog, d_evlog_count;
   struct ScatStats {
@@ -735,8 +759,10 @@ struct r3d_engine {
     return bufs.back().get();
   }
   ~r3d_engine() {
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
+    for (unsigned i = 0; i < kCounters; i++) {
+      if (ev0[i]) (void)hipEventDestroy(ev0[i]);
+      if (ev1[i]) (void)hipEventDestroy(ev1[i]);
+    }
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -860,7 +886,7 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
     g_error = "device index out of range";
     return nullptr;
   }
-  R3D_HIP_OK(hipSetDevice(device));
+  R3D_ON_DEVICE(device);
   auto e = std::make_unique<r3d_engine>();
   e->device = device;
   e->kind = m->cell_kind;
@@ -1043,14 +1069,34 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   R3D_HIP_OK(e->d_scalars.alloc_zero(R3D_N_SCALARS * sizeof(uint64_t)));
   R3D_HIP_OK(e->d_next.alloc_zero(r3d_engine::kCounters * sizeof(unsigned long long)));
   R3D_HIP_OK(hipStreamCreate(&e->stream));
-  R3D_HIP_OK(hipEventCreate(&e->ev0));
-  R3D_HIP_OK(hipEventCreate(&e->ev1));
+  for (unsigned i = 0; i < r3d_engine::kCounters; i++) {
+    R3D_HIP_OK(hipEventCreate(&e->ev0[i]));
+    R3D_HIP_OK(hipEventCreate(&e->ev1[i]));
+  }
   return e.release();
+}
+
+int r3d_engine_carry_pending(const r3d_engine* e) { return (e && e->carry_pending) ? 1 : 0; }
+
+int r3d_engine_close(r3d_engine* e) {
+  const int fail_value = 1;
+  if (!e) return 0;
+  if (e->carry_pending)
+    return g_error = "histories carried over from the last r3d_run_device_carry launch are still in the engine: "
+                     "flush them (final != 0) before closing it, or their tallies and bins are lost", 1;
+  {
+    R3D_ON_DEVICE(e->device);
+    R3D_HIP_OK(hipDeviceSynchronize());
+    delete e;
+  }
+  return 0;
 }
 
 void r3d_engine_destroy(r3d_engine* e) {
   if (!e) return;
-  (void)hipSetDevice(e->device);
+  if (e->carry_pending)   // (a void call cannot refuse: leave the fact where the caller can find it)
+    g_error = "r3d_engine_destroy: carried histories were dropped unflushed (see r3d_engine_close)";
+  DeviceGuard guard(e->device);
   delete e;
 }
 
@@ -1064,10 +1110,11 @@ static int enqueue(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, 
   const int fail_value = 1;
   if (!e) return g_error = "null engine", 1;
   if (!d_energy || !d_counts || !d_scalars) return g_error = "null result buffer", 1;
-  R3D_HIP_OK(hipSetDevice(e->device));
+  R3D_ON_DEVICE(e->device);
   KArgs a = e->args;
   a.n = n, a.first_id = first_id, a.seed = seed;
-  a.next = reinterpret_cast<unsigned long long*>(e->d_next.p) + (e->launch_seq++ % r3d_engine::kCounters);
+  const unsigned slot = e->launch_seq++ % r3d_engine::kCounters;
+  a.next = reinterpret_cast<unsigned long long*>(e->d_next.p) + slot;
   a.energy = d_energy;
   a.counts = reinterpret_cast<unsigned long long*>(d_counts);
   a.scalars = reinterpret_cast<unsigned long long*>(d_scalars);
@@ -1089,11 +1136,11 @@ static int enqueue(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, 
     e->carry_seed = seed;
   }
   R3D_HIP_OK(hipMemsetAsync(a.next, 0, sizeof(unsigned long long), s));
-  R3D_HIP_OK(hipEventRecord(e->ev0, s));
+  R3D_HIP_OK(hipEventRecord(e->ev0[slot], s));
   if (must_launch)
     R3D_HIP_OK(launch_any(e, a, d_finals != nullptr || a.evlog != nullptr, s, /*drain_only*/ carry == 2 && n == 0));
-  R3D_HIP_OK(hipEventRecord(e->ev1, s));
-  e->timed = true;
+  R3D_HIP_OK(hipEventRecord(e->ev1[slot], s));
+  e->launches++;
   return 0;
 }
 
@@ -1116,7 +1163,7 @@ static int run_host(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,
   const int fail_value = 1;
   if (!e) return g_error = "null engine", 1;
   if (!out || !out->energy || !out->counts) return g_error = "null result", 1;
-  R3D_HIP_OK(hipSetDevice(e->device));
+  R3D_ON_DEVICE(e->device);
   R3D_HIP_OK(hipMemsetAsync(e->d_energy.p, 0, e->d_energy.bytes, e->stream));
   R3D_HIP_OK(hipMemsetAsync(e->d_counts.p, 0, e->d_counts.bytes, e->stream));
   R3D_HIP_OK(hipMemsetAsync(e->d_scalars.p, 0, e->d_scalars.bytes, e->stream));
@@ -1216,7 +1263,7 @@ int r3d_engine_scatterer_stats(const r3d_engine* e, int s, double out[8]) {
 int r3d_engine_download_scatterer(r3d_engine* e, int s, double* cdf[4], double* spol) {
   const int fail_value = 1;
   if (!e || s < 0 || s >= (int)e->scat_ptrs.size()) return g_error = "scatterer index out of range", 1;
-  R3D_HIP_OK(hipSetDevice(e->device));
+  R3D_ON_DEVICE(e->device);
   const size_t bytes = e->n_toa * sizeof(double);
   for (int k = 0; k < 4; k++)
     if (cdf && cdf[k]) R3D_HIP_OK(hipMemcpy(cdf[k], e->scat_ptrs[s].cdf[k], bytes, hipMemcpyDeviceToHost));
@@ -1227,7 +1274,7 @@ int r3d_engine_download_scatterer(r3d_engine* e, int s, double* cdf[4], double* 
 int r3d_engine_set_event_log(r3d_engine* e, uint32_t mask, uint64_t capacity) {
   const int fail_value = 1;
   if (!e) return g_error = "null engine", 1;
-  R3D_HIP_OK(hipSetDevice(e->device));
+  R3D_ON_DEVICE(e->device);
   KArgs& a = e->args;
   a.evlog = nullptr, a.evlog_count = nullptr, a.evlog_cap = 0, a.evlog_mask = 0;
   e->d_evlog.reset(), e->d_evlog_count.reset();
@@ -1244,7 +1291,7 @@ int r3d_engine_set_event_log(r3d_engine* e, uint32_t mask, uint64_t capacity) {
 uint64_t r3d_event_log_count(r3d_engine* e) {
   const uint64_t fail_value = ~uint64_t(0);
   if (!e || !e->d_evlog_count) return 0;
-  R3D_HIP_OK(hipSetDevice(e->device));
+  R3D_ON_DEVICE(e->device);
   R3D_HIP_OK(hipDeviceSynchronize());
   unsigned long long n = 0;
   R3D_HIP_OK(hipMemcpy(&n, e->d_evlog_count->p, sizeof n, hipMemcpyDeviceToHost));
@@ -1263,13 +1310,14 @@ uint64_t r3d_event_log_read(r3d_engine* e, r3d_event* out, uint64_t max, int res
   return n;
 }
 
-int r3d_engine_set_volume(r3d_engine* e, const r3d_volume_desc* v) {
+static int attach_volume(r3d_engine* e, const r3d_volume_desc* v, void* d_counters) {
   const int fail_value = 1;
   if (!e) return g_error = "null engine", 1;
-  R3D_HIP_OK(hipSetDevice(e->device));
+  R3D_ON_DEVICE(e->device);
   R3D_HIP_OK(hipStreamSynchronize(e->stream));
   e->d_volume.reset();
   e->volume_len = 0;
+  e->volume_ext = nullptr;
   KArgs& a = e->args;
   a.vol = nullptr;
   if (!v) return 0;
@@ -1277,41 +1325,62 @@ int r3d_engine_set_volume(r3d_engine* e, const r3d_volume_desc* v) {
       !(v->cell_size[0] > 0) || !(v->cell_size[1] > 0) || !(v->cell_size[2] > 0))
     return g_error = "volume grid: dimensions, cell sizes and frame length must be positive", 1;
   const size_t len = (size_t)2 * v->n_frames * v->dims[2] * v->dims[1] * v->dims[0];
-  auto buf = std::make_unique<DevBuf>();
-  R3D_HIP_OK(buf->alloc_zero(len * sizeof(unsigned int)));
+  if (d_counters) {
+    e->volume_ext = d_counters;
+  } else {
+    auto buf = std::make_unique<DevBuf>();
+    R3D_HIP_OK(buf->alloc_zero(len * sizeof(unsigned int)));
+    e->d_volume = std::move(buf);
+  }
   for (int k = 0; k < 3; k++) {
     a.vol_origin[k] = v->origin[k], a.vol_inv_cell[k] = 1.0 / v->cell_size[k], a.vol_dim[k] = v->dims[k];
     a.vol_dim_f[k] = (double)v->dims[k];
   }
   a.vol_frames = v->n_frames, a.vol_frames_f = (double)v->n_frames;
   a.vol_inv_dt = 1.0 / v->frame_dt;
-  a.vol = reinterpret_cast<unsigned int*>(buf->p);
-  e->d_volume = std::move(buf);
+  a.vol = reinterpret_cast<unsigned int*>(d_counters ? d_counters : e->d_volume->p);
   e->volume_len = len;
   return 0;
 }
 
+int r3d_engine_set_volume(r3d_engine* e, const r3d_volume_desc* v) { return attach_volume(e, v, nullptr); }
+
+int r3d_engine_set_volume_buffer(r3d_engine* e, const r3d_volume_desc* v, uint32_t* d_counters) {
+  if (v && !d_counters) return g_error = "null volume buffer", 1;
+  return attach_volume(e, v, d_counters);
+}
+
 size_t r3d_volume_len(const r3d_engine* e) { return e ? e->volume_len : 0; }
 
-void* r3d_volume_device_ptr(r3d_engine* e) { return (e && e->d_volume) ? e->d_volume->p : nullptr; }
+void* r3d_volume_device_ptr(r3d_engine* e) {
+  if (!e) return nullptr;
+  return e->volume_ext ? e->volume_ext : (e->d_volume ? e->d_volume->p : nullptr);
+}
 
 int r3d_volume_read(r3d_engine* e, uint32_t* out, int reset) {
   const int fail_value = 1;
-  if (!e || !e->d_volume) return g_error = "no volume grid attached", 1;
+  void* const vol = r3d_volume_device_ptr(e);
+  if (!vol) return g_error = "no volume grid attached", 1;
   if (!out) return g_error = "null output", 1;
-  R3D_HIP_OK(hipSetDevice(e->device));
-  R3D_HIP_OK(hipStreamSynchronize(e->stream));
-  R3D_HIP_OK(hipMemcpy(out, e->d_volume->p, e->volume_len * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  if (reset) R3D_HIP_OK(hipMemset(e->d_volume->p, 0, e->volume_len * sizeof(uint32_t)));
+  R3D_ON_DEVICE(e->device);
+  R3D_HIP_OK(hipDeviceSynchronize());   // (runs may have been enqueued on caller streams)
+  R3D_HIP_OK(hipMemcpy(out, vol, e->volume_len * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (reset) R3D_HIP_OK(hipMemset(vol, 0, e->volume_len * sizeof(uint32_t)));
   return 0;
 }
 
-double r3d_last_kernel_ms(r3d_engine* e) {
-  if (!e || !e->timed) return -1.0;
-  if (hipEventSynchronize(e->ev1) != hipSuccess) return -1.0;
+uint64_t r3d_launch_count(const r3d_engine* e) { return e ? e->launches : 0; }
+
+double r3d_kernel_ms(r3d_engine* e, uint64_t launch) {
+  if (!e || launch == 0 || launch > e->launches || e->launches - launch >= r3d_engine::kCounters) return -1.0;
+  DeviceGuard guard(e->device);
+  const unsigned slot = (unsigned)((launch - 1) % r3d_engine::kCounters);
+  if (hipEventSynchronize(e->ev1[slot]) != hipSuccess) return -1.0;
   float ms = 0;
-  if (hipEventElapsedTime(&ms, e->ev0, e->ev1) != hipSuccess) return -1.0;
+  if (hipEventElapsedTime(&ms, e->ev0[slot], e->ev1[slot]) != hipSuccess) return -1.0;
   return (double)ms;
 }
+
+double r3d_last_kernel_ms(r3d_engine* e) { return e ? r3d_kernel_ms(e, e->launches) : -1.0; }
 
 }  // extern "C"

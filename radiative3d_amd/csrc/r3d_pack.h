@@ -135,22 +135,34 @@ inline uint32_t guide_bits_for(uint64_t n_toa) {
 // ---- velocity-step classification of interior faces -------------------------
 // Phonon::Refract (phonons.cpp:243-252) evaluates max over P,S of
 // |2 (v2 - v1) / (v2 + v1)| at the crossing point and compares it with 1e-5.
-// On a face this is a ratio of affine functions of position (constants for
-// layered and spherical cells), so over the face it lies between its values at
-// the face's corners.  If every corner is safely below the threshold the face
-// is SMOOTH, if every corner is safely above it is a STEP; only faces that
-// straddle it keep the run-time test.  The 10 % guard band dwarfs any rounding
-// in where exactly on the face the phonon sits.
-inline double frac_step(double v1, double v2) { return std::fabs(2 * (v2 - v1) / (v2 + v1)); }
+// On a face each signed step f_t = 2 (v2 - v1) / (v2 + v1) is a ratio of affine
+// functions of position (constants for layered and spherical cells) with a
+// positive denominator, hence monotone along every line: over the face it lies
+// between its values at the face's corners.  So
+//   * if |f_t| is safely below the threshold at every corner for both wave types,
+//     max_t |f_t| is below it everywhere: the face is SMOOTH;
+//   * if for ONE wave type f_t is safely beyond the threshold WITH THE SAME SIGN
+//     at every corner, |f_t| -- and with it the maximum -- is beyond it everywhere:
+//     the face is a STEP.  (A corner-only lower bound on |f_t| would not do: where
+//     f_t changes sign across the face it passes through zero in between.)
+// Faces that satisfy neither keep the run-time test.  The 10 % guard band dwarfs any
+// rounding in where exactly on the face the phonon sits.
+inline double signed_step(double v1, double v2) { return 2 * (v2 - v1) / (v2 + v1); }
 
-inline uint32_t classify_from_corner_steps(const double* steps, int n) {
-  double lo = 1e300, hi = -1e300;
-  for (int i = 0; i < n; i++) {
-    if (!(steps[i] == steps[i])) return 0;   // NaN: decide at run time
-    lo = std::min(lo, steps[i]), hi = std::max(hi, steps[i]);
-  }
-  if (hi < 0.9e-5) return F_SMOOTH;
-  if (lo > 1.1e-5) return F_STEP;
+// steps[corner][type]
+inline uint32_t classify_from_corner_steps(const double (*steps)[2], int n) {
+  bool smooth = true;
+  bool up[2] = {true, true}, down[2] = {true, true};
+  for (int i = 0; i < n; i++)
+    for (int t = 0; t < 2; t++) {
+      const double s = steps[i][t];
+      if (!(s == s)) return 0;   // NaN: decide at run time
+      smooth = smooth && std::fabs(s) < 0.9e-5;
+      up[t] = up[t] && s > 1.1e-5;
+      down[t] = down[t] && s < -1.1e-5;
+    }
+  if (smooth) return F_SMOOTH;
+  if (up[0] || down[0] || up[1] || down[1]) return F_STEP;
   return 0;
 }
 
@@ -185,26 +197,25 @@ inline uint32_t classify_velocity_step(const r3d_model_desc& m, int ci, int f) {
   const r3d_face& F = c.faces[f];
   if (!(F.flags & R3D_FACE_ADJOIN) || (F.flags & (R3D_FACE_DISCON | R3D_FACE_REFLECT))) return 0;
   const r3d_cell& o = m.cells[F.neighbor];
+  double steps[3][2];
   if (m.cell_kind == R3D_CELL_CYLINDER) {
-    double s = std::max(frac_step(c.vel_c[0], o.vel_c[0]), frac_step(c.vel_c[1], o.vel_c[1]));
-    return classify_from_corner_steps(&s, 1);
+    for (int t = 0; t < 2; t++) steps[0][t] = signed_step(c.vel_c[t], o.vel_c[t]);
+    return classify_from_corner_steps(steps, 1);
   }
   if (m.cell_kind == R3D_CELL_SPHERESHELL) {
     const double r2 = F.radius * F.radius;
-    double s = std::max(frac_step(c.vel_c[0] + c.vel_a[0] * r2, o.vel_c[0] + o.vel_a[0] * r2),
-                        frac_step(c.vel_c[1] + c.vel_a[1] * r2, o.vel_c[1] + o.vel_a[1] * r2));
-    return classify_from_corner_steps(&s, 1);
+    for (int t = 0; t < 2; t++)
+      steps[0][t] = signed_step(c.vel_c[t] + c.vel_a[t] * r2, o.vel_c[t] + o.vel_a[t] * r2);
+    return classify_from_corner_steps(steps, 1);
   }
-  double steps[3];
   int n = 0;
   for (int corner = 0; corner < 4; corner++) {
     if (corner == f) continue;                 // corners ON face f are those opposite the other faces
     double x[3];
     if (!tet_corner(c, corner, x)) return 0;
-    double s = 0;
     for (int t = 0; t < 2; t++)
-      s = std::max(s, frac_step(dot3(c.vel_grad[t], x) + c.vel_c[t], dot3(o.vel_grad[t], x) + o.vel_c[t]));
-    steps[n++] = s;
+      steps[n][t] = signed_step(dot3(c.vel_grad[t], x) + c.vel_c[t], dot3(o.vel_grad[t], x) + o.vel_c[t]);
+    n++;
   }
   return classify_from_corner_steps(steps, n);
 }

@@ -211,16 +211,26 @@ class Engine:
                 model._lib.r3dh_model_set_scatterer_stats(model._h, s, (C.c_double * 2)(*st[0:2]),
                                                           (C.c_double * 2)(*st[2:4]))
 
-    def close(self):
+    def close(self, discard_carried=False):
+        """Release the engine.  Refuses (RuntimeError) while histories carried over by
+        run_device(carry="carry") await their flush -- their tallies and bins would be lost --
+        unless discard_carried is set."""
         if getattr(self, "_e", None):
-            self._lib.r3d_engine_destroy(self._e)
+            if discard_carried or self._lib.r3d_engine_close(self._e):
+                if not discard_carried:
+                    raise RuntimeError("r3d_engine_close failed: " + self._lib.r3d_last_error().decode())
+                self._lib.r3d_engine_destroy(self._e)
             self._e = None
 
     def __del__(self):
         try:
-            self.close()
+            self.close(discard_carried=True)
         except Exception:
             pass
+
+    @property
+    def carry_pending(self):
+        return bool(self._lib.r3d_engine_carry_pending(self._e))
 
     def run(self, n, first_id=0, seed=0x5EED, result=None, trace=False):
         """Run histories [first_id, first_id+n); accumulate into `result`."""
@@ -257,6 +267,14 @@ class Engine:
         v = volume_desc(origin, cell_size, dims, n_frames, frame_dt)
         if self._lib.r3d_engine_set_volume(self._e, C.byref(v)):
             raise RuntimeError("r3d_engine_set_volume failed: " + self._lib.r3d_last_error().decode())
+        self._vol_shape = (2, int(n_frames), int(dims[2]), int(dims[1]), int(dims[0]))
+
+    def set_volume_buffer(self, origin, cell_size, dims, n_frames, frame_dt, d_counters):
+        """The same grid in caller-owned device memory (raw address of 2*n_frames*nz*ny*nx zeroed
+        uint32 counters, e.g. a torch tensor's data_ptr that is reduced over ranks afterwards)."""
+        v = volume_desc(origin, cell_size, dims, n_frames, frame_dt)
+        if self._lib.r3d_engine_set_volume_buffer(self._e, C.byref(v), d_counters):
+            raise RuntimeError("r3d_engine_set_volume_buffer failed: " + self._lib.r3d_last_error().decode())
         self._vol_shape = (2, int(n_frames), int(dims[2]), int(dims[1]), int(dims[0]))
 
     def read_volume(self, reset=False):
@@ -307,3 +325,11 @@ class Engine:
 
     def last_kernel_ms(self):
         return float(self._lib.r3d_last_kernel_ms(self._e))
+
+    def launch_count(self):
+        """Launches enqueued so far; launch ids run from 1."""
+        return int(self._lib.r3d_launch_count(self._e))
+
+    def kernel_ms(self, launch):
+        """Kernel time of launch id `launch` (one of the 16 most recent), -1 if not on record."""
+        return float(self._lib.r3d_kernel_ms(self._e, int(launch)))

@@ -1,81 +1,4 @@
-"""Run configurations as the reference's do-*.sh scripts assemble them
-(scripts/do-fundamentals.sh:396-419), parametrised by TOA degree so tests can
-use small tables.  Values are the scripts' own (do-halfspace.sh:41-101,
-do-crustpinch.sh:26-74, do-lopnor.sh:26-104 with event=expl,
-do-spherical.sh:27-74)."""
-
-
-def halfspace(deg=9, one_receiver=False):
-    seis = ("--seis-p2p=0,0,0,260,0,0,2.737,0.105,10.0,1" if one_receiver else
-            "--seis-p2p=0,0,0,183.85,183.85,0,2.737,0.105,10.0,48 "
-            "--seis-p2p=0,0,0,260,0,0,2.737,0.105,10.0,48 "
-            "--seis-p2p=0,0,0,240.21,-99.5,0,2.737,0.105,10.0,48")
-    return ("--grid-compiled=40 "
-            "--model-args=0.8,0.01,1.0,0.5,1000,0.8,0.01,1.0,0.5,1000,6.40,3.63,2.83,-60,6.40,3.63,2.83,-400 "
-            "--range=900 --source=SDR,0,90,0,0.0 --source-loc=0,0,-5 --frequency=2.0 --timetolive=200 "
-            f"--binsize=0.50 --toa-degree={deg} " + seis).split()
-
-
-def crustpinch(deg=9):
-    return ("--grid-compiled=5 "
-            "--model-args=0.8,0.01,0.20,0.2,200,0.8,0.01,0.20,0.3,1500,0.8,0.01,0.20,0.3,1500,"
-            "0.8,0.01,0.20,0.4,1500,0.8,0.01,0.20,0.5,900,2.0,30.0,5.0,.3666667,.4736842,1,1 "
-            "--source=SDR,22.5,90,0 --source-loc=0,0,-10 --frequency=2.0 --timetolive=600 "
-            f"--binsize=2.00 --toa-degree={deg} "
-            "--seis-p2p=0,67.5,0,950,67.5,0,1.0,2.0,40.0,160 "
-            "--seis-p2p=0,112.5,0,950,112.5,0,1.0,2.0,40.0,160 "
-            "--seis-p2p=0,90,0,950,90,0,1.0,2.0,40.0,160").split()
-
-
-def lopnor(deg=9):
-    return ("--grid-compiled=1 --flatten --range=1200 "
-            "--model-args=0.8,0.01,0.5,0.2,50,0.8,0.01,0.5,0.3,1000,0.8,0.01,0.7,0.5,300 "
-            "--source=EXPL --source-loc=425.54,-169.53,-1.02 --frequency=2.0 --timetolive=600 "
-            f"--binsize=2.00 --toa-degree={deg} "
-            "--seis-p2p=425.54,-169.53,0.98,-390.04,-167.18,1.457,1.0,2.0,40.0,160 "
-            "--seis-p2p=425.54,-169.53,0.98,-102.27,430.84,0.60,1.0,2.0,40.0,160").split()
-
-
-def sphere(deg=9, source_depth=-10):
-    return ("--grid-compiled=16 --source=SDR,22.5,90,0 "
-            f"--source-loc=0,0,{source_depth} --frequency=2.0 --timetolive=8000 "
-            f"--binsize=20.0 --toa-degree={deg} "
-            "--seis-p2p=0,67.5,0,12000,67.5,0,20.0,20.0,400.0,160 "
-            "--seis-p2p=0,112.5,0,12000,112.5,0,20.0,20.0,400.0,160 "
-            "--seis-p2p=0,90,0,12000,90,0,20.0,20.0,400.0,160").split()
-
-
-def toysphere_vids(deg=4):
-    """do-toysphere-vids.sh:21-60: model 30, pinned mean free paths, scattering without
-    deflection, raw output coordinates (a ray-path video run)."""
-    return ("--grid-compiled=30 --model-args=0.8,0.01,0.5,0.2,50,0.8,0.01,0.5,0.3,1000,0.8,0.01,0.7,0.5,300 "
-            "--source=SDR,22.5,90,0 --source-loc=0,0,-10 --frequency=2.0 --timetolive=6000 "
-            f"--binsize=60.0 --toa-degree={deg} --overridemfp=50,40 --nodeflect --ocsraw "
-            "--seis-p2p=0,0,0,1000,0,0,1.0,2.0,40.0,16 --seis-p2p=0,90,0,1000,90,0,1.0,2.0,40.0,16").split()
-
-
-def lopnor_vids(deg=4):
-    """do-lopnor-vids.sh:21-100 with event=eq: model 21 (Moho transition, gradual profile),
-    Earth-flattened, four scattering regions, pinned mean free paths, no deflection."""
-    return ("--grid-compiled=21 --flatten --range=1200 "
-            "--model-args=0.8,0.01,0.5,0.2,50,0.8,0.01,0.5,0.3,1000,0.8,0.01,0.7,0.5,300,0.8,0.02,0.5,0.5,2000 "
-            "--source=SDR,125,40,90,0.0 --source-loc=425.54,-169.53,-31.02 --frequency=2.0 --timetolive=350 "
-            f"--binsize=10.0 --toa-degree={deg} --overridemfp=1,1 --nodeflect "
-            "--seis-p2p=425.54,-169.53,0.98,-390.04,-167.18,1.457,1.0,2.0,40.0,16 "
-            "--seis-p2p=425.54,-169.53,0.98,-102.27,430.84,0.60,1.0,2.0,40.0,16").split()
-
-
-def upthrust(deg=4):
-    """Model 8 (crust upthrust, tetra) with the crust-pinch run's source and arrays
-    (no reference run script uses it; user_Upthrust_inc.cpp argument pattern of 32)."""
-    return ("--grid-compiled=8 "
-            "--model-args=0.8,0.01,0.20,0.2,200,0.8,0.01,0.20,0.3,1500,0.8,0.02,0.30,0.3,1200,"
-            "0.8,0.01,0.20,0.4,1500,0.8,0.01,0.20,0.5,900,2.0,30.0,10.0,-12,-3,1.5,4 "
-            "--source=SDR,22.5,90,0 --source-loc=0,0,-10 --frequency=2.0 --timetolive=600 "
-            f"--binsize=2.00 --toa-degree={deg} "
-            "--seis-p2p=0,67.5,0,950,67.5,0,1.0,2.0,40.0,40 "
-            "--seis-p2p=0,112.5,0,950,112.5,0,1.0,2.0,40.0,40").split()
-
-
-CONFIGS = {"halfspace": halfspace, "crustpinch": crustpinch, "lopnor": lopnor, "sphere": sphere,
-           "toysphere_vids": toysphere_vids, "lopnor_vids": lopnor_vids, "upthrust": upthrust}
+"""The run configurations live with the package (radiative3d_amd/configs.py) so that bench.py
+does not depend on the test tree; tests keep importing them from here."""
+from radiative3d_amd.configs import *  # noqa: F401,F403
+from radiative3d_amd.configs import CONFIGS  # noqa: F401

@@ -85,3 +85,12 @@ extern "C" int r3d_emul_run(const r3d_model_desc* m, uint64_t n, uint64_t first_
   }
   return 0;
 }
+
+// Pack-time class (F_SMOOTH / F_STEP / 0) of face f of cell ci: r3d_pack.h classify_velocity_step.
+extern "C" uint32_t r3d_emul_face_class(const r3d_model_desc* m, int ci, int f) {
+  return classify_velocity_step(*m, ci, f);
+}
+// ... and of bare corner values steps[corner][type] of the signed fractional velocity step
+extern "C" uint32_t r3d_emul_class_from_corners(const double* steps, int n) {
+  return classify_from_corner_steps(reinterpret_cast<const double (*)[2]>(steps), n);
+}

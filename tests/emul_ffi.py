@@ -25,6 +25,10 @@ def lib():
         L.r3d_emul_run.argtypes = [C.POINTER(_ffi.ModelDesc), C.c_uint64, C.c_uint64, C.c_uint64,
                                    C.POINTER(_ffi.Result), C.POINTER(_ffi.Final)]
         L.r3d_emul_set_volume.argtypes = [C.POINTER(_ffi.VolumeDesc), C.POINTER(C.c_uint32)]
+        L.r3d_emul_face_class.restype = C.c_uint32
+        L.r3d_emul_face_class.argtypes = [C.POINTER(_ffi.ModelDesc), C.c_int, C.c_int]
+        L.r3d_emul_class_from_corners.restype = C.c_uint32
+        L.r3d_emul_class_from_corners.argtypes = [C.POINTER(C.c_double), C.c_int]
         _lib = L
     return _lib
 
@@ -49,3 +53,16 @@ def run(model, n, first_id=0, seed=0x5EED, result=None, trace=False):
         raise RuntimeError("emul run failed")
     res._from_c(c)
     return (res, finals) if trace else res
+
+
+F_SMOOTH, F_STEP = 16, 32
+
+
+def class_from_corners(steps):
+    """Pack-time class of a face from the signed velocity steps [(P, S), ...] at its corners."""
+    flat = [x for pair in steps for x in pair]
+    return int(lib().r3d_emul_class_from_corners((C.c_double * len(flat))(*flat), len(steps)))
+
+
+def face_class(model, cell, face):
+    return int(lib().r3d_emul_face_class(model.desc_p, cell, face))

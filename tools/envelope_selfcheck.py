@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from radiative3d_amd import Model, Engine
-from tests.configs import crustpinch
+from radiative3d_amd.configs import crustpinch
 from bench import envelope_agreement, batch_moments
 m = Model(crustpinch(9) + ["--device-tables"]); e = Engine(m)
 def batches(k, per, base):

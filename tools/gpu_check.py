@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from radiative3d_amd import Model, Engine
 from oracle import oracle_ffi as O
-from tests.configs import CONFIGS
+from radiative3d_amd.configs import CONFIGS
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "halfspace"

@@ -3,7 +3,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from radiative3d_amd import Model, Engine
-from tests.configs import CONFIGS
+from radiative3d_amd.configs import CONFIGS
 name, deg = sys.argv[1], int(sys.argv[2])
 m = Model(CONFIGS[name](deg) + ["--device-tables"]); e = Engine(m)
 e.run(1_000_000)

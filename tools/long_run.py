@@ -2,7 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from radiative3d_amd import Model, Engine
-from tests.configs import CONFIGS
+from radiative3d_amd.configs import CONFIGS
 name, deg, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 10_000_000
 m = Model(CONFIGS[name](deg)); e = Engine(m); res = m.new_result()

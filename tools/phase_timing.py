@@ -3,7 +3,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["R3D_HIP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "radiative3d_amd", "lib", os.environ.get("R3D_PHASE_LIB", "variant_PHASE.so"))
 from radiative3d_amd import Model, Engine, _ffi
-from tests.configs import CONFIGS
+from radiative3d_amd.configs import CONFIGS
 name, deg, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 m = Model(CONFIGS[name](deg)); e = Engine(m)
 L = _ffi.hip_lib(); out = (C.c_ulonglong * 8)()

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from radiative3d_amd import Model, Engine
 from radiative3d_amd.parallel import DeviceResult
-from tests.configs import CONFIGS
+from radiative3d_amd.configs import CONFIGS
 name, deg, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 k = int(sys.argv[4]) if len(sys.argv) > 4 else 6
 m = Model(CONFIGS[name](deg) + ["--device-tables"]); e = Engine(m)

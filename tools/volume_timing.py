@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from radiative3d_amd import Model, Engine
-from tests.configs import crustpinch
+from radiative3d_amd.configs import crustpinch
 m = Model(crustpinch(9) + ["--device-tables"]); e = Engine(m)
 n = 10_000_000
 e.run(n // 10)
