@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- phonon-histories/s of the HIP engine on the reference's headline
-configuration (BASELINE.json configs[1]: NSCP crust-pinch, do-crustpinch.sh
-arguments, TOA degree 9, 1e7 histories per step), one process per GPU.
+"""bench.py -- phonon-histories/s of the HIP engine, one process per GPU.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path (GenerateEventPhonon + Propagate) over a
-fresh batch of 1e7 history ids per GPU; tables are resident in HBM before the
-timed region; the per-receiver bins stay in HBM and are summed over ranks with
-one RCCL all-reduce per buffer inside the timed region (weak scaling: every
-rank runs the same count).  Rank 0 prints one JSON line.
+Default workload: the reference's headline configuration (BASELINE.json configs[1]: NSCP
+crust-pinch, do-crustpinch.sh arguments, TOA degree 9, 1e7 histories per GPU per step).
+--config selects the other BASELINE configurations (halfspace, lopnor, sphere = SphereEarth
+with the deep source, crustpinch_volume = crust-pinch video run + the 10 GB scatter-event grid).
+
+Called directly with --gpus N > 1 (no launcher environment) the program starts N rank
+processes itself, before anything touches a GPU (radiative3d_amd/launch.py); under
+torch.distributed.run it is one rank of the launcher's job.  Either way the world size must
+equal --gpus, and `n_gpus` in the output is the process group's size.
+
+A step = one pass of the hot path (GenerateEventPhonon + Propagate) over a fresh batch of
+history ids per GPU; tables are resident in HBM before the timed region; the per-receiver bins
+stay in HBM and are summed over ranks with one RCCL all-reduce per buffer inside the timed
+region (weak scaling: every rank runs the same count).  Rank 0 prints one JSON line.
 """
 import argparse
+import hashlib
 import json
 import math
 import os
@@ -23,11 +31,39 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+# /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+HBM_PEAK_GBS = 8000.0
+N_SIMD = 256 * 4
+MAX_CLOCK_GHZ = 2.4
+PROFILE_ROUND = "r02"
+
+
+def workloads():
+    from radiative3d_amd import configs as C
+    return {
+        "halfspace": dict(
+            args=lambda deg: C.halfspace(deg, one_receiver=True), histories=10_000_000, volume=None,
+            label="Halfspace (do-halfspace.sh arguments, one receiver as BASELINE config 1 names)"),
+        "crustpinch": dict(
+            args=C.crustpinch, histories=10_000_000, volume=None,
+            label="NSCP crust-pinch (do-crustpinch.sh arguments)"),
+        "lopnor": dict(
+            args=C.lopnor, histories=10_000_000, volume=None,
+            label="LopNorCyl (do-lopnor.sh arguments, explosion source)"),
+        "sphere": dict(
+            args=lambda deg: C.sphere(deg, source_depth=-600), histories=10_000_000, volume=None,
+            label="SphereEarth (do-spherical.sh arguments, deep double-couple source at 600 km)"),
+        "crustpinch_volume": dict(
+            args=C.crustpinch_vids, histories=10_000_000, volume=C.CRUSTPINCH_VOLUME,
+            label="NSCP crust-pinch video run (do-crustpinch-vids.sh arguments: pinned mean free paths, no "
+                  "deflection) with a dense scatter-event grid 2 x 300 x 64 x 256 x 256 uint32 = 10 GB"),
+    }
 
 
 def algorithmic_bytes_per_history(ev, n_toa, n_seis, cell_kind):
-    """must-touch bytes per history from per-history event counts."""
+    """must-touch bytes per history of the REFERENCE's algorithm from
+    per-history event counts (every receiver tested on every surface arrival, every cell record
+    from memory).  Reported as `contract_bytes`; the engine does not move most of them."""
     probes = 2 + math.ceil(math.log2(n_toa))
     b_cell = {0: 150, 1: 340, 2: 120}[cell_kind]
     return (probes * 8 + 16
@@ -40,18 +76,36 @@ def algorithmic_bytes_per_history(ev, n_toa, n_seis, cell_kind):
             + 104)
 
 
-def recorded_hbm_traffic(toa_degree, n):
-    """HBM bytes per launch of the traversal kernel from the committed rocprofv3 PMC passes
-    (FETCH_SIZE + WRITE_SIZE, KiB -> bytes; profiles/r01/pmc_counters_bench_nscp_deg9.json).
-    PMC collection needs the profiler around the process, so bench.py cannot measure it in
-    line; the figure is only reported when it was taken on this very workload."""
-    path = os.path.join(REPO, "profiles", "r01", "pmc_counters_bench_nscp_deg9.json")
-    if toa_degree != 9 or n != 10_000_000 or not os.path.exists(path):
-        return None
+def kernel_source_hash():
+    """sha256 over the kernel's sources and build flags: what the recorded counters are keyed by."""
+    h = hashlib.sha256()
+    csrc = os.path.join(REPO, "radiative3d_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".h", ".hip")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    for line in open(os.path.join(REPO, "Makefile")):
+        if line.startswith("HIPFLAGS") or line.lstrip().startswith("-mllvm"):
+            h.update(line.encode())
+    return h.hexdigest()[:16]
+
+
+def recorded_counters(config, toa_degree, n):
+    """Per-launch hardware counters of this workload's traversal kernel from the committed
+    rocprofv3 --pmc passes (profiles/<round>/pmc_<config>.json, written by tools/pmc_summary.py
+    from tools/collect_profiles.sh).  PMC collection needs the profiler around the process, so
+    bench.py cannot take them in line: they are RECORDED figures, named as such in the output,
+    and are dropped when they were taken on other kernel sources or another workload."""
+    rel = os.path.join("profiles", PROFILE_ROUND, f"pmc_{config}.json")
     try:
-        return float(json.load(open(path))["hbm_traffic_bytes_per_launch"])
-    except (KeyError, ValueError, OSError):
-        return None
+        rec = json.load(open(os.path.join(REPO, rel)))
+    except (OSError, ValueError):
+        return None, rel, "no counter file"
+    if rec.get("toa_degree") != toa_degree or rec.get("histories_per_launch") != n:
+        return None, rel, "recorded on another workload size"
+    if rec.get("kernel_source_hash") != kernel_source_hash():
+        return None, rel, "recorded on other kernel sources"
+    return rec, rel, None
 
 
 def usable_cores(cap=16):
@@ -67,18 +121,20 @@ def usable_cores(cap=16):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(model, budget_s=12.0):
-    """The oracle (CPU port of the reference's algorithm) on this box's host
-    cores: one thread per core, each on its own id range, bounded to ~budget_s.
-    Returns the JSON object, the per-thread results (independent batches, for the
-    envelope check) and the histories per thread."""
+def cpu_baseline(model, target_histories=10_000_000, budget_s=25.0):
+    """The oracle (CPU port of the reference's algorithm) on this box's host cores: one thread
+    per core, each on its own id range.  The sample is the 1e7 histories north_star names when
+    they fit ~budget_s of wall time on these cores, else what does (stated in `sample`).
+    Returns the JSON object, the per-thread results (independent batches, for the envelope
+    check) and the histories per thread."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle_ffi
     cores = usable_cores()
+    probe = 2000
     t = time.perf_counter()
-    oracle_ffi.run(model, 2000, first_id=1 << 50)
-    per_core_rate = 2000 / (time.perf_counter() - t)
-    per_thread = max(2000, int(per_core_rate * budget_s))
+    oracle_ffi.run(model, probe, first_id=1 << 50)
+    per_core_rate = probe / (time.perf_counter() - t)
+    per_thread = max(probe, min(int(per_core_rate * budget_s), -(-target_histories // cores)))
 
     def work(i):
         return oracle_ffi.run(model, per_thread, first_id=(1 << 50) + (i + 1) * per_thread)
@@ -119,6 +175,9 @@ def envelope_agreement(gpu_mom, cpu_mom, n_gpu, n_cpu, min_count=25):
     ng = ng.sum(-1).astype(float)[..., None]
     nc = nc.sum(-1).astype(float)[..., None]
     sel = np.broadcast_to((nc >= min_count) & (ng >= min_count), eg.shape) & (ec > 0) & (eg > 0)
+    if not sel.any():
+        return {"rms_sigma": None, "bins": 0, "gpu_histories": int(n_gpu), "cpu_histories": int(n_cpu),
+                "min_count": min_count}
     z = (eg - ec)[sel] / np.sqrt((vg + vc)[sel])
     zp = (eg - ec)[sel] / np.sqrt((eg ** 2 / np.maximum(ng, 1) + ec ** 2 / np.maximum(nc, 1))[sel])
     return {"rms_sigma": float(np.sqrt(np.mean(z ** 2))), "bins": int(sel.sum()),
@@ -128,92 +187,132 @@ def envelope_agreement(gpu_mom, cpu_mom, n_gpu, n_cpu, min_count=25):
                           "ranges; sigma^2 = variance of batch means (GPU and CPU batches summed)"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--histories", type=int, default=10_000_000, help="histories per GPU per step")
+    ap.add_argument("--config", default="crustpinch",
+                    choices=["halfspace", "crustpinch", "lopnor", "sphere", "crustpinch_volume"])
+    ap.add_argument("--histories", type=int, default=None, help="histories per GPU per step (default: per config)")
     ap.add_argument("--toa-degree", type=int, default=9)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--self-contained", action="store_true",
                     help="every step a self-contained launch that drains its own stragglers "
                          "(default: steps chained, one flush launch at the end of the timed region)")
-    args = ap.parse_args()
+    ap.add_argument("--timed-only", action="store_true",
+                    help="stop after the timed region: no single-launch, device-table, CPU-baseline or envelope "
+                         "legs (profiling passes: every dispatch is then a step or flush launch of the chain)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, form the process group (gloo, no GPU), print its size and exit: "
+                         "the CPU check of the launcher path")
+    return ap.parse_args(argv)
 
+
+def rendezvous_only(args, rank, world):
     import torch
     import torch.distributed as dist
-    from radiative3d_amd import Engine, Model
-    from radiative3d_amd.parallel import DeviceResult
-    from radiative3d_amd.configs import crustpinch
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    t = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"n_gpus": dist.get_world_size(), "ranks_seen": int(t.item()), "rendezvous": "ok"}),
+              flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    from radiative3d_amd.launch import spawn_ranks, under_launcher
+    launched = under_launcher()
+    if not launched and (args.gpus > 1 or args.rendezvous_only):
+        # called directly: start the ranks here, before anything touches a GPU
+        sys.exit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    under_launcher = "RANK" in os.environ and "MASTER_PORT" in os.environ   # torch.distributed.run
-    if under_launcher:
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.rendezvous_only:
+        return rendezvous_only(args, rank, world)
+
+    import torch
+    import torch.distributed as dist
+    from radiative3d_amd import Engine, Model
+    from radiative3d_amd.parallel import DeviceResult, DeviceVolume
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if under_launcher:   # also at world size 1, so the RCCL path is the one that runs
+    if launched:   # also at world size 1, so the RCCL path is the one that runs
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        assert dist.get_world_size() == args.gpus
+    n_gpus = dist.get_world_size() if launched else 1
 
-    # ---- build the model (host) and put it in HBM: not timed --------------
     def note(msg):
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
+    wl = workloads()[args.config]
+    n = args.histories or wl["histories"]
+    seed = 0x5EED
+
+    # ---- build the model (host) and put it in HBM: not timed --------------
     # One GPU: host-built tables, the ones the CPU baseline / envelope check also runs on.
     # Several ranks: every rank lets its engine evaluate the tables in HBM (--device-tables)
-    # instead of N processes each spending the host's cores on the same 1.5 GB of tables.
-    model_args = crustpinch(args.toa_degree) + (["--device-tables"] if world > 1 else [])
+    # instead of N processes each spending the host's cores on the same GBs of tables.
+    model_args = wl["args"](args.toa_degree) + (["--device-tables"] if world > 1 else [])
     t0 = time.perf_counter()
     model = Model(model_args)
     t_build = time.perf_counter() - t0
     t0 = time.perf_counter()
     engine = Engine(model, device=local_rank)
     t_upload = time.perf_counter() - t0
-    note(f"model built in {t_build:.1f} s, tables in HBM after {t_upload:.1f} s")
+    note(f"{args.config}: model built in {t_build:.1f} s, tables in HBM after {t_upload:.1f} s")
     result = DeviceResult(model, device)
+    step_res = DeviceResult(model, device)
+    volume = None
+    if wl["volume"]:
+        volume = DeviceVolume(engine, device=device, **wl["volume"])
     stream = torch.cuda.current_stream(device)
-    n = args.histories
-    seed = 0x5EED
 
     # A lone batch ends in a drain phase: the work counter is exhausted and ever fewer lanes
-    # still carry a history (the longest NSCP histories are ~40 times the mean), about 8 of a
-    # lone 1e7-history launch's 25 ms.  The steps therefore form a carry chain
-    # (r3d_run_device_carry): the histories still in flight when a step's ids run out stay in
-    # the engine and are resumed by the next step's launch, and one flush launch after the
-    # last step runs the stragglers to their end.  Results do not depend on it.
-    step_res = DeviceResult(model, device)
-
-    def step(i, events=None):
+    # still carry a history (the longest NSCP histories are ~40 times the mean).  The steps
+    # therefore form a carry chain (r3d_run_device_carry): the histories still in flight when a
+    # step's ids run out stay in the engine and are resumed by the next step's launch, and one
+    # flush launch after the last step runs the stragglers to their end.  Results do not
+    # depend on it.  --self-contained times lone launches instead; the default run reports
+    # them too, as `single_launch`.
+    def step(i, launches=None):
         # every step and every rank gets its own disjoint id range; a step ends with the
         # whole-job bins of that launch (summed over ranks) added to the running total
         first = (i * world + rank) * n
         step_res.zero_()
-        if events is not None:
-            events[0].record(stream)
         engine.run_device(n, first, seed, *step_res.pointers(), stream=stream.cuda_stream,
                           carry=None if args.self_contained else "carry")
-        if events is not None:
-            events[1].record(stream)
+        if launches is not None:
+            launches.append(engine.launch_count())
         step_res.allreduce_()     # no-op at world == 1
         result.add_(step_res)
 
-    def flush():
-        if args.self_contained:
-            return
-        step_res.zero_()
-        engine.run_device(0, 0, seed, *step_res.pointers(), stream=stream.cuda_stream, carry="final")
-        step_res.allreduce_()
-        result.add_(step_res)
+    def flush(launches=None):
+        if not args.self_contained:
+            step_res.zero_()
+            engine.run_device(0, 0, seed, *step_res.pointers(), stream=stream.cuda_stream, carry="final")
+            if launches is not None:
+                launches.append(engine.launch_count())
+            step_res.allreduce_()
+            result.add_(step_res)
 
     def sync():
-        if under_launcher:
+        if launched:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -222,99 +321,171 @@ def main():
     flush()
     sync()
     result.zero_()
+    if volume is not None:
+        volume.zero_()
     sync()
-    # per-launch kernel durations: HIP events on the launch stream, recorded around each
-    # launch and read after the timed region
-    kernel_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                     for _ in range(args.steps)]
+    # per-launch kernel durations: the engine records a HIP event pair around every launch on
+    # the stream it is launched on (r3d_kernel_ms); read after the timed region
+    step_launches, flush_launches = [], []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i, kernel_events[i])
-    flush()
+        step(args.warmup + i, step_launches)
+    flush(flush_launches)
+    t_vol0 = time.perf_counter()
+    if volume is not None:   # the job's event grid: summed over ranks once, at the end
+        volume.allreduce_()
     sync()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = [a.elapsed_time(b) for a, b in kernel_events]
-    if under_launcher:
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    volume_reduce_s = (t1 - t_vol0) if volume is not None else None
+    step_ms = [ms for ms in (engine.kernel_ms(k) for k in step_launches) if ms >= 0]   # (the 64 most recent)
+    flush_ms = [ms for ms in (engine.kernel_ms(k) for k in flush_launches) if ms >= 0]
+    if launched:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
     note(f"timed {args.steps} steps in {elapsed:.3f} s")
+
     if rank == 0:
         res = result.to_result()
         total = res.events["generated"]            # histories summed over ranks and passes
+        assert total == args.steps * n * world, (total, args.steps, n, world)
+        assert res.n_lost + res.n_timeout + res.n_invalid == total
         ev = {k: v / total for k, v in res.events.items()}
-        b_hist = algorithmic_bytes_per_history(ev, model.n_toa, model.n_seismometers, model.desc.cell_kind)
-        avg_ms = sum(kernel_ms) / len(kernel_ms)
-        achieved = n * b_hist / (avg_ms * 1e-3) / 1e9
         value = args.steps * n * world / elapsed
+        avg_step_ms = sum(step_ms) / max(1, len(step_ms))
+        # kernel time per step with the chain's flush launch shared out over its steps
+        kernel_ms_per_step = (sum(step_ms) + sum(flush_ms)) / max(1, len(step_ms))
+        kind_name = {0: "cylinder", 1: "tetra", 2: "sphere"}[model.desc.cell_kind]
+
+        # ---- what bounds the kernel (recorded counters, measured time) ----
+        rec, rec_path, why_not = recorded_counters(args.config, args.toa_degree, n)
+        b_hist = algorithmic_bytes_per_history(ev, model.n_toa, model.n_seismometers, model.desc.cell_kind)
+        roofline = {
+            "bound": "valu",
+            "kernel": f"propagate_kernel<{kind_name}>", "kernel_ms_step_avg": avg_step_ms,
+            "kernel_ms_flush": flush_ms, "kernel_ms_per_step_incl_flush": kernel_ms_per_step,
+            "note": "the traversal is fp64 vector code with divergent gathers; no MFMA, ~3-5 % of HBM peak. "
+                    "achieved = VALU-busy SIMD-cycles per second of a step launch (SQ_ACTIVE_INST_VALU x 4 "
+                    "cycles, recorded per launch by rocprofv3 --pmc, / this run's measured launch time); "
+                    "peak = 1024 SIMDs x 2.4 GHz",
+            "events_per_history": {k: round(v, 4) for k, v in ev.items()},
+        }
+        if rec is not None:
+            busy_cycles = 4.0 * rec["SQ_ACTIVE_INST_VALU"]
+            achieved = busy_cycles / (avg_step_ms * 1e-3) / 1e9
+            peak = N_SIMD * MAX_CLOCK_GHZ
+            traffic = rec.get("hbm_traffic_bytes_per_launch")
+            roofline.update({
+                "achieved": achieved, "peak": peak, "unit": "G SIMD-cycles/s", "frac": achieved / peak,
+                "traffic": traffic, "counters": "recorded", "counters_source": rec_path,
+                "valu_insts_per_launch": rec.get("SQ_INSTS_VALU"),
+                "valu_busy_at_recorded_clock": rec.get("valu_busy"),
+                "lanes_active_per_valu_inst": rec.get("lane_activity"),
+                "hbm": {"bytes_per_launch": traffic,
+                        "GBps": traffic / (avg_step_ms * 1e-3) / 1e9 if traffic else None,
+                        "frac_of_peak": traffic / (avg_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
+                        "peak_GBps": HBM_PEAK_GBS, "source": rec_path}})
+        else:
+            roofline.update({"achieved": None, "peak": N_SIMD * MAX_CLOCK_GHZ, "unit": "G SIMD-cycles/s",
+                             "frac": None, "traffic": None, "counters": f"none ({why_not}: {rec_path})"})
+        contract = {
+            "per_history": b_hist, "per_launch": b_hist * n,
+            "GBps": n * b_hist / (avg_step_ms * 1e-3) / 1e9,
+            "over_hbm_peak": n * b_hist / (avg_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "SURVEY.md 8(d) must-touch bytes of the reference's algorithm (all receivers tested per "
+                    "surface arrival, cell records from memory) / measured launch time; not HBM traffic -- the "
+                    "receiver hash and the LDS-resident tables never move most of these bytes, hence > peak"}
+
         line = {
             "metric": "phonon-histories/sec", "value": value, "unit": "histories/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "NSCP crust-pinch (do-crustpinch.sh arguments), "
-                                   f"TOA degree {args.toa_degree}, {n} histories per GPU per step, "
-                                   "480 seismometers x 300 bins",
+            "config": {"workload": f"{wl['label']}, TOA degree {args.toa_degree}, {n} histories per GPU per step, "
+                                   f"{model.n_seismometers} seismometers x {model.n_bins} bins",
+                       "name": args.config,
                        "histories_per_gpu_per_step": n, "toa_degree": args.toa_degree,
                        "cells": model.n_cells, "scatterers": model.n_scatterers,
                        "parallelism": f"history-id shards x{world}, one all-reduce of the bins per step; "
                                       + ("every step a self-contained launch" if args.self_contained else
                                          "steps chained (unfinished histories carried into the next "
                                          "step's launch, one flush launch at the end, inside the timed region)")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": recorded_hbm_traffic(args.toa_degree, n),
-                         "kernel": "propagate_kernel<tetra>", "kernel_ms_avg": avg_ms,
-                         "algorithmic_bytes_per_history": b_hist,
-                         "events_per_history": {k: round(v, 4) for k, v in ev.items()}},
+            "roofline": roofline, "contract_bytes": contract,
             "host": {"model_build_s": round(t_build, 2), "table_upload_s": round(t_upload, 2),
                      "tables": "device-built" if world > 1 else "host-built"},
         }
-        # the same model with the scattering tables evaluated in HBM (--device-tables):
-        # what a production run pays before its first history
-        t0 = time.perf_counter()
-        dev_model = Model(crustpinch(args.toa_degree) + ["--device-tables"])
-        t_dev_host = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        dev_engine = Engine(dev_model, device=local_rank)
-        t_dev_engine = time.perf_counter() - t0
-        dev_engine.close()
-        line["host"]["device_tables"] = {"model_build_s": round(t_dev_host, 2),
-                                         "engine_create_s": round(t_dev_engine, 2)}
-        if not args.no_cpu_baseline and world == 1:
+        if volume is not None:
+            line["volume"] = {"shape": list(volume.shape), "bytes": volume.counters.numel() * 4,
+                              "events_binned": volume.total(),
+                              "reduce_over_ranks_s": volume_reduce_s, "saturated_cells": volume.saturated}
+
+        if args.timed_only:
+            line["cpu_baseline"] = None
+            print(json.dumps(line), flush=True)
+        # ---- one self-contained launch of the same size (drains its own stragglers) ----
+        if not args.self_contained and not args.timed_only:
+            lone = []
+            for i in range(3):
+                step_res.zero_()
+                engine.run_device(n, (1 << 40) + i * n, seed, *step_res.pointers(), stream=stream.cuda_stream)
+                torch.cuda.synchronize()
+                lone.append(engine.last_kernel_ms())
+            lone.sort()
+            line["single_launch"] = {"histories": n, "kernel_ms": lone[1], "value": n / (lone[1] * 1e-3),
+                                     "unit": "histories/s",
+                                     "note": "median of 3 self-contained launches (each drains its own "
+                                             "stragglers), this rank only"}
+
+        # the same model with every table evaluated in HBM (--device-tables): what a production
+        # run pays before its first history
+        if not args.timed_only:
+            t0 = time.perf_counter()
+            dev_model = Model(wl["args"](args.toa_degree) + ["--device-tables"])
+            t_dev_host = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            dev_engine = Engine(dev_model, device=local_rank)
+            t_dev_engine = time.perf_counter() - t0
+            dev_engine.close()
+            line["host"]["device_tables"] = {"model_build_s": round(t_dev_host, 2),
+                                             "engine_create_s": round(t_dev_engine, 2)}
+
+        if args.timed_only:
+            pass
+        elif not args.no_cpu_baseline and world == 1:
             note("timing the CPU baseline (oracle) ...")
             line["cpu_baseline"], cpu_parts, per_thread = cpu_baseline(model)
             note("envelope check: GPU batches ...")
-            n_batch, nb = 32, max(1, n // 8)
-            g_e, g_c = [], []
-            for b in range(n_batch):   # untimed; ids beyond every range used above
-                step_res.zero_()
-                engine.run_device(nb, (1 << 44) + b * nb, seed, *step_res.pointers(), stream=stream.cuda_stream)
-                torch.cuda.synchronize()
-                r = step_res.to_result()
-                g_e.append(r.energy / nb), g_c.append(r.counts)
-            gpu_mom = batch_moments(g_e, g_c)
+            # the GPU sample mirrors the CPU sample's batch structure (same count, same size), on
+            # ids beyond every range used above: two independent samples of 1e7 histories each
+            # when the CPU got that far
+
+            def gpu_batches(base):
+                g_e, g_c = [], []
+                for b in range(len(cpu_parts)):   # untimed
+                    step_res.zero_()
+                    engine.run_device(per_thread, base + b * per_thread, seed, *step_res.pointers(),
+                                      stream=stream.cuda_stream)
+                    torch.cuda.synchronize()
+                    r = step_res.to_result()
+                    g_e.append(r.energy / per_thread), g_c.append(r.counts)
+                return batch_moments(g_e, g_c)
+
+            n_side = per_thread * len(cpu_parts)
+            gpu_mom = gpu_batches(1 << 44)
             cpu_mom = batch_moments([p.energy / per_thread for p in cpu_parts], [p.counts for p in cpu_parts])
-            line["envelope"] = envelope_agreement(gpu_mom, cpu_mom, n_batch * nb, per_thread * len(cpu_parts))
-            # calibration of the statistic: the same comparison with the CPU sample replaced by an
-            # independent GPU sample of the CPU sample's batch structure (both sides the same code).
-            # With few, unequal batches and heavy-tailed bins it sits above 1; the GPU-vs-CPU figure
-            # is to be read against it.
-            c_e, c_c = [], []
-            for b in range(len(cpu_parts)):
-                step_res.zero_()
-                engine.run_device(per_thread, (1 << 52) + b * per_thread, seed, *step_res.pointers(),
-                                  stream=stream.cuda_stream)
-                torch.cuda.synchronize()
-                r = step_res.to_result()
-                c_e.append(r.energy / per_thread), c_c.append(r.counts)
-            twin = envelope_agreement(gpu_mom, batch_moments(c_e, c_c), n_batch * nb, per_thread * len(cpu_parts))
+            line["envelope"] = envelope_agreement(gpu_mom, cpu_mom, n_side, n_side)
+            # calibration of the statistic: the same comparison with the CPU sample replaced by a
+            # second independent GPU sample (both sides the same code); with few batches and
+            # heavy-tailed bins it need not sit at exactly 1
+            twin = envelope_agreement(gpu_mom, gpu_batches(1 << 52), n_side, n_side)
             line["envelope"]["rms_sigma_gpu_vs_gpu_same_batches"] = twin["rms_sigma"]
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
-    if under_launcher:
+        if not args.timed_only:
+            print(json.dumps(line), flush=True)
+    engine.close()
+    if launched:
         dist.barrier()
         dist.destroy_process_group()
 

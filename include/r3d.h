@@ -246,7 +246,7 @@ int r3d_run(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,
  * stream).  d_scalars holds 3 + R3D_INV_NUM + R3D_EV_NUM uint64 counters in
  * the order n_lost, n_timeout, n_invalid, invalid_reasons[], events[].
  * Asynchronous: returns after enqueueing.  d_finals may be NULL.           */
-/* (Up to 16 r3d_run_device launches of one engine may be in flight at a time, on
+/* (Up to 64 r3d_run_device launches of one engine may be in flight at a time, on
  * different streams and into different buffers: a batch ends in a drain phase in
  * which ever fewer lanes still carry a history -- the longest histories are ~40
  * times the mean -- and the next batch's workgroups fill the CUs it frees.)      */
@@ -354,7 +354,7 @@ uint64_t r3d_event_log_read(r3d_engine* e, r3d_event* out, uint64_t max, int res
  * most recent r3d_run / r3d_run_device[_carry] call on this engine, measured
  * with HIP events on the stream it was launched on (blocks until it has
  * completed).  Launches are numbered from 1 in enqueue order: r3d_launch_count
- * is the number so far, r3d_kernel_ms reads any of the 16 most recent (each has
+ * is the number so far, r3d_kernel_ms reads any of the 64 most recent (each has
  * its own event pair, so overlapping launches on several streams are timed
  * separately); -1 for a launch that is not on record.                        */
 double   r3d_last_kernel_ms(r3d_engine* e);

@@ -45,6 +45,27 @@ def sphere(deg=9, source_depth=-10):
             "--seis-p2p=0,90,0,12000,90,0,20.0,20.0,400.0,160").split()
 
 
+def crustpinch_vids(deg=9):
+    """do-crustpinch-vids.sh:22-72: the crust-pinch model as a scatter-event video run -- pinned
+    mean free paths, scattering without deflection (scatter events become dense check-points,
+    ~10 SCT + REF events per history), 350 s, coarse bins, three 16-receiver lines.  With a
+    dense event grid attached this is BASELINE config 5."""
+    return ("--grid-compiled=5 "
+            "--model-args=0.8,0.01,0.20,0.2,200,0.8,0.01,0.20,0.3,1500,0.8,0.01,0.20,0.3,1500,"
+            "0.8,0.01,0.20,0.4,1500,0.8,0.01,0.20,0.5,900,2.0,30.0,5.0,.3666667,.4736842,1,1 "
+            "--source=SDR,22.5,90,0 --source-loc=0,0,-10 --frequency=2.0 --timetolive=350 "
+            f"--binsize=10.0 --toa-degree={deg} --overridemfp=25,50 --nodeflect "
+            "--seis-p2p=0,67.5,0,950,67.5,0,1.0,2.0,40.0,16 "
+            "--seis-p2p=0,112.5,0,950,112.5,0,1.0,2.0,40.0,16 "
+            "--seis-p2p=0,90,0,950,90,0,1.0,2.0,40.0,16").split()
+
+
+# Dense scatter-event grid of BASELINE config 5 (SURVEY.md 8(d) row 5): 2 wave types x 300 frames
+# x 64 x 256 x 256 uint32 = 10 GB over the crust-pinch model's footprint and the run's 350 s.
+CRUSTPINCH_VOLUME = dict(origin=(-1000.0, -1000.0, -250.0), cell_size=(2000.0 / 256, 2000.0 / 256, 250.0 / 64),
+                         dims=(256, 256, 64), n_frames=300, frame_dt=350.0 / 300)
+
+
 def toysphere_vids(deg=4):
     """do-toysphere-vids.sh:21-60: model 30, pinned mean free paths, scattering without
     deflection, raw output coordinates (a ray-path video run)."""
@@ -77,5 +98,5 @@ def upthrust(deg=4):
             "--seis-p2p=0,112.5,0,950,112.5,0,1.0,2.0,40.0,40").split()
 
 
-CONFIGS = {"halfspace": halfspace, "crustpinch": crustpinch, "lopnor": lopnor, "sphere": sphere,
+CONFIGS = {"halfspace": halfspace, "crustpinch": crustpinch, "crustpinch_vids": crustpinch_vids, "lopnor": lopnor, "sphere": sphere,
            "toysphere_vids": toysphere_vids, "lopnor_vids": lopnor_vids, "upthrust": upthrust}

@@ -734,7 +734,7 @@ struct r3d_engine {
   DevBuf d_energy, d_counts, d_scalars, d_next;
   // launches on different streams may be in flight together (a caller overlapping one
   // batch's drain with the next batch): each takes its own work counter from a small ring
-  static constexpr unsigned kCounters = 16;
+  static constexpr unsigned kCounters = 64;
   unsigned launch_seq = 0;
   // ... and its own pair of timing events, so that r3d_kernel_ms(e, launch) reads the launch
   // it names and not whichever recorded last

@@ -331,5 +331,5 @@ class Engine:
         return int(self._lib.r3d_launch_count(self._e))
 
     def kernel_ms(self, launch):
-        """Kernel time of launch id `launch` (one of the 16 most recent), -1 if not on record."""
+        """Kernel time of launch id `launch` (one of the 64 most recent), -1 if not on record."""
         return float(self._lib.r3d_kernel_ms(self._e, int(launch)))

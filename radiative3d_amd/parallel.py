@@ -70,3 +70,83 @@ class DeviceResult:
         res.counts[...] = self.counts.cpu().numpy()[:res.counts.size].astype(np.uint64).reshape(res.counts.shape)
         res.set_scalars(self.scalars.cpu().numpy())
         return res
+
+
+U32_MAX = 0xFFFFFFFF
+
+
+def _as_unsigned(chunk_i32):
+    """int32 storage holding uint32 counters -> their values as int64."""
+    return chunk_i32.to(torch.int64) & U32_MAX
+
+
+def _to_storage(values_i64):
+    """int64 values in [0, 2^32) -> the int32 bit pattern of the same uint32."""
+    return torch.where(values_i64 > 0x7FFFFFFF, values_i64 - (1 << 32), values_i64).to(torch.int32)
+
+
+class DeviceVolume:
+    """The volumetric scatter-event grid count[type][frame][z][y][x] (uint32, include/r3d.h
+    r3d_volume_desc) in caller-owned device memory, and its sum over ranks.
+
+    The reference has no such grid: its video pipeline writes one text line per SCT / REF
+    event (dataout.cpp:570-577) and the Octave scripts bin them per frame
+    (vis/scattervid/scattervid_above.m:111); replicas are combined by adding
+    (vis/seisplot/combine.m:26-33).  Here every rank's engine increments its own grid
+    (r3d_engine_set_volume_buffer) and `allreduce_` / `reduce_` add the grids once at the end
+    of the job.  The counters are uint32 (a 10 GB grid at the 300 x 64 x 256 x 256 size of
+    BASELINE config 5), and a sum over ranks of 1e8..1e9 histories could pass 2^32 in a hot
+    cell: the reduction therefore runs chunk by chunk in int64 and SATURATES at 2^32 - 1
+    instead of wrapping; `saturated` counts the cells that hit the ceiling.  (torch has no
+    arithmetic on uint32, so the storage is int32 holding the same bits.)"""
+
+    def __init__(self, engine, origin, cell_size, dims, n_frames, frame_dt, device):
+        self.shape = (2, int(n_frames), int(dims[2]), int(dims[1]), int(dims[0]))
+        n = 1
+        for d in self.shape:
+            n *= d
+        self.counters = torch.zeros(n, dtype=torch.int32, device=device)
+        self.saturated = 0
+        self.engine = engine
+        if engine is not None:
+            engine.set_volume_buffer(origin, cell_size, dims, n_frames, frame_dt, self.counters.data_ptr())
+
+    def zero_(self):
+        self.counters.zero_()
+        self.saturated = 0
+
+    def _reduce_chunks(self, collective, chunk_elems, keep):
+        """Widen, add over ranks, saturate, store back -- chunk by chunk so that the int64
+        scratch stays small next to a multi-GB grid."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return self
+        sat = 0
+        for lo in range(0, self.counters.numel(), chunk_elems):
+            part = self.counters[lo:lo + chunk_elems]
+            wide = _as_unsigned(part)
+            collective(wide)
+            if keep:
+                sat += int((wide > U32_MAX).sum().item())
+                part.copy_(_to_storage(wide.clamp_(max=U32_MAX)))
+        self.saturated += sat
+        return self
+
+    def allreduce_(self, chunk_elems=1 << 26):
+        """Every rank ends with the job's grid (one all-reduce(SUM) per chunk)."""
+        return self._reduce_chunks(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), chunk_elems, True)
+
+    def reduce_(self, dst=0, chunk_elems=1 << 26):
+        """Rank `dst` ends with the job's grid; the other ranks keep their own shard's."""
+        return self._reduce_chunks(lambda t: dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM), chunk_elems,
+                                   dist.is_initialized() and dist.get_rank() == dst)
+
+    def total(self, chunk_elems=1 << 26):
+        """Sum of all counters (events binned), computed chunk by chunk."""
+        t = 0
+        for lo in range(0, self.counters.numel(), chunk_elems):
+            t += int(_as_unsigned(self.counters[lo:lo + chunk_elems]).sum().item())
+        return t
+
+    def to_numpy(self):
+        import numpy as np
+        return self.counters.cpu().numpy().view(np.uint32).reshape(self.shape)

@@ -1,0 +1,49 @@
+"""bench.py --gpus N as the driver calls it (no launcher environment): the program must start N
+ranks itself and form one process group of that size (the reference's replicas:
+scripts/do-parallel.sh:23-29).  --rendezvous-only runs exactly that part on CPU (gloo)."""
+import json
+import os
+import subprocess
+import sys
+
+from radiative3d_amd import launch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(REPO, "bench.py")
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    return env
+
+
+def test_gpus_2_spawns_two_ranks_and_reports_the_group_size():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rendezvous-only"], env=_clean_env(),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
+
+
+def test_world_size_must_match_gpus_under_a_launcher():
+    env = _clean_env()
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(launch.free_port()))
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rendezvous-only"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "--gpus 2" in out.stderr
+
+
+def test_a_failing_rank_stops_the_job():
+    prog = ("import os, sys, time\n"
+            "r = int(os.environ['RANK'])\n"
+            "assert os.environ['WORLD_SIZE'] == '3' and os.environ['LOCAL_RANK'] == str(r)\n"
+            "if r == 1: sys.exit(7)\n"
+            "time.sleep(60)\n")
+    rc = launch.spawn_ranks(3, [sys.executable, "-c", prog])
+    assert rc != 0
+
+
+def test_under_launcher_detection():
+    assert not launch.under_launcher({})
+    assert launch.under_launcher({"RANK": "0", "WORLD_SIZE": "1", "MASTER_PORT": "1"})
