@@ -45,6 +45,11 @@ def sphere(deg=9, source_depth=-10):
             "--seis-p2p=0,90,0,12000,90,0,20.0,20.0,400.0,160").split()
 
 
+def sphere_deep(deg=9):
+    """BASELINE config 4: the spherical-Earth run with the double-couple source 600 km deep."""
+    return sphere(deg, source_depth=-600)
+
+
 def crustpinch_vids(deg=9):
     """do-crustpinch-vids.sh:22-72: the crust-pinch model as a scatter-event video run -- pinned
     mean free paths, scattering without deflection (scatter events become dense check-points,
@@ -98,5 +103,5 @@ def upthrust(deg=4):
             "--seis-p2p=0,112.5,0,950,112.5,0,1.0,2.0,40.0,40").split()
 
 
-CONFIGS = {"halfspace": halfspace, "crustpinch": crustpinch, "crustpinch_vids": crustpinch_vids, "lopnor": lopnor, "sphere": sphere,
+CONFIGS = {"halfspace": halfspace, "crustpinch": crustpinch, "crustpinch_vids": crustpinch_vids, "lopnor": lopnor, "sphere": sphere, "sphere_deep": sphere_deep,
            "toysphere_vids": toysphere_vids, "lopnor_vids": lopnor_vids, "upthrust": upthrust}

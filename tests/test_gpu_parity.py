@@ -10,7 +10,7 @@ from conftest import finals_differ
 from oracle import oracle_ffi as O
 from radiative3d_amd import Engine, Model, _ffi
 from radiative3d_amd.parallel import DeviceResult, shard_range
-from tests.configs import crustpinch, halfspace
+from tests.configs import crustpinch, halfspace, lopnor, sphere_deep
 
 pytestmark = pytest.mark.gpu
 
@@ -45,8 +45,8 @@ def check_against_oracle(engine, n, first_id=0, seed=0x5EED, allow_frac=0.0005):
 
 
 @pytest.mark.parametrize("name,n", [("halfspace", 50000), ("crustpinch", 20000), ("lopnor", 20000),
-                                    ("sphere", 3000), ("toysphere_vids", 2000), ("lopnor_vids", 2000),
-                                    ("upthrust", 20000)])
+                                    ("sphere", 3000), ("sphere_deep", 3000), ("toysphere_vids", 2000),
+                                    ("lopnor_vids", 2000), ("upthrust", 20000), ("crustpinch_vids", 5000)])
 def test_engine_matches_oracle_history_by_history(engines, name, n):
     check_against_oracle(engines(name), n)
 
@@ -124,13 +124,31 @@ def test_full_size_crustpinch_properties():
     assert a.n_invalid == 0
     assert int(a.counts.sum()) == a.events["catch"]
     assert np.allclose(a.energy[:, :, :3].sum(-1), a.energy[:, :, 3:].sum(-1), rtol=1e-10, atol=1e-300)
-    # reference 1 M-history run: timeout fraction 1.25e-4, 1.04 catches,
-    # 27.9 iterations, 23.9 transfers, 0.04 scatters per history
-    assert a.n_timeout / n == pytest.approx(1.25e-4, rel=0.25)
-    assert a.events["catch"] / n == pytest.approx(1.04, rel=0.10)
-    assert a.events["iterations"] / n == pytest.approx(27.9, rel=0.05)
-    assert a.events["transfer"] / n == pytest.approx(23.9, rel=0.05)
-    assert a.events["scatter"] / n == pytest.approx(0.04, rel=0.15)
+    # The survey's figures of the unmodified reference (tests/golden/reference_recorded.json), each
+    # held to its own Monte-Carlo error (tests/refstats.py): the 1 M-history loss counters to their
+    # counting error, the 5000-history event mix to 3 sigma of a 5000-history mean + print rounding,
+    # sigma from batch means of that size on the engine.
+    import json
+    import os
+    from refstats import poisson_fraction_tolerance, tolerance
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_recorded.json")))
+    loss = ref["crustpinch_1M_loss_counters"]
+    f_ref = loss["timeout"] / loss["_n_histories"]
+    assert abs(a.n_timeout / n - f_ref) <= poisson_fraction_tolerance(f_ref, loss["_n_histories"], a.n_timeout / n, n)
+    mix = ref["events_per_history"]
+    n_ref = mix["_n_histories"]
+    small = [e.run(n_ref, first_id=(3 << 40) + k * n_ref) for k in range(64)]
+    for k, v in mix["crustpinch"].items():
+        means = [r.events[k] / n_ref for r in small]
+        tol = tolerance(means, v)
+        print(f"crustpinch deg 9 {k:10s} reference {v:8.3f}  engine(1e7) {a.events[k] / n:8.4f}  allowed +-{tol:.3f}")
+        assert abs(a.events[k] / n - v) <= tol, (k, a.events[k] / n, v, tol)
+    big = [e.run(loss["_n_histories"], first_id=(5 << 40) + k * loss["_n_histories"]) for k in range(8)]
+    catches = [r.events["catch"] / loss["_n_histories"] for r in big]
+    tol = tolerance(catches, loss["catches_per_history"])
+    print(f"crustpinch deg 9 catches/history reference {loss['catches_per_history']}  engine {a.events['catch'] / n:.4f}"
+          f"  allowed +-{tol:.4f}")
+    assert abs(a.events["catch"] / n - loss["catches_per_history"]) <= tol
     # a disjoint id range is an independent sample: per-bin arrival counts are (compound)
     # Poisson -- a reverberating phonon can be caught more than once per bin -- so their
     # normalised differences look normal with a spread a little above 1; total energy agrees to ~1 %
@@ -143,6 +161,138 @@ def test_full_size_crustpinch_properties():
     assert a.energy.sum() == pytest.approx(b.energy.sum(), rel=0.02)
     # small-sample oracle comparison on the big tables too
     check_against_oracle(e, 3000, first_id=123456789)
+
+
+def independent_halves_agree(e, n, min_bins):
+    """Two disjoint id ranges are independent samples: per-bin arrival counts are (compound) Poisson,
+    so their normalised differences look normal with a spread a little above 1.  (Their mean is not
+    held to 1/sqrt(bins): one long-reverberating history feeds many bins, so bins share fluctuations
+    -- 0.16 between two 1e7-history LopNor samples.)"""
+    a, b = e.run(n, first_id=0), e.run(n, first_id=n)
+    for r in (a, b):
+        assert r.n_lost + r.n_timeout + r.n_invalid == n and r.events["generated"] == n
+        assert int(r.counts.sum()) == r.events["catch"]
+        assert np.allclose(r.energy[:, :, :3].sum(-1), r.energy[:, :, 3:].sum(-1), rtol=1e-10, atol=1e-300)
+    na, nb = a.counts.astype(float), b.counts.astype(float)
+    sel = (na + nb) >= 50
+    assert sel.sum() > min_bins
+    z = (na[sel] - nb[sel]) / np.sqrt(na[sel] + nb[sel])
+    assert abs(z.mean()) < 0.3 and 0.9 < z.std() < 1.6, (z.mean(), z.std())
+    return a, b
+
+
+def reference_event_mix(e, name, whole, n):
+    """The survey's 5000-history event mix of the reference for this model, at its own error."""
+    import json
+    import os
+    from refstats import tolerance
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_recorded.json")))
+    mix = ref["events_per_history"]
+    n_ref = mix["_n_histories"]
+    small = [e.run(n_ref, first_id=(3 << 40) + k * n_ref) for k in range(32)]
+    for k, v in mix[name].items():
+        means = [r.events[k] / n_ref for r in small]
+        tol = tolerance(means, v)
+        print(f"{name} deg 9 {k:10s} reference {v:8.3f}  engine {whole.events[k] / n:8.4f}  allowed +-{tol:.3f}")
+        assert abs(whole.events[k] / n - v) <= tol, (k, whole.events[k] / n, v, tol)
+
+
+def test_full_size_lopnor_properties():
+    """BASELINE config 3 at its full table size (TOA degree 9: 21 scatterers, 4.4 GB of tables;
+    explosion source), 1e7 histories: size-independent properties, the survey's event mix, and a
+    small-sample oracle comparison on the big tables."""
+    m = Model(lopnor(9))
+    assert m.n_toa == 20 * 4 ** 9 and (m.n_cells, m.n_scatterers, m.n_seismometers) == (21, 21, 320)
+    e = Engine(m)
+    n = 10_000_000
+    a, b = independent_halves_agree(e, n, 3000)
+    assert a.n_invalid == 0 and a.energy.sum() == pytest.approx(b.energy.sum(), rel=0.03)
+    reference_event_mix(e, "lopnor", a, n)
+    check_against_oracle(e, 3000, first_id=987654321)
+    e.close()
+
+
+def test_full_size_sphere_deep_source_properties():
+    """BASELINE config 4 at its full table size (TOA degree 9: 15 scatterers, 3.1 GB of tables;
+    double-couple source 600 km deep), 2e6 histories.  Every history ends at the time limit (a
+    whole Earth has no loss surface).  The survey's event mix was taken with the script's 10 km
+    source, so it is checked on that source's engine."""
+    m = Model(sphere_deep(9))
+    assert m.n_toa == 20 * 4 ** 9 and (m.n_cells, m.n_scatterers, m.n_seismometers) == (15, 15, 480)
+    e = Engine(m)
+    n = 2_000_000
+    a, b = independent_halves_agree(e, n, 3000)
+    assert a.n_timeout == n and a.n_invalid == 0
+    assert a.events["scatter"] / n > 50 and a.events["rtsolve"] / n > 20
+    check_against_oracle(e, 1500, first_id=24680)
+    e.close()
+    from tests.configs import sphere
+    e = Engine(Model(sphere(9)))
+    whole = e.run(1_000_000)
+    reference_event_mix(e, "sphere", whole, 1_000_000)
+    e.close()
+
+
+def _two_rank_worker(rank, world, port, n, out_path):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = Model(lopnor(4) + ["--device-tables"])      # the multi-rank bench builds its tables on the device
+    e = Engine(model, device=0)
+    dev = DeviceResult(model, "cuda:0")
+    lo, hi = shard_range(n, rank, world)
+    e.run_device(hi - lo, lo, 0x5EED, *dev.pointers())
+    torch.cuda.synchronize()
+    host = DeviceResult(model, "cpu")                   # gloo reduces host tensors; RCCL needs a GPU per rank
+    host.energy.copy_(dev.energy), host._ints.copy_(dev._ints)
+    host.allreduce_()
+    if rank == 0:
+        r = host.to_result()
+        np.savez(out_path, energy=r.energy, counts=r.counts, scalars=r.scalars())
+    dist.barrier()
+    e.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_the_gpu_sum_to_one_engine_run(engines, tmp_path):
+    """The multi-rank path end to end with real engines: two rank processes (both on this box's one
+    GPU), device-built tables, id shards, r3d_run_device into DeviceResult buffers, one all-reduce
+    (gloo here -- RCCL wants a GPU per rank) -- equal to a single engine's run of the union range."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    n = 200_001
+    out = str(tmp_path / "two.npz")
+    mp.spawn(_two_rank_worker, args=(2, port, n, out), nprocs=2, join=True)
+    got = np.load(out)
+    want = engines("lopnor", 4, ("--device-tables",)).run(n)
+    assert (got["counts"] == want.counts).all() and (got["scalars"] == want.scalars()).all()
+    assert np.allclose(got["energy"], want.energy, rtol=1e-11, atol=1e-300)
+
+
+def test_engine_leaves_the_callers_device_and_refuses_to_drop_carried_histories(engines):
+    e = engines("halfspace")
+    before = torch.cuda.current_device()
+    e.run(1000)
+    assert torch.cuda.current_device() == before
+    buf = DeviceResult(e.model, "cuda:0")
+    e.run_device(200000, 0, 9, *buf.pointers(), carry="carry")
+    torch.cuda.synchronize()
+    assert e.carry_pending
+    with pytest.raises(RuntimeError, match="carried"):
+        e.close()
+    e.run_device(0, 0, 9, *buf.pointers(), carry="final")
+    torch.cuda.synchronize()
+    assert not e.carry_pending
+    r = buf.to_result()
+    assert r.n_lost + r.n_timeout + r.n_invalid == 200000
+    # launches are timed one by one
+    k = e.launch_count()
+    assert e.kernel_ms(k) > 0 and e.kernel_ms(k - 1) > 0 and e.kernel_ms(k) != e.kernel_ms(k - 1)
+    assert e.kernel_ms(k + 1) == -1.0 and e.kernel_ms(0) == -1.0
 
 
 def test_one_call_seam_equals_engine_run(engines):
