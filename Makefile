@@ -56,3 +56,9 @@ oracle/libr3d_oracle.so: oracle/r3d_oracle.cpp oracle/philox.h include/r3d.h
 
 clean:
 	rm -f $(LIBDIR)/*.so oracle/*.so main
+
+# Developer variants of the engine (timing-only / diagnostic builds, never shipped as libr3d_hip.so):
+#   make variant NAME=PHASE DEFS="-DR3D_PHASE_TIMING"   ->  radiative3d_amd/lib/variant_PHASE.so
+# run with R3D_HIP_LIB=radiative3d_amd/lib/variant_PHASE.so (tools/time_chain.py, tools/pool_stats.py)
+variant:
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -shared -pthread -o $(LIBDIR)/variant_$(NAME).so $(ENGINE_SRC)

@@ -662,6 +662,10 @@ __global__ __launch_bounds__(kBlock) void drain_kernel(const KArgs a) {
   propagate_body<KIND, RES, false>(a);
 }
 
+}  // namespace r3d
+#include "r3d_pool.h"
+namespace r3d {
+
 // ------------------------------------------------------------------- engine --
 thread_local std::string g_error;
 
@@ -724,6 +728,8 @@ struct r3d_engine {
   int device = 0;
   int kind = 0;
   int res = RES_ALL;   // which tables live in LDS (see propagate_kernel)
+  bool pool = true;    // the pool kernel (r3d_pool.h); false: the lane-resident kernel (R3D_KERNEL=lanes)
+  size_t carry_bytes = 0;
   int n_seis = 0;
   uint32_t n_bins = 0;
   KArgs args{};
@@ -800,7 +806,28 @@ hipError_t with_kernel(const r3d_engine* e, F&& f) {
   }
 }
 
+// pool kernels: res 0 = cell records + scatterer heads in LDS, 1 = scatterer heads only, 2 = neither
+template <class F>
+hipError_t with_pool_kernel(const r3d_engine* e, F&& f) {
+  return with_kernel(e, [&](auto kind, auto res) {
+    constexpr int K = decltype(kind)::value, R = decltype(res)::value;
+    return f(kind, std::integral_constant<bool, R == RES_ALL>{}, std::integral_constant<bool, R != RES_NONE>{});
+  });
+}
+
 hipError_t launch_any(r3d_engine* e, const KArgs& a, bool trace, hipStream_t s, bool drain_only = false) {
+  if (e->pool)
+    return with_pool_kernel(e, [&](auto kind, auto cells, auto scat) {
+      constexpr int K = decltype(kind)::value;
+      constexpr bool C = decltype(cells)::value, H = decltype(scat)::value;
+      if (drain_only && !trace)
+        hipLaunchKernelGGL((pool_drain_kernel<K, C, H>), dim3(e->grid_blocks), dim3(kPoolBlock), e->lds_bytes, s, a);
+      else if (trace)
+        hipLaunchKernelGGL((pool_kernel<K, C, H, true>), dim3(e->grid_blocks), dim3(kPoolBlock), e->lds_bytes, s, a);
+      else
+        hipLaunchKernelGGL((pool_kernel<K, C, H, false>), dim3(e->grid_blocks), dim3(kPoolBlock), e->lds_bytes, s, a);
+      return hipGetLastError();
+    });
   return with_kernel(e, [&](auto kind, auto res) {
     constexpr int K = decltype(kind)::value, R = decltype(res)::value;
     if (drain_only && !trace)
@@ -814,6 +841,19 @@ hipError_t launch_any(r3d_engine* e, const KArgs& a, bool trace, hipStream_t s, 
 }
 
 hipError_t set_lds_attr(const r3d_engine* e) {
+  if (e->pool)
+    return with_pool_kernel(e, [&](auto kind, auto cells, auto scat) {
+      constexpr int K = decltype(kind)::value;
+      constexpr bool C = decltype(cells)::value, H = decltype(scat)::value;
+      hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_kernel<K, C, H, false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
+      if (r != hipSuccess) return r;
+      r = hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_drain_kernel<K, C, H>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
+      if (r != hipSuccess) return r;
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_kernel<K, C, H, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
+    });
   return with_kernel(e, [&](auto kind, auto res) {
     constexpr int K = decltype(kind)::value, R = decltype(res)::value;
     hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_kernel<K, R, false>),
@@ -1005,53 +1045,106 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   }
 
   // ---- LDS carve-up and launch geometry ----
-  auto align16 = [](size_t x) { return (x + 15) & ~size_t(15); };
-  size_t off = 0;
-  // static LDS of the kernel: the waves' catch queues and the block's tallies
-  const size_t kStaticLds = sizeof(CatchQueue) * kWaves + 1024;
-  const size_t scat_bytes = (size_t)m->n_scatterers * sizeof(ScatHead);
-  const size_t scan_bytes = (size_t)std::max(1, m->n_seismometers) * sizeof(SeisScan);
-  // The scatterer heads and the receiver scan records go to LDS unless they would leave
-  // less than 16 KB for everything else (thousands of scatterers or receivers); the cell
-  // records go with them when they are small (layered and spherical models).
-  const bool tables_fit = scat_bytes + scan_bytes + kStaticLds + 16 * 1024 <= 160 * 1024;
-  const bool cells_fit = tables_fit && cell_bytes <= 48 * 1024 &&
-                         cell_bytes + scat_bytes + scan_bytes + kStaticLds + 16 * 1024 <= 160 * 1024;
-  e->res = cells_fit ? RES_ALL : tables_fit ? RES_TABLES : RES_NONE;
-  a.lds_cells_off = a.lds_scat_off = a.lds_seis_off = 0xFFFFFFFFu;
-  if (cells_fit) a.lds_cells_off = (uint32_t)off, off = align16(off + cell_bytes);
-  if (tables_fit) {
-    a.lds_scat_off = (uint32_t)off, off = align16(off + scat_bytes);
-    a.lds_seis_off = (uint32_t)off, off = align16(off + scan_bytes);
-  }
-  // the receiver "hit" records go to LDS only if everything still fits in the CU's 160 KB
-  const size_t hit_bytes = (size_t)std::max(1, m->n_seismometers) * sizeof(SeisHit);
-  a.lds_hit_off = 0xFFFFFFFFu;
-  if (tables_fit && off + hit_bytes + kStaticLds + 8192 <= 160 * 1024)
-    a.lds_hit_off = (uint32_t)off, off = align16(off + hit_bytes);
-  // the seismometer hash, when it is small (it is for the reference's survey lines and arrays:
-  // a few thousand cells): both levels of the lookup become LDS reads instead of two
-  // dependent global loads in every collecting iteration
-  a.lds_grid_off = 0xFFFFFFFFu, a.grid_n_items = (uint32_t)pm.grid_items.size();
-  {
-    const size_t grid_bytes = ((size_t)a.grid.n_cells + 1) * sizeof(uint32_t) + pm.grid_items.size() * sizeof(uint16_t);
-    if (m->n_seismometers > 0 && m->n_seismometers <= 65535 && grid_bytes <= 40 * 1024 &&
-        off + grid_bytes + kStaticLds + 8192 <= 160 * 1024)
-      a.lds_grid_off = (uint32_t)off, off = align16(off + grid_bytes);
-  }
-  // what is left (minus a little slack) goes to the bin accumulators
-  a.lds_acc_off = (uint32_t)off, a.acc_bits = 0;
-  if (m->n_seismometers > 0) {
-    const size_t left = 160 * 1024 - std::min<size_t>(160 * 1024, off + kStaticLds + 2048);
-    uint32_t bits = 0;
-    while (bits < 11 && (kAccEntryBytes << (bits + 1)) <= left) bits++;
-    if (const char* s = getenv("R3D_ACC_BITS")) bits = std::min<uint32_t>(bits, (uint32_t)atoi(s));   // developer tuning
-    if (bits >= 5) a.acc_bits = bits, off = align16(off + (kAccEntryBytes << bits));
-  }
-  e->lds_bytes = off;
-  if (e->lds_bytes + kStaticLds > 160 * 1024) {
-    g_error = "internal error: LDS carve-up exceeds the 160 KB of a CU";
-    return nullptr;
+  if (const char* k = getenv("R3D_KERNEL")) e->pool = std::string(k) != "lanes";   // developer A/B
+  a.grid_n_items = (uint32_t)pm.grid_items.size();
+  if (e->pool) {
+    // Pool kernel (r3d_pool.h): the cell records (when there are few of them) and the scatterer
+    // heads are staged in LDS, then a minimum of bin accumulators, and everything else goes to
+    // the pool: S slots of 128 B plus the six rings of 16-bit slot numbers.
+    auto align16 = [](size_t x) { return (x + 15) & ~size_t(15); };
+    const size_t kLds = 160 * 1024, kStatic = 1024;   // static: queue control words, tallies
+    const size_t scat_bytes = (size_t)m->n_scatterers * sizeof(ScatHead);
+    const bool scat_fit = scat_bytes <= 24 * 1024;
+    const bool cells_fit = scat_fit && cell_bytes + scat_bytes <= 24 * 1024;
+    e->res = cells_fit ? RES_ALL : scat_fit ? RES_TABLES : RES_NONE;
+    size_t off = 0;
+    a.lds_cells_off = a.lds_scat_off = a.lds_seis_off = a.lds_hit_off = a.lds_grid_off = 0xFFFFFFFFu;
+    if (cells_fit) a.lds_cells_off = (uint32_t)off, off = align16(off + cell_bytes);
+    if (scat_fit) a.lds_scat_off = (uint32_t)off, off = align16(off + scat_bytes);
+    uint32_t acc_bits = m->n_seismometers > 0 ? 8u : 0u;   // 256 accumulators = 13 KB ...
+    if (const char* s = getenv("R3D_ACC_BITS")) acc_bits = (uint32_t)atoi(s);   // developer tuning
+    if (acc_bits && acc_bits < 5) acc_bits = 0;
+    a.lds_acc_off = (uint32_t)off, a.acc_bits = acc_bits;
+    if (acc_bits) off = align16(off + (kAccEntryBytes << acc_bits));
+    const size_t left = kLds - kStatic - off;
+    // S slots need 128 S bytes + 6 rings of (power of two >= S) u16: try the largest first
+    uint32_t slots = 0, cap = 0;
+    for (uint32_t s_try = 2048; s_try >= 128; s_try -= 64) {
+      uint32_t c = 64;
+      while (c < s_try) c <<= 1;
+      if ((size_t)s_try * sizeof(Slot) + (size_t)Q_NUM * c * sizeof(uint16_t) <= left) {
+        slots = s_try, cap = c;
+        break;
+      }
+    }
+    if (const char* s = getenv("R3D_POOL_SLOTS")) {   // developer tuning (never more than fits)
+      const uint32_t want = (uint32_t)atoi(s) / 64 * 64;
+      if (want >= 64 && want < slots) {
+        slots = want, cap = 64;
+        while (cap < slots) cap <<= 1;
+      }
+    }
+    if (slots < (uint32_t)kPoolBlock) {
+      g_error = "internal error: the model's LDS tables leave no room for the phonon pool";
+      return nullptr;
+    }
+    a.pool_slots = slots, a.pool_ring_mask = cap - 1;
+    a.lds_pool_off = (uint32_t)off, off += (size_t)slots * sizeof(Slot);
+    a.lds_ring_off = (uint32_t)off, off = align16(off + (size_t)Q_NUM * cap * sizeof(uint16_t));
+    e->lds_bytes = off;
+    if (e->lds_bytes + kStatic > kLds) {
+      g_error = "internal error: LDS carve-up exceeds the 160 KB of a CU";
+      return nullptr;
+    }
+  } else {
+    auto align16 = [](size_t x) { return (x + 15) & ~size_t(15); };
+    size_t off = 0;
+    // static LDS of the kernel: the waves' catch queues and the block's tallies
+    const size_t kStaticLds = sizeof(CatchQueue) * kWaves + 1024;
+    const size_t scat_bytes = (size_t)m->n_scatterers * sizeof(ScatHead);
+    const size_t scan_bytes = (size_t)std::max(1, m->n_seismometers) * sizeof(SeisScan);
+    // The scatterer heads and the receiver scan records go to LDS unless they would leave
+    // less than 16 KB for everything else (thousands of scatterers or receivers); the cell
+    // records go with them when they are small (layered and spherical models).
+    const bool tables_fit = scat_bytes + scan_bytes + kStaticLds + 16 * 1024 <= 160 * 1024;
+    const bool cells_fit = tables_fit && cell_bytes <= 48 * 1024 &&
+                           cell_bytes + scat_bytes + scan_bytes + kStaticLds + 16 * 1024 <= 160 * 1024;
+    e->res = cells_fit ? RES_ALL : tables_fit ? RES_TABLES : RES_NONE;
+    a.lds_cells_off = a.lds_scat_off = a.lds_seis_off = 0xFFFFFFFFu;
+    if (cells_fit) a.lds_cells_off = (uint32_t)off, off = align16(off + cell_bytes);
+    if (tables_fit) {
+      a.lds_scat_off = (uint32_t)off, off = align16(off + scat_bytes);
+      a.lds_seis_off = (uint32_t)off, off = align16(off + scan_bytes);
+    }
+    // the receiver "hit" records go to LDS only if everything still fits in the CU's 160 KB
+    const size_t hit_bytes = (size_t)std::max(1, m->n_seismometers) * sizeof(SeisHit);
+    a.lds_hit_off = 0xFFFFFFFFu;
+    if (tables_fit && off + hit_bytes + kStaticLds + 8192 <= 160 * 1024)
+      a.lds_hit_off = (uint32_t)off, off = align16(off + hit_bytes);
+    // the seismometer hash, when it is small (it is for the reference's survey lines and arrays:
+    // a few thousand cells): both levels of the lookup become LDS reads instead of two
+    // dependent global loads in every collecting iteration
+    a.lds_grid_off = 0xFFFFFFFFu, a.grid_n_items = (uint32_t)pm.grid_items.size();
+    {
+      const size_t grid_bytes = ((size_t)a.grid.n_cells + 1) * sizeof(uint32_t) + pm.grid_items.size() * sizeof(uint16_t);
+      if (m->n_seismometers > 0 && m->n_seismometers <= 65535 && grid_bytes <= 40 * 1024 &&
+          off + grid_bytes + kStaticLds + 8192 <= 160 * 1024)
+        a.lds_grid_off = (uint32_t)off, off = align16(off + grid_bytes);
+    }
+    // what is left (minus a little slack) goes to the bin accumulators
+    a.lds_acc_off = (uint32_t)off, a.acc_bits = 0;
+    if (m->n_seismometers > 0) {
+      const size_t left = 160 * 1024 - std::min<size_t>(160 * 1024, off + kStaticLds + 2048);
+      uint32_t bits = 0;
+      while (bits < 11 && (kAccEntryBytes << (bits + 1)) <= left) bits++;
+      if (const char* s = getenv("R3D_ACC_BITS")) bits = std::min<uint32_t>(bits, (uint32_t)atoi(s));   // developer tuning
+      if (bits >= 5) a.acc_bits = bits, off = align16(off + (kAccEntryBytes << bits));
+    }
+    e->lds_bytes = off;
+    if (e->lds_bytes + kStaticLds > 160 * 1024) {
+      g_error = "internal error: LDS carve-up exceeds the 160 KB of a CU";
+      return nullptr;
+    }
   }
   hipDeviceProp_t prop;
   R3D_HIP_OK(hipGetDeviceProperties(&prop, device));
@@ -1059,9 +1152,11 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   // persistent grid: exactly the workgroups that can be resident at once (register- and
   // LDS-limited), so every block is running while there is work and none queues behind
   int per_cu = 1;
-  R3D_HIP_OK(blocks_per_cu(e.get(), &per_cu));
+  if (!e->pool) R3D_HIP_OK(blocks_per_cu(e.get(), &per_cu));   // (the pool takes the CU's whole LDS: one workgroup)
   per_cu = std::max(1, std::min(per_cu, 8));
   e->grid_blocks = prop.multiProcessorCount * per_cu;
+  e->carry_bytes = e->pool ? (size_t)e->grid_blocks * a.pool_slots * sizeof(Slot)
+                           : (size_t)e->grid_blocks * kBlock * sizeof(CarrySlot);
 
   // ---- result scratch, work counter, stream, events ----
   R3D_HIP_OK(e->d_energy.alloc_zero((size_t)std::max(1, e->n_seis) * e->n_bins * R3D_N_ENERGY * sizeof(double)));
@@ -1127,7 +1222,7 @@ static int enqueue(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, 
       return g_error = "carried histories were started under another seed", 1;
     if (!e->d_carry) {
       auto buf = std::make_unique<DevBuf>();
-      R3D_HIP_OK(buf->alloc_zero((size_t)e->grid_blocks * kBlock * sizeof(CarrySlot)));
+      R3D_HIP_OK(buf->alloc_zero(e->carry_bytes));
       e->d_carry = std::move(buf);
     }
     if (e->carry_pending) a.carry_in = e->d_carry->p, must_launch = true;
@@ -1244,6 +1339,13 @@ int r3d_run_traced(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, 
 }
 
 #ifdef R3D_PHASE_TIMING
+// diagnostic builds only: per queue of the pool kernel, batches served / lanes filled / wave cycles
+// since the last call (slot 6 of the first row: idle polls)
+int r3d_debug_pool_stats(unsigned long long out[24]) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pool_stats), 24 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  unsigned long long zero[24] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_pool_stats), zero, sizeof zero) != hipSuccess;
+}
 // diagnostic builds only: cumulative per-phase wave cycles since the last call
 int r3d_debug_phase_cycles(unsigned long long out[8]) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;

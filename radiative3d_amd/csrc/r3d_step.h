@@ -250,15 +250,17 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
 // the kernel.
 // PART selects what is compiled in: EV_ALL everything; EV_LIGHT everything but the
 // reflection/transmission solve (the caller guarantees the event is not one); EV_RT only
-// that solve (the caller guarantees it is one).  The kernel's two call sites use the
-// halves, which keeps its code -- and its instruction-cache footprint -- smaller.
-enum { EV_ALL = 0, EV_LIGHT = 1, EV_RT = 2 };
+// that solve (the caller guarantees it is one); EV_SCATTER only the scattering branch (the
+// caller guarantees ev.face < 0); EV_BEND only the face branch without the solve (Snell bend
+// or hand-over; the caller guarantees a face with a neighbour and no solve).  The kernel calls
+// the parts from separate, wave-wide phases, which keeps each call site's code small.
+enum { EV_ALL = 0, EV_LIGHT = 1, EV_RT = 2, EV_SCATTER = 3, EV_BEND = 4 };
 template <int KIND, int PART = EV_ALL>
 R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng, LaneStats& st,
                       const Pending& ev) {
   using Cell = typename CellOf<KIND>::type;
   const Cell& c = T.cells[p.cell];
-  if (PART != EV_RT && ev.face < 0) {
+  if (PART == EV_SCATTER || (PART != EV_RT && PART != EV_BEND && ev.face < 0)) {
     // Scatterer::GetRandomScatteredRelativePhonon, scatterers.cpp:318-363
     st.scatter++;
     if (a.no_deflect) {
@@ -280,12 +282,13 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
     volume_count(a, p);   // SCT
     return FATE_ALIVE;
   }
+  if (PART == EV_SCATTER) return FATE_ALIVE;   // (not reached)
   const uint32_t fl = ev.flags;
   if (!(fl & (F_REFLECT | F_ADJOIN))) return FATE_LOST;  // phonons.cpp:675
   const int nbr = cell_neighbor(c, ev.face);
   const bool adjoin = (fl & F_ADJOIN) != 0;
   bool crossed;
-  if (PART != EV_LIGHT && (PART == EV_RT || (fl & F_REFLECT) || (fl & F_DISCON))) {
+  if (PART != EV_LIGHT && PART != EV_BEND && (PART == EV_RT || (fl & F_REFLECT) || (fl & F_DISCON))) {
     Iface f;
     f.normal = cell_face_normal(c, ev.face, p.loc);
     f.vR[0] = cell_velocity(c, p.loc, 0), f.vR[1] = cell_velocity(c, p.loc, 1);

@@ -169,6 +169,11 @@ struct KArgs {
   uint32_t grid_n_items;
   uint32_t lds_acc_off;      // bin accumulators (see BinCache in r3d_engine.hip)
   uint32_t acc_bits;         // 2^acc_bits accumulator entries; 0: none
+  // phonon pool (r3d_pool.h): slots of histories in flight and the rings of the phase queues
+  uint32_t pool_slots;       // S, a multiple of 64
+  uint32_t pool_ring_mask;   // ring capacity - 1 (capacity: the power of two >= S)
+  uint32_t lds_pool_off;
+  uint32_t lds_ring_off;
 };
 
 }  // namespace r3d

@@ -23,7 +23,7 @@ for c in $configs; do
   i=0
   for set in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" \
              "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
-             "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
+             "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
     i=$((i+1))
     echo "== $c: pmc pass $i ($set)" >&2
     timeout -k 10 300 rocprofv3 --pmc $set -d $out/pmc_${c}_$i -o pmc --output-format csv -- $B > $out/pmc_${c}_$i.log 2>&1

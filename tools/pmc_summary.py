@@ -21,7 +21,7 @@ for f in sorted(glob.glob(f"{out}/pmc_{config}_*/**/*counter_collection.csv", re
     for row in csv.DictReader(open(f)):
         if "drain_kernel" in row["Kernel_Name"]:
             drain[row["Counter_Name"]][int(row["Dispatch_Id"])] += float(row["Counter_Value"])
-        if "propagate_kernel" not in row["Kernel_Name"]:
+        if not ("propagate_kernel" in row["Kernel_Name"] or "pool_kernel" in row["Kernel_Name"]):
             continue
         acc[row["Counter_Name"]][int(row["Dispatch_Id"])] += float(row["Counter_Value"])
         if kern is None:
@@ -45,7 +45,8 @@ res = {"config": config, "toa_degree": 9, "histories_per_launch": bench.workload
                   "per counter group, no tracing)",
        "kernel": kern}
 for name in ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
-             "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE"):
+             "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_SALU",
+             "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
     res[name] = mean(name)
 if mean("FETCH_SIZE") is not None and mean("WRITE_SIZE") is not None:
     # KiB per dispatch -> bytes.  The gfx950 x2 FETCH_SIZE correction of MI355X_MICROARCH.md holds for wide
