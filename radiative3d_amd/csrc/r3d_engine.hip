@@ -1050,7 +1050,7 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   if (e->pool) {
     // Pool kernel (r3d_pool.h): the cell records (when there are few of them) and the scatterer
     // heads are staged in LDS, then a minimum of bin accumulators, and everything else goes to
-    // the pool: S slots of 128 B plus the six rings of 16-bit slot numbers.
+    // the pool: S slots of 124 B (field-major) plus the rings of 16-bit slot numbers.
     auto align16 = [](size_t x) { return (x + 15) & ~size_t(15); };
     const size_t kLds = 160 * 1024, kStatic = 1024;   // static: queue control words, tallies
     const size_t scat_bytes = (size_t)m->n_scatterers * sizeof(ScatHead);
@@ -1067,12 +1067,12 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
     a.lds_acc_off = (uint32_t)off, a.acc_bits = acc_bits;
     if (acc_bits) off = align16(off + (kAccEntryBytes << acc_bits));
     const size_t left = kLds - kStatic - off;
-    // S slots need 128 S bytes + 6 rings of (power of two >= S) u16: try the largest first
+    // S slots need 124 S bytes + one ring of (power of two >= S) u16 per queue: try the largest first
     uint32_t slots = 0, cap = 0;
     for (uint32_t s_try = 2048; s_try >= 128; s_try -= 64) {
       uint32_t c = 64;
       while (c < s_try) c <<= 1;
-      if ((size_t)s_try * sizeof(Slot) + (size_t)Q_NUM * c * sizeof(uint16_t) <= left) {
+      if ((size_t)s_try * kSlotBytes + (size_t)Q_NUM * c * sizeof(uint16_t) <= left) {
         slots = s_try, cap = c;
         break;
       }
@@ -1089,7 +1089,7 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
       return nullptr;
     }
     a.pool_slots = slots, a.pool_ring_mask = cap - 1;
-    a.lds_pool_off = (uint32_t)off, off += (size_t)slots * sizeof(Slot);
+    a.lds_pool_off = (uint32_t)off, off = align16(off + (size_t)slots * kSlotBytes);
     a.lds_ring_off = (uint32_t)off, off = align16(off + (size_t)Q_NUM * cap * sizeof(uint16_t));
     e->lds_bytes = off;
     if (e->lds_bytes + kStatic > kLds) {
@@ -1155,7 +1155,7 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   if (!e->pool) R3D_HIP_OK(blocks_per_cu(e.get(), &per_cu));   // (the pool takes the CU's whole LDS: one workgroup)
   per_cu = std::max(1, std::min(per_cu, 8));
   e->grid_blocks = prop.multiProcessorCount * per_cu;
-  e->carry_bytes = e->pool ? (size_t)e->grid_blocks * a.pool_slots * sizeof(Slot)
+  e->carry_bytes = e->pool ? (size_t)e->grid_blocks * a.pool_slots * kSlotBytes
                            : (size_t)e->grid_blocks * kBlock * sizeof(CarrySlot);
 
   // ---- result scratch, work counter, stream, events ----

@@ -72,6 +72,80 @@ R3D_HD double asin_small(double x) {
   return x + x * (p / q);
 }
 
+// ---- lean elementary functions for the hot path ------------------------------------------------
+// The device library's exp / log / sincos carry argument screening, table look-ups and special-case
+// repair that the traversal never needs (arguments are finite, of moderate size, and a NaN may
+// simply propagate); with the loop's constants re-materialised on every iteration they cost 45-120
+// instructions a call, and the kernel is bound by instruction issue.  These versions are plain
+// argument reduction + one polynomial; errors stay below 1-2 ulp, far inside the 1e-9 the parity
+// tests allow.
+//
+// exp(x), any finite x of moderate size (the attenuation exponent -pi f t / Q): x = k ln2 + r,
+// |r| <= ln2 / 2, e^r by its Taylor polynomial of degree 13 (|r|^14 / 14! < 5e-18), scaled by 2^k.
+R3D_HD double exp_lean(double x) {
+  const double k = rint(x * 1.4426950408889634074);
+  double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);   // ln2 in two parts
+  r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;   // 1/13!
+  p = __builtin_fma(p, r, 1.0 / 479001600.0);
+  p = __builtin_fma(p, r, 1.0 / 39916800.0);
+  p = __builtin_fma(p, r, 1.0 / 3628800.0);
+  p = __builtin_fma(p, r, 1.0 / 362880.0);
+  p = __builtin_fma(p, r, 1.0 / 40320.0);
+  p = __builtin_fma(p, r, 1.0 / 5040.0);
+  p = __builtin_fma(p, r, 1.0 / 720.0);
+  p = __builtin_fma(p, r, 1.0 / 120.0);
+  p = __builtin_fma(p, r, 1.0 / 24.0);
+  p = __builtin_fma(p, r, 1.0 / 6.0);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return ldexp(p, (int)k);
+}
+// atanh(y) for |y| <= 0.2 by its odd series y + y^3/3 + ... + y^23/23 (first term left out:
+// y^25 / 25, below 1e-18 relative to y on this interval).
+R3D_HD double atanh_small(double y) {
+  const double t = y * y;
+  double p = 1.0 / 23.0;
+  p = __builtin_fma(p, t, 1.0 / 21.0);
+  p = __builtin_fma(p, t, 1.0 / 19.0);
+  p = __builtin_fma(p, t, 1.0 / 17.0);
+  p = __builtin_fma(p, t, 1.0 / 15.0);
+  p = __builtin_fma(p, t, 1.0 / 13.0);
+  p = __builtin_fma(p, t, 1.0 / 11.0);
+  p = __builtin_fma(p, t, 1.0 / 9.0);
+  p = __builtin_fma(p, t, 1.0 / 7.0);
+  p = __builtin_fma(p, t, 1.0 / 5.0);
+  p = __builtin_fma(p, t, 1.0 / 3.0);
+  return __builtin_fma(y * t, p, y);
+}
+// sin and cos for |x| <= pi/4: the classical kernels (fdlibm k_sin.c / k_cos.c coefficients, error
+// below one ulp on this interval); no argument reduction.
+R3D_HD void sincos_small(double x, double* s, double* c) {
+  const double z = x * x;
+  double ps = 1.58969099521155010221e-10;
+  ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+  ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+  ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+  ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+  ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+  *s = __builtin_fma(x * z, ps, x);
+  double pc = -1.13596475577881948265e-11;
+  pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+  pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+  pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+  pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+  pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+  *c = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+}
+
+// sin and cos of a rotation angle: the small-argument kernels where they apply (a scatter leg is a
+// fraction of a cell), else the library's.
+R3D_HD void rotation(double x, double* s, double* c) {
+  if (fabs(x) <= 0.78539816339744830962) sincos_small(x, s, c);
+  else sincos(x, s, c);
+}
+
 struct V3 {
   double x, y, z;
 };

@@ -105,7 +105,7 @@ R3D_HD void cyl_advance(const CellCyl& c, Phonon& p, double len) {
   double time = len / c.v[p.type];
   p.path += len, p.t += time, p.recent += time;
   p.loc = p.loc + len * p.dir;
-  p.amp *= exp(c.att[p.type] * time);
+  p.amp *= exp_lean(c.att[p.type] * time);
   p.moves += 1;
 }
 
@@ -241,15 +241,18 @@ R3D_HD void tet_advance(const CellTet& c, const TetArc& A, Phonon& p, double len
   const int t = p.type;
   V3 nl = A.center + ((A.R * s1) * A.v1 + (A.R * c1) * A.v3);   // point of the circle at the end angle
   V3 nd = c1 * A.v1 + (-s1) * A.v3;                             // tangent (cos a, 0, -sin a)
-  // time = (ln|tan(a1/2+pi/4)| - ln|tan(a0/2+pi/4)|) / |g|,  ln|tan(a/2+pi/4)| = atanh(sin a)
-  double time = 0.5 * c.inv_gmag[t] * log(((1.0 + s1) * (1.0 - A.s0)) / ((1.0 - s1) * (1.0 + A.s0)));
+  // time = (ln|tan(a1/2+pi/4)| - ln|tan(a0/2+pi/4)|) / |g|,  ln|tan(a/2+pi/4)| = atanh(sin a), and
+  // atanh(s1) - atanh(s0) = atanh(y), y = (s1 - s0) / (1 - s0 s1): a leg spans a few degrees, so y
+  // is small and the series does (one division, no logarithm)
+  const double y = (s1 - A.s0) / (1.0 - A.s0 * s1);
+  double time = c.inv_gmag[t] * ((fabs(y) <= 0.2) ? atanh_small(y) : 0.5 * log((1.0 + y) / (1.0 - y)));
   p.path += len, p.t += time, p.recent += time;
   p.loc = nl;
   // (nd = c1 v1 - s1 v3 with v1, v3 orthonormal is unit to rounding; the reference's
   //  renormalisation + (theta, phi) round trip changes it by ~1e-16 and is skipped --
   //  the next leg rebuilds v1 from scratch, so nothing accumulates)
   p.dir = nd;
-  p.amp *= exp(c.att[t] * time);
+  p.amp *= exp_lean(c.att[t] * time);
   p.moves += 1;
 }
 
@@ -268,11 +271,19 @@ R3D_HD double sph_linear_exit(double radius, V3 loc, V3 dir) {
 // Ray arc in a v = a r^2 + c shell (reference RayArcAttributes +
 // cache_RD2_precompute, raypath.hpp:31-113; SphereShell::GetRayArc_RD2,
 // media.cpp:795-861).
+//
+// ANGLES ARE NOT FORMED where the reference forms them: a position on the arc is carried as the sine
+// and cosine of its angle from the arc bottom (the reference takes atan2 for the start, acos for
+// each face and sin / cos of the end angle, media_cellface.cpp:717-748, media.cpp:877-957).  Which
+// face the arc leaves through follows from the faces' cosines and the sign of the start angle alone
+// (see sph_exit); the only inverse function left is the one arc length that is needed, from the
+// sine and cosine of the angle DIFFERENCE; the end point of a boundary leg is the exit point itself;
+// and the two atanh of the travel time collapse into one.
 struct SphArc {
   double radius, rad2;
   V3 center, u1, u3;
   double S2, TwoSQ, CotZetaBy2, timeCoef;
-  double a0;       // angle of the current location from the arc bottom
+  double s0, c0;   // sine / cosine of the current location's angle from the arc bottom
   bool straight;   // a == 0: straight rays
 };
 R3D_HD V3 down_at(const double ec[3], V3 loc) {  // ECS.GetDown, ecs.cpp:147-167
@@ -284,7 +295,7 @@ R3D_HD SphArc sph_arc(const CellSph& c, const double ec[3], const Phonon& p) {
   A.straight = (c.a[t] == 0);
   if (A.straight) {
     A.radius = pos_inf(), A.rad2 = pos_inf(), A.S2 = 0, A.TwoSQ = 0, A.CotZetaBy2 = 0;
-    A.timeCoef = 0, A.a0 = 0, A.center = v3(0, 0, 0), A.u1 = p.dir, A.u3 = v3(0, 0, 0);
+    A.timeCoef = 0, A.s0 = 0, A.c0 = 1, A.center = v3(0, 0, 0), A.u1 = p.dir, A.u3 = v3(0, 0, 0);
     return A;
   }
   V3 w3 = down_at(ec, p.loc);
@@ -316,38 +327,74 @@ R3D_HD SphArc sph_arc(const CellSph& c, const double ec[3], const Phonon& p) {
   A.CotZetaBy2 = (1 + cz) / sz;
   A.timeCoef = -1 / (c.a[t] * S * sz);
   V3 cl = p.loc - A.center;
-  A.a0 = atan2(dot(A.u1, cl), dot(A.u3, cl));
+  const double y = dot(A.u1, cl), x = dot(A.u3, cl);   // the reference's a0 = atan2(y, x)
+  const double h2 = x * x + y * y;
+  const double ih = frsqrt(h2);
+  A.s0 = (h2 == 0) ? 0.0 : y * ih;   // atan2(0, 0) = 0
+  A.c0 = (h2 == 0) ? 1.0 : x * ih;
   return A;
 }
-R3D_HD double sph_arc_exit(double radius, const SphArc& A, const Phonon& p) {
-  // reference SphereFace::CircularArcDistToExit, media_cellface.cpp:717-748
-  if (A.S2 == 0) return sph_linear_exit(radius, p.loc, p.dir);
-  bool outward = radius > 0;
-  double cosq = (A.S2 + A.rad2 - radius * radius) / A.TwoSQ;
-  if (cosq > 1.0) return outward ? -pos_inf() : pos_inf();
-  double b2e = acos(cosq);
-  if (outward) return (b2e - A.a0) * A.radius;
-  if (A.a0 >= 0) return pos_inf();
-  return (-b2e - A.a0) * A.radius;
+// An angle in (-pi, pi] from its sine and cosine (unit to rounding): the small-angle arcsin where
+// it applies (a leg rarely spans more than a few degrees), else the general function.
+R3D_HD double angle_from_sincos(double s, double c) {
+  if (c > 0 && fabs(s) <= 0.5) return asin_small(s);
+  return atan2(s, c);
 }
-// reference SphereShell::GetPathToBoundary, media.cpp:668-757 (search part)
-R3D_HD Exit sph_exit(const CellSph& c, const SphArc& A, const Phonon& p) {
-  double dt, db;
-  if (A.straight) {
-    dt = sph_linear_exit(c.radius[0], p.loc, p.dir);
-    db = sph_linear_exit(c.radius[1], p.loc, p.dir);
-  } else {
-    dt = sph_arc_exit(c.radius[0], A, p);
-    db = sph_arc_exit(c.radius[1], A, p);
+// reference SphereShell::GetPathToBoundary, media.cpp:668-757 (search part), with
+// SphereFace::CircularArcDistToExit, media_cellface.cpp:717-748, for both faces.
+//
+// With b = acos(cosq) in [0, pi] the reference has, for the start angle a0 in (-pi, pi]:
+//   top    (outward): cosq > 1 ? -inf : (b_top - a0) R
+//   bottom (inward) : cosq > 1 ? +inf : a0 >= 0 ? +inf : (-b_bot - a0) R
+// and takes the top only if its distance is strictly smaller.  A finite bottom distance is never
+// larger than a finite top one (-b_bot <= 0 <= b_top), so: top at -inf wins; else the bottom wins
+// whenever it is reachable (its cosine <= 1 and the start angle negative, i.e. s0 < 0); else the top.
+// Negative lengths are squashed to 0.  (sx, cx): sine / cosine of the exit angle when `on_arc`.
+struct SphExit {
+  double len, sx, cx;
+  int face;
+  bool on_arc;   // the leg ends at the exit point of the arc (not squashed, not a straight ray)
+};
+R3D_HD SphExit sph_exit(const CellSph& c, const SphArc& A, const Phonon& p) {
+  SphExit e;
+  e.sx = 0, e.cx = 1, e.on_arc = false;
+  if (A.straight || A.S2 == 0) {
+    const double dt = sph_linear_exit(c.radius[0], p.loc, p.dir);
+    const double db = sph_linear_exit(c.radius[1], p.loc, p.dir);
+    e.face = (dt < db) ? 0 : 1;
+    e.len = e.face == 0 ? dt : db;
+    if (e.len < 0) e.len = 0;
+    return e;
   }
-  Exit e;
-  e.face = (dt < db) ? 0 : 1;
-  e.len = e.face == 0 ? dt : db;
+  const double base = A.S2 + A.rad2;
+  const double cq_t = (base - c.radius[0] * c.radius[0]) / A.TwoSQ;
+  const double cq_b = (base - c.radius[1] * c.radius[1]) / A.TwoSQ;
+  const bool bottom_reach = !(cq_b > 1.0) && (A.s0 < 0);
+  if (cq_t > 1.0) {          // top at -inf: taken, squashed to a zero-length leg
+    e.face = 0, e.len = 0;
+    return e;
+  }
+  if (!bottom_reach && !(cq_t >= -1.0)) {   // acos of the top's cosine is NaN: (NaN < +inf) is false
+    e.face = 1, e.len = pos_inf();
+    return e;
+  }
+  e.face = bottom_reach ? 1 : 0;
+  e.cx = bottom_reach ? cq_b : cq_t;
+  const double sq = fsqrt(1.0 - e.cx * e.cx);   // sin acos; NaN beyond [-1, 1], as acos is
+  e.sx = bottom_reach ? -sq : sq;
+  // arc angle = exit angle - start angle, from its sine and cosine; a top exit reached from a
+  // negative start angle lies in (0, 2 pi)
+  const double sd = e.sx * A.c0 - e.cx * A.s0, cd = e.cx * A.c0 + e.sx * A.s0;
+  double d = angle_from_sincos(sd, cd);
+  if (!bottom_reach && A.s0 < 0 && d < 0) d += kPi360;
+  e.len = d * A.radius;
+  e.on_arc = !(e.len < 0);
   if (e.len < 0) e.len = 0;
   return e;
 }
-// reference SphereShell::AdvanceLength_* (media.cpp:877-957) + Phonon::Move
-R3D_HD void sph_advance(const CellSph& c, const SphArc& A, Phonon& p, double len) {
+// reference SphereShell::AdvanceLength_* (media.cpp:877-957) + Phonon::Move.  (s1, c1): sine /
+// cosine of the end angle on the arc (ignored for straight rays).
+R3D_HD void sph_advance(const CellSph& c, const SphArc& A, Phonon& p, double len, double s1, double c1) {
   const int t = p.type;
   double time, att_time;
   if (A.straight || A.radius == pos_inf()) {
@@ -360,20 +407,18 @@ R3D_HD void sph_advance(const CellSph& c, const SphArc& A, Phonon& p, double len
     }
     p.loc = nl;
   } else {
-    double a1 = A.a0 + len / A.radius;
-    double s1, c1, s0, c0;
-    sincos(a1, &s1, &c1);
-    sincos(A.a0, &s0, &c0);
     p.loc = A.center + ((A.radius * s1) * A.u1 + (A.radius * c1) * A.u3);
     V3 nd = c1 * A.u1 + (-s1) * A.u3;
-    // tan(a/2) = sin a / (1 + cos a)
-    double t0 = A.timeCoef * atanh(A.CotZetaBy2 * (s0 / (1.0 + c0)));
-    double t1 = A.timeCoef * atanh(A.CotZetaBy2 * (s1 / (1.0 + c1)));
-    time = att_time = t1 - t0;
+    // time = timeCoef (atanh(x1) - atanh(x0)), x = CotZetaBy2 tan(a/2), tan(a/2) = sin a / (1 + cos a);
+    // atanh(x1) - atanh(x0) = atanh((x1 - x0) / (1 - x0 x1))
+    const double x0 = A.CotZetaBy2 * (A.s0 / (1.0 + A.c0));
+    const double x1 = A.CotZetaBy2 * (s1 / (1.0 + c1));
+    const double y = (x1 - x0) / (1.0 - x0 * x1);
+    time = att_time = A.timeCoef * ((fabs(y) <= 0.2) ? atanh_small(y) : 0.5 * log((1.0 + y) / (1.0 - y)));
     p.dir = through_angles(unit(nd));
   }
   p.path += len, p.t += time, p.recent += time;
-  p.amp *= exp(c.att[t] * att_time);
+  p.amp *= exp_lean(c.att[t] * att_time);
   p.moves += 1;
 }
 
@@ -567,21 +612,37 @@ R3D_HD uint64_t sample_cdf(const double* __restrict__ cdf, uint64_t n, double u)
   }
   return k2;
 }
-// The same draw with a search guide (r3d_pack.h build_guide): identical result,
-// ~5 probes into one or two cache lines instead of ceil(log2 n) dependent probes
-// scattered over the whole table.
+// The same draw with a search guide (r3d_pack.h build_guide): identical result.  The guide narrows
+// the search to a bracket [k1, k2] of a few entries (about four on average); the bracket's first
+// eight entries are then fetched AT ONCE and the answer is k1 + (how many of them lie below r) --
+// the table is non-decreasing, so that is the smallest k with r <= cdf[k], what the bisection
+// finds -- instead of two or three probes that each wait for the one before: the draw costs two
+// dependent memory round trips (guide, bracket) where the bisection cost three to four.  Only
+// a bracket longer than eight entries falls back to bisecting its remainder.
 R3D_HD uint64_t sample_cdf_guided(const double* __restrict__ cdf, const uint32_t* __restrict__ guide,
                                   uint32_t bits, double total, double u) {
   const double r = total * u;
   uint32_t j = (uint32_t)(u * (double)(1u << bits));
   if (j > (1u << bits) - 1u) j = (1u << bits) - 1u;
-  uint64_t k1 = guide[j], k2 = guide[j + 1];
-  while (k1 != k2) {
-    uint64_t k = (k1 + k2) >> 1;
-    if (r <= cdf[k]) k2 = k;
-    else k1 = k + 1;
+  uint64_t k1 = guide[j];
+  const uint64_t k2 = guide[j + 1];
+  constexpr int kAtOnce = 8;
+  double c[kAtOnce];
+#pragma unroll
+  for (int i = 0; i < kAtOnce; i++) c[i] = cdf[(k1 + i < k2) ? k1 + i : k2];
+  uint32_t below = 0;
+#pragma unroll
+  for (int i = 0; i < kAtOnce; i++) below += (k1 + i < k2 && !(r <= c[i])) ? 1u : 0u;
+  k1 += below;
+  if (below == kAtOnce) {   // all eight below r and the bracket goes on: bisect what is left
+    uint64_t hi = k2;
+    while (k1 != hi) {
+      const uint64_t k = (k1 + hi) >> 1;
+      if (r <= cdf[k]) hi = k;
+      else k1 = k + 1;
+    }
   }
-  return k2;
+  return k1;
 }
 R3D_HD int sample_small(const double* cdf, int n, double u) {
   const double r = cdf[n - 1] * u;

@@ -45,23 +45,25 @@ namespace r3d {
 constexpr int kPoolBlock = R3D_POOL_BLOCK;   // 8 waves = 2 per SIMD: 256 registers per lane, no spills
 constexpr int kPoolWaves = kPoolBlock / 64;
 
-enum { Q_MOVE = 0, Q_COLLECT = 1, Q_RT = 2, Q_BEND = 3, Q_SCATTER = 4, Q_FREE = 5, Q_NUM = 6 };
+enum { Q_MOVE = 0, Q_COLLECT = 1, Q_RT = 2, Q_SCATTER = 3, Q_FREE = 4, Q_NUM = 5 };
 constexpr uint16_t kRingEmpty = 0xFFFFu;
 
-// One history in flight.  meta: bit 0 ray type | bits 1-3 pending face + 1 (0: scattered inside
-// the cell) | bits 8-15 that face's flags | bits 16-18 the queue the slot is in (for carry-over).
-struct alignas(16) Slot {
-  double t, path, recent, amp;
-  double loc[3], dir[3];
-  double pc, ps;
-  uint32_t cell, moves, k, meta;
-  uint32_t id_lo, id_hi, catches, spare;
-};
-static_assert(sizeof(Slot) == 128, "a pool slot is 128 bytes");
+// One history in flight = one slot number; its state is spread over field-major arrays in LDS
+// (fd[field][slot] doubles, fu[field][slot] words), so that a batch of neighbouring slot numbers
+// reads and writes each field without bank conflicts (slot-major 128-byte records measured 77 % of
+// the LDS cycles as conflicts).  meta: bit 0 ray type | bits 1-3 pending face + 1 (0: none) |
+// bits 8-15 that face's flags | bits 16-18 the queue the slot is in (for carry-over).
+enum { FD_T, FD_PATH, FD_RECENT, FD_AMP, FD_LX, FD_LY, FD_LZ, FD_DX, FD_DY, FD_DZ, FD_PC, FD_PS, FD_NUM };
+enum { FU_CELL, FU_MOVES, FU_K, FU_META, FU_IDLO, FU_IDHI, FU_CATCH, FU_NBR, FU_NUM };   // NBR: the cell behind the pending face
+constexpr size_t kSlotBytes = FD_NUM * sizeof(double) + FU_NUM * sizeof(uint32_t);   // 128
 
+// Queue control: word[q] = head ticket << 16 | published entries (a consumer moves both with one
+// compare-and-swap), tail[q] = next ticket for producers; word[kDrainedWord] = the global id
+// counter ran out.
+constexpr int kDrainedWord = 6;
 struct PoolCtl {
-  uint32_t head[Q_NUM], tail[Q_NUM], count[Q_NUM];
-  uint32_t drained;   // the global id counter ran out
+  uint32_t word[8];
+  uint32_t tail[8];
 };
 
 __device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) {
@@ -71,23 +73,23 @@ __device__ __forceinline__ uint32_t meta_pack(int type, int face, uint32_t flags
   return (uint32_t)type | ((uint32_t)(face + 1) << 1) | ((flags & 0xFFu) << 8) | ((uint32_t)queue << 16);
 }
 
-// Take up to `want` (<= 64) slot numbers from queue q; returns how many (wave-uniform); lane l < k
-// gets its slot in `id`.
+// Take up to 64 slot numbers from queue q, whose control word was last seen as `seen`; returns how
+// many (wave-uniform); lane l < k gets its slot in `id`.
 __device__ __forceinline__ unsigned q_pop(PoolCtl& ctl, uint16_t* ring, uint32_t mask, int q, unsigned lane,
-                                          unsigned want, unsigned& id) {
+                                          uint32_t seen, unsigned& id) {
   unsigned k = 0, pos = 0;
   if (lane == 0) {
-    uint32_t c = lds_ld(&ctl.count[q]);
-    while (c) {
-      const uint32_t t = c < want ? c : want;
-      const uint32_t seen = atomicCAS(&ctl.count[q], c, c - t);
-      if (seen == c) {
-        k = t;
+    uint32_t w = seen;
+    while (w & 0xFFFFu) {
+      const uint32_t c = w & 0xFFFFu, t = c < 64u ? c : 64u;
+      const uint32_t next = ((w + (t << 16)) & 0xFFFF0000u) | (c - t);
+      const uint32_t was = atomicCAS(&ctl.word[q], w, next);
+      if (was == w) {
+        k = t, pos = w >> 16;
         break;
       }
-      c = seen;
+      w = was;
     }
-    if (k) pos = atomicAdd(&ctl.head[q], k);
   }
   k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
   pos = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
@@ -105,25 +107,31 @@ __device__ __forceinline__ unsigned q_pop(PoolCtl& ctl, uint16_t* ring, uint32_t
   return k;
 }
 
-// Hand the slots of the lanes with `cond` to queue q.
-__device__ __forceinline__ void q_push(PoolCtl& ctl, uint16_t* ring, uint32_t mask, int q, unsigned lane, bool cond,
-                                       unsigned id) {
-  const unsigned long long m = __ballot(cond);
-  if (!m) return;
+// Hand every active lane's slot to the queue named in its `dest` (all queues in one go: lane q
+// takes the tail tickets of queue q and publishes its count, so the whole distribution costs one
+// round of LDS atomics each way).
+__device__ __forceinline__ void q_push_all(PoolCtl& ctl, uint16_t* rings, uint32_t rcap, unsigned lane, bool act,
+                                           int dest, unsigned id) {
+  unsigned long long m[Q_NUM];
+  uint32_t kq = 0, rank = 0;
+#pragma unroll
+  for (int q = 0; q < Q_NUM; q++) {
+    m[q] = __ballot(act && dest == q);
+    kq = (lane == (unsigned)q) ? (uint32_t)__popcll(m[q]) : kq;
+    rank = (dest == q) ? rank_in(m[q]) : rank;
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the slots' state before their numbers
-  const unsigned k = (unsigned)__popcll(m);
-  const int first = __ffsll((long long)m) - 1;
-  unsigned pos = 0;
-  if ((int)lane == first) pos = atomicAdd(&ctl.tail[q], k);
-  pos = (unsigned)__shfl((int)pos, first);
-  if (cond) {
-    volatile uint16_t* e = ring + ((pos + rank_in(m)) & mask);
+  uint32_t pos = 0;
+  if (lane < Q_NUM && kq) pos = atomicAdd(&ctl.tail[lane], kq);
+  const uint32_t mine = (uint32_t)__shfl((int)pos, act ? dest : 0);
+  if (act) {
+    volatile uint16_t* e = rings + (size_t)dest * rcap + ((mine + rank) & (rcap - 1u));
     while (*e != kRingEmpty) {
     }
     *e = (uint16_t)id;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if ((int)lane == first) atomicAdd(&ctl.count[q], k);
+  if (lane < Q_NUM && kq) atomicAdd(&ctl.word[lane], kq);
 }
 
 // Seismometer collection for a batch of arrivals (one per lane with k1 > k0): the same tests and
@@ -220,9 +228,22 @@ __device__ __forceinline__ uint32_t pool_collect_pairs(const KArgs& a, const Tab
 }
 
 #ifdef R3D_PHASE_TIMING
-// diagnostic build: per queue, batches served, lanes filled, wave cycles spent; slot 6: idle polls
+// diagnostic build: per queue, batches served, lanes filled, wave cycles spent; slot 6: idle polls;
+// slot 7 of rows 0 / 1: move sub-iterations run / lanes live in them
 __device__ unsigned long long g_pool_stats[3][8];
 #endif
+
+// Moves a batch may make before its slots go back to the queues: lanes whose move ends with nothing
+// to do but change cells (or bend) stay in registers and move again while at least kMoveAgainLanes
+// of them do, so the pool round trip is paid once per several moves.
+#ifndef R3D_POOL_MOVES
+#define R3D_POOL_MOVES 4
+#endif
+#ifndef R3D_POOL_MOVE_AGAIN
+#define R3D_POOL_MOVE_AGAIN 44
+#endif
+constexpr int kPoolMoves = R3D_POOL_MOVES;
+constexpr unsigned kMoveAgainLanes = R3D_POOL_MOVE_AGAIN;
 
 // LDS_CELLS / LDS_SCAT: the cell records / the scatterer heads are staged in LDS (models with a few
 // dozen cells; all but models with thousands of scatterers).  The receiver tables are read through
@@ -273,47 +294,49 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   T.seis_hit = a.seis_hit;   // fetched on a hit only: stays in HBM / L2
 
   // ---- the pool, its queues, the block's tallies ----
-  Slot* const pool = reinterpret_cast<Slot*>(smem + a.lds_pool_off);
-  uint16_t* const rings = reinterpret_cast<uint16_t*>(smem + a.lds_ring_off);
-  const uint32_t S = a.pool_slots, rmask = a.pool_ring_mask, rcap = a.pool_ring_mask + 1u;
+  const uint32_t S = a.pool_slots, rcap = a.pool_ring_mask + 1u, rmask = a.pool_ring_mask;
+  double* const fd = reinterpret_cast<double*>(smem + a.lds_pool_off);          // [FD_NUM][S]
+  uint32_t* const fu = reinterpret_cast<uint32_t*>(fd + (size_t)FD_NUM * S);    // [FU_NUM][S]
+  uint16_t* const rings = reinterpret_cast<uint16_t*>(smem + a.lds_ring_off);   // [Q_NUM][rcap]
   __shared__ PoolCtl ctl;
   __shared__ unsigned long long s_tally[R3D_N_SCALARS];
   for (uint32_t i = tid; i < Q_NUM * rcap; i += kPoolBlock) rings[i] = kRingEmpty;
   if (tid < R3D_N_SCALARS) s_tally[tid] = 0ull;
-  if (tid == 0) {
-    for (int q = 0; q < Q_NUM; q++) ctl.head[q] = ctl.tail[q] = ctl.count[q] = 0u;
-    ctl.drained = 0u;
-  }
+  if (tid < 8) ctl.word[tid] = 0u, ctl.tail[tid] = 0u;
   __syncthreads();
   auto ring = [&](int q) { return rings + (size_t)q * rcap; };
+  const size_t image_words = (size_t)S * (kSlotBytes / 4);   // the pool's state as 32-bit words
   if (a.carry_in) {
     // resume: the pool image this workgroup parked at the end of the engine's previous launch;
     // every slot goes back to the queue named in its meta word
-    const Slot* img = reinterpret_cast<const Slot*>(a.carry_in) + (size_t)blockIdx.x * S;
+    const uint32_t* img = reinterpret_cast<const uint32_t*>(a.carry_in) + (size_t)blockIdx.x * image_words;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(fd);
+    for (size_t i = tid; i < image_words; i += kPoolBlock) dst[i] = img[i];
+    __syncthreads();
     for (uint32_t base = 0; base < S; base += kPoolBlock) {
       const uint32_t s = base + tid;
-      int tag = -1;
-      if (s < S) {
-        pool[s] = img[s];
-        tag = (int)((pool[s].meta >> 16) & 7u);
-      }
-#pragma unroll
-      for (int q = 0; q < Q_NUM; q++) q_push(ctl, ring(q), rmask, q, lane, tag == q, s);
+      const bool have = s < S;
+      const int tag = have ? (int)((fu[FU_META * S + s] >> 16) & 7u) : 0;
+      q_push_all(ctl, rings, rcap, lane, have, tag, s);
     }
   } else {
     for (uint32_t s = tid; s < S; s += kPoolBlock) {
       ring(Q_FREE)[s] = (uint16_t)s;
-      pool[s].meta = meta_pack(0, -1, 0u, Q_FREE);
+      fu[FU_META * S + s] = meta_pack(0, -1, 0u, Q_FREE);
     }
-    if (tid == 0) ctl.tail[Q_FREE] = S, ctl.count[Q_FREE] = S;
+    if (tid == 0) ctl.tail[Q_FREE] = S, ctl.word[Q_FREE] = S;
   }
   __syncthreads();
 
   constexpr int kEv = 3 + R3D_INV_NUM;
+  // Tallies: the per-lane event counters of r3d_step.h (LaneStats) and the fates run on in
+  // registers for the whole launch and are added up once at the end; wave-uniform counts are
+  // added to the block's LDS tallies by lane 0.
+  LaneStats st = {0, 0, 0, 0, 0, 0, 0};
+  uint32_t n_lost = 0, n_timeout = 0, n_invalid = 0;
   auto tally_n = [&](int slot, unsigned long long n) {
     if (lane == 0 && n) atomicAdd(&s_tally[slot], n);
   };
-  auto tally = [&](bool cond, int slot) { tally_n(slot, (unsigned long long)__popcll(__ballot(cond))); };
   // Report stream (diagnostic kernel only; include/r3d.h r3d_event): the lanes for which `cond`
   // holds append one record each; the wave claims the slots with one atomic.
   auto report = [&](bool cond, int tag, const Phonon& q, uint64_t hid) {
@@ -335,17 +358,17 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       r->tag = (uint8_t)tag, r->type = (uint8_t)q.type;
     }
   };
-  // A history ended (lanes with `died`): loss counters, the final record, the slot back to FREE.
-  auto finish = [&](bool died, int fate, int reason, const Phonon& p, uint64_t hid, uint32_t catches, unsigned id) {
-    if (!__any(died)) return;
-    tally(died && fate == FATE_LOST, 0);
-    tally(died && fate == FATE_TIMEOUT, 1);
+  // A history ended (lanes with `died`): loss counters, report line, final record.
+  auto finish = [&](bool died, int fate, int reason, const Phonon& p, uint64_t hid, uint32_t catches) {
+    n_lost += (died && fate == FATE_LOST) ? 1u : 0u;
+    n_timeout += (died && fate == FATE_TIMEOUT) ? 1u : 0u;
     if (__any(died && fate == FATE_INVALID)) {   // rare
-      tally(died && fate == FATE_INVALID, 2);
+      n_invalid += (died && fate == FATE_INVALID) ? 1u : 0u;
 #pragma unroll
-      for (int r = 0; r < R3D_INV_NUM; r++) tally(died && fate == FATE_INVALID && reason == r, 3 + r);
+      for (int r = 0; r < R3D_INV_NUM; r++)
+        tally_n(3 + r, (unsigned long long)__popcll(__ballot(died && fate == FATE_INVALID && reason == r)));
     }
-    if (TRACE) {
+    if (TRACE && __any(died)) {
       report(died && fate == FATE_LOST, 5, p, hid);
       report(died && fate == FATE_TIMEOUT, 6, p, hid);
       report(died && fate == FATE_INVALID, 7, p, hid);
@@ -360,27 +383,28 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         f->n_catch = (uint16_t)(catches > 65535u ? 65535u : catches);
       }
     }
-    if (died) pool[id].meta = meta_pack(0, -1, 0u, Q_FREE);
-    q_push(ctl, ring(Q_FREE), rmask, Q_FREE, lane, died, id);
   };
-  // Where a phonon that sits on face `face` with flags `fl` goes next (phonons.cpp:640-676):
-  // lost | full reflection / transmission solve | plain hand-over (taken at once) | Snell bend or
-  // run-time test.  Returns the destination queue, or -1 if the history ends here (lost).
-  auto face_dest = [&](uint32_t fl) -> int {
-    if (!(fl & (F_REFLECT | F_ADJOIN))) return -1;
-    if (fl & (F_REFLECT | F_DISCON)) return Q_RT;
-    if (fl & F_SMOOTH) return Q_MOVE;
-    return Q_BEND;
-  };
-  auto load_phonon = [&](unsigned id, Phonon& p, Rng& rng, uint32_t& meta) {
-    const Slot& s = pool[id];
-    p.t = s.t, p.path = s.path, p.recent = s.recent, p.amp = s.amp;
-    p.loc = v3(s.loc), p.dir = v3(s.dir);
-    p.pc = s.pc, p.ps = s.ps;
-    p.cell = (int32_t)s.cell, p.moves = s.moves;
-    meta = s.meta;
+  auto load_state = [&](unsigned id, Phonon& p, Rng& rng, uint32_t& meta) {
+    const double* d = fd + id;
+    const uint32_t* u = fu + id;
+    p.t = d[FD_T * S], p.path = d[FD_PATH * S], p.recent = d[FD_RECENT * S], p.amp = d[FD_AMP * S];
+    p.loc = v3(d[FD_LX * S], d[FD_LY * S], d[FD_LZ * S]);
+    p.dir = v3(d[FD_DX * S], d[FD_DY * S], d[FD_DZ * S]);
+    p.pc = d[FD_PC * S], p.ps = d[FD_PS * S];
+    p.cell = (int32_t)u[FU_CELL * S], p.moves = u[FU_MOVES * S];
+    meta = u[FU_META * S];
     p.type = (int32_t)(meta & 1u);
-    rng.k = s.k, rng.id_lo = s.id_lo, rng.id_hi = s.id_hi;
+    rng.k = u[FU_K * S], rng.id_lo = u[FU_IDLO * S], rng.id_hi = u[FU_IDHI * S];
+  };
+  // (the fields a move or a face event can change: everything but the history id)
+  auto store_state = [&](unsigned id, const Phonon& p, const Rng& rng, uint32_t meta) {
+    double* d = fd + id;
+    uint32_t* u = fu + id;
+    d[FD_T * S] = p.t, d[FD_PATH * S] = p.path, d[FD_RECENT * S] = p.recent, d[FD_AMP * S] = p.amp;
+    d[FD_LX * S] = p.loc.x, d[FD_LY * S] = p.loc.y, d[FD_LZ * S] = p.loc.z;
+    d[FD_DX * S] = p.dir.x, d[FD_DY * S] = p.dir.y, d[FD_DZ * S] = p.dir.z;
+    d[FD_PC * S] = p.pc, d[FD_PS * S] = p.ps;
+    u[FU_CELL * S] = (uint32_t)p.cell, u[FU_MOVES * S] = p.moves, u[FU_K * S] = rng.k, u[FU_META * S] = meta;
   };
 #ifdef R3D_PHASE_TIMING
   __shared__ unsigned long long s_stats[3][8];
@@ -391,12 +415,12 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   for (;;) {
     // ---- choose a queue: a full batch of a minor phase first (they all feed MOVE), then a
     //      refill, then MOVE; with no full batch anywhere, the fullest queue ----
-    const uint32_t cnt = lane < Q_NUM ? lds_ld(&ctl.count[lane]) : 0u;
-    const uint32_t drained = lds_ld(&ctl.drained);
+    const uint32_t snap = lane < 8 ? lds_ld(&ctl.word[lane]) : 0u;
+    const uint32_t drained = (uint32_t)__builtin_amdgcn_readlane((int)snap, kDrainedWord);
     if (drained && a.carry_out) break;   // no ids left: the pool is parked as it is for the next launch
-    uint32_t c[Q_NUM];
+    uint32_t w[Q_NUM], c[Q_NUM];
 #pragma unroll
-    for (int q = 0; q < Q_NUM; q++) c[q] = (uint32_t)__builtin_amdgcn_readlane((int)cnt, q);
+    for (int q = 0; q < Q_NUM; q++) w[q] = (uint32_t)__builtin_amdgcn_readlane((int)snap, q), c[q] = w[q] & 0xFFFFu;
     if (drained) {
       if (c[Q_FREE] == S) break;   // every slot is free and nothing is left to hand out
       c[Q_FREE] = 0u;              // (free slots are of no use any more)
@@ -405,7 +429,6 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
     if (c[Q_RT] >= 64u) q = Q_RT;
     else if (c[Q_COLLECT] >= 64u) q = Q_COLLECT;
     else if (c[Q_SCATTER] >= 64u) q = Q_SCATTER;
-    else if (c[Q_BEND] >= 64u) q = Q_BEND;
     else if (c[Q_FREE] >= 64u) q = Q_FREE;
     else if (c[Q_MOVE] >= 64u) q = Q_MOVE;
     else {
@@ -421,13 +444,17 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       __builtin_amdgcn_s_sleep(8);
       continue;
     }
+    uint32_t wq = 0;
+#pragma unroll
+    for (int j = 0; j < Q_NUM; j++) wq = (q == j) ? w[j] : wq;
     unsigned id;
-    const unsigned k = q_pop(ctl, ring(q), rmask, q, lane, 64u, id);
+    const unsigned k = q_pop(ctl, ring(q), rmask, q, lane, wq, id);
     if (k == 0) continue;   // another wave was quicker
     const bool act = lane < k;
 #ifdef R3D_PHASE_TIMING
     const unsigned long long t_begin = __builtin_readcyclecounter();
 #endif
+    int dest = Q_FREE;   // where each active lane's slot goes after this phase
 
     if (q == Q_FREE) {
       // ---- fresh histories: ids from the global counter, source spray (events.cpp:111-124) ----
@@ -435,7 +462,8 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       if (lane == 0) base = atomicAdd(a.next, (unsigned long long)k);
       base = __shfl(base, 0);
       const unsigned take = base >= a.n ? 0u : (a.n - base < k ? (unsigned)(a.n - base) : k);
-      if (take < k && lane == 0) __hip_atomic_store(&ctl.drained, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (take < k && lane == 0)
+        __hip_atomic_store(&ctl.word[kDrainedWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       const bool fresh = lane < take;
       Phonon p;
       uint64_t hid = 0;
@@ -444,62 +472,79 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         hid = a.first_id + base + lane;
         rng_init(rng, hid);
         spray(a, p, rng);
-        Slot& s = pool[id];
-        s.t = p.t, s.path = p.path, s.recent = p.recent, s.amp = p.amp;
-        s.loc[0] = p.loc.x, s.loc[1] = p.loc.y, s.loc[2] = p.loc.z;
-        s.dir[0] = p.dir.x, s.dir[1] = p.dir.y, s.dir[2] = p.dir.z;
-        s.pc = p.pc, s.ps = p.ps;
-        s.cell = (uint32_t)p.cell, s.moves = p.moves, s.k = rng.k;
-        s.meta = meta_pack(p.type, -1, 0u, Q_MOVE);
-        s.id_lo = rng.id_lo, s.id_hi = rng.id_hi, s.catches = 0u, s.spare = 0u;
+        store_state(id, p, rng, meta_pack(p.type, -1, 0u, Q_MOVE));
+        fu[FU_IDLO * S + id] = rng.id_lo, fu[FU_IDHI * S + id] = rng.id_hi, fu[FU_CATCH * S + id] = 0u;
+        dest = Q_MOVE;
       }
       report(fresh, 0, p, hid);   // GEN
       tally_n(kEv + R3D_EV_GENERATED, take);
-      q_push(ctl, ring(Q_MOVE), rmask, Q_MOVE, lane, fresh, id);
-      q_push(ctl, ring(Q_FREE), rmask, Q_FREE, lane, act && !fresh, id);
     } else if (q == Q_MOVE) {
-      // ---- termination checks, boundary search, free-path draw, advance (phonons.cpp:549-623) ----
+      // ---- termination checks, boundary search, free-path draw, advance (phonons.cpp:549-623),
+      //      and what the face reached asks for when that is little: a plain hand-over, a Snell
+      //      bend (phonons.cpp:640-661).  Lanes that can simply move again do so here. ----
       Phonon p;
       Rng rng;
       uint32_t meta = 0;
       int fate = FATE_ALIVE, reason = 0;
-      LaneStats st = {0, 0, 0, 0, 0, 0, 0};
-      Pending ev;
-      ev.vel = 0.0, ev.face = -1, ev.flags = 0u;
       uint64_t hid = 0;
+      bool live = act;   // still moving in registers
       if (act) {
-        load_phonon(id, p, rng, meta);
+        load_state(id, p, rng, meta);
         hid = ((uint64_t)rng.id_hi << 32) | rng.id_lo;
-        fate = step_move<KIND>(a, T, p, rng, st, &reason, ev);
       }
-      tally(st.iterations != 0, kEv + R3D_EV_ITERATIONS);
-      const bool moved = act && fate == FATE_ALIVE;
-      int dest = -1;   // where the slot goes; -1: the history ended
-      if (moved) {
-        if (ev.face < 0) dest = Q_SCATTER;
-        else if (ev.flags & F_COLLECT) dest = Q_COLLECT;
-        else dest = face_dest(ev.flags);
-        if (dest < 0) fate = FATE_LOST;   // phonons.cpp:675
+#pragma nounroll
+      for (int rep = 0;; rep++) {
+        Pending ev;
+        ev.vel = 0.0, ev.face = -1, ev.flags = 0u;
+        bool leaving = false;
+        if (live) {
+          fate = step_move<KIND>(a, T, p, rng, st, &reason, ev);
+          leaving = true;
+          if (fate != FATE_ALIVE) {
+            dest = Q_FREE;
+          } else if (ev.face < 0) {
+            dest = Q_SCATTER;
+          } else if (ev.flags & F_COLLECT) {
+            dest = Q_COLLECT;
+          } else if (!(ev.flags & (F_REFLECT | F_ADJOIN))) {
+            dest = Q_FREE, fate = FATE_LOST;   // phonons.cpp:675
+          } else if (ev.flags & (F_REFLECT | F_DISCON)) {
+            dest = Q_RT;
+          } else {
+            leaving = false;   // hand-over or bend: served right here, and on to the next move
+          }
+        }
+        const bool light = live && !leaving;
+        if (light) {
+          const uint32_t tr0 = st.transfer, rf0 = st.reflect;
+          step_event<KIND, EV_BEND>(a, T, p, rng, st, ev);
+          if (TRACE) {
+            report(st.reflect != rf0, 2, p, hid);    // REF
+            report(st.transfer != tr0, 4, p, hid);   // CEL
+          }
+        } else if (TRACE) {
+          report(false, 2, p, hid), report(false, 4, p, hid);
+        }
+        live = light;
+        const unsigned n_live = (unsigned)__popcll(__ballot(live));
+        const bool last = (rep + 1 >= kPoolMoves) || (n_live < kMoveAgainLanes);
+#ifdef R3D_PHASE_TIMING
+        if (lane == 0) atomicAdd(&s_stats[0][7], 1ull), atomicAdd(&s_stats[1][7], (unsigned long long)(n_live));
+#endif
+        if (last && live) dest = Q_MOVE;
+        if (leaving || (last && live)) {
+          const bool keep = dest != Q_FREE;   // (a history that ended leaves nothing to keep)
+          if (keep) {
+            store_state(id, p, rng, meta_pack(p.type, dest == Q_MOVE ? -1 : ev.face, dest == Q_MOVE ? 0u : ev.flags, dest));
+            if (dest == Q_RT || dest == Q_COLLECT)   // (the cell's record is at hand here: the later phase need not wait for it)
+              fu[FU_NBR * S + id] = (uint32_t)cell_neighbor(T.cells[p.cell], ev.face);
+          } else
+            fu[FU_META * S + id] = meta_pack(0, -1, 0u, Q_FREE);
+        }
+        if (last) break;
       }
-      const bool handover = moved && dest == Q_MOVE;   // nothing to do on this face but change cells
-      if (handover) p.cell = cell_neighbor(T.cells[p.cell], ev.face);
-      tally(handover, kEv + R3D_EV_TRANSFER);
-      report(handover, 4, p, hid);   // CEL
-      const bool died = act && dest < 0;
-      if (act && !died) {
-        Slot& s = pool[id];
-        s.t = p.t, s.path = p.path, s.recent = p.recent, s.amp = p.amp;
-        s.loc[0] = p.loc.x, s.loc[1] = p.loc.y, s.loc[2] = p.loc.z;
-        s.dir[0] = p.dir.x, s.dir[1] = p.dir.y, s.dir[2] = p.dir.z;
-        s.cell = (uint32_t)p.cell, s.moves = p.moves, s.k = rng.k;
-        s.meta = meta_pack(p.type, handover ? -1 : ev.face, handover ? 0u : ev.flags, dest);
-      }
-      q_push(ctl, ring(Q_SCATTER), rmask, Q_SCATTER, lane, dest == Q_SCATTER, id);
-      q_push(ctl, ring(Q_COLLECT), rmask, Q_COLLECT, lane, dest == Q_COLLECT, id);
-      q_push(ctl, ring(Q_RT), rmask, Q_RT, lane, dest == Q_RT, id);
-      q_push(ctl, ring(Q_BEND), rmask, Q_BEND, lane, dest == Q_BEND, id);
-      q_push(ctl, ring(Q_MOVE), rmask, Q_MOVE, lane, dest == Q_MOVE, id);
-      finish(died, fate, reason, p, hid, TRACE && died ? pool[id].catches : 0u, id);
+      const bool died = act && dest == Q_FREE;
+      finish(died, fate, reason, p, hid, (TRACE && died) ? fu[FU_CATCH * S + id] : 0u);
     } else if (q == Q_COLLECT) {
       // ---- arrival at a collection face: the receivers, with the incident state
       //      (phonons.cpp:629-631), then on to what the face itself asks for ----
@@ -509,11 +554,12 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       uint64_t hid = 0;
       uint32_t k0 = 0, k1 = 0, catches = 0;
       double vel = 1.0;
-      int face = 0;
+      Pending ev;
+      ev.vel = 0.0, ev.face = 0, ev.flags = 0u;
       if (act) {
-        load_phonon(id, p, rng, meta);
+        load_state(id, p, rng, meta);
         hid = ((uint64_t)rng.id_hi << 32) | rng.id_lo;
-        face = (int)((meta >> 1) & 7u) - 1;
+        ev.face = (int)((meta >> 1) & 7u) - 1, ev.flags = (meta >> 8) & 0xFFu;
         vel = cell_velocity(T.cells[p.cell], p.loc, p.type);
         const SeisGrid& g = a.grid;
         const double fx = (p.loc.x - g.origin[0]) * g.inv_h;
@@ -535,58 +581,66 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
                                                               lane, catches, bc);
         tally_n(kEv + R3D_EV_CATCH, hits);
       }
-      const uint32_t fl = (meta >> 8) & 0xFFu;
-      const int dest = act ? face_dest(fl) : Q_NUM;
-      const bool handover = act && dest == Q_MOVE;
-      if (handover) p.cell = cell_neighbor(T.cells[p.cell], face);
-      tally(handover, kEv + R3D_EV_TRANSFER);
-      report(handover, 4, p, hid);   // CEL
-      const bool died = act && dest < 0;
-      if (act && !died) {
-        Slot& s = pool[id];
-        if (handover) s.cell = (uint32_t)p.cell;
-        s.meta = meta_pack(p.type, handover ? -1 : face, handover ? 0u : fl, dest);
-        if (TRACE) s.catches += catches;
+      bool died = false;
+      if (act) {
+        if (!(ev.flags & (F_REFLECT | F_ADJOIN))) {
+          died = true;   // lost through this face (phonons.cpp:675)
+        } else if (ev.flags & (F_REFLECT | F_DISCON)) {
+          dest = Q_RT;
+        } else {
+          dest = Q_MOVE;
+        }
       }
-      q_push(ctl, ring(Q_RT), rmask, Q_RT, lane, dest == Q_RT, id);
-      q_push(ctl, ring(Q_BEND), rmask, Q_BEND, lane, dest == Q_BEND, id);
-      q_push(ctl, ring(Q_MOVE), rmask, Q_MOVE, lane, dest == Q_MOVE, id);
-      finish(died, FATE_LOST, 0, p, hid, TRACE && died ? pool[id].catches + catches : 0u, id);
+      const bool light = act && dest == Q_MOVE;
+      if (light) {
+        const uint32_t tr0 = st.transfer, rf0 = st.reflect;
+        step_event<KIND, EV_BEND>(a, T, p, rng, st, ev, (int)fu[FU_NBR * S + id]);
+        if (TRACE) {
+          report(st.reflect != rf0, 2, p, hid);    // REF
+          report(st.transfer != tr0, 4, p, hid);   // CEL
+        }
+        double* d = fd + id;
+        d[FD_DX * S] = p.dir.x, d[FD_DY * S] = p.dir.y, d[FD_DZ * S] = p.dir.z;
+        d[FD_PC * S] = p.pc, d[FD_PS * S] = p.ps;
+        fu[FU_CELL * S + id] = (uint32_t)p.cell;
+      } else if (TRACE) {
+        report(false, 2, p, hid), report(false, 4, p, hid);
+      }
+      if (act) {
+        fu[FU_META * S + id] = died ? meta_pack(0, -1, 0u, Q_FREE)
+                                    : meta_pack(p.type, light ? -1 : ev.face, light ? 0u : ev.flags, dest);
+        if (TRACE) fu[FU_CATCH * S + id] += catches;
+      }
+      finish(died, FATE_LOST, 0, p, hid, (TRACE && died) ? fu[FU_CATCH * S + id] : 0u);
     } else {
-      // ---- RT: reflection / transmission solve; BEND: Snell bend or hand-over after the
-      //      run-time velocity-step test; SCATTER: deflection drawn from the scatterer's tables
-      //      (phonons.cpp:611-618, :640-661) ----
+      // ---- RT: reflection / transmission solve; SCATTER: deflection drawn from the scatterer's
+      //      tables (phonons.cpp:611-618, :640-661) ----
       Phonon p;
       Rng rng;
       uint32_t meta = 0;
       uint64_t hid = 0;
-      LaneStats st = {0, 0, 0, 0, 0, 0, 0};
+      const uint32_t tr0 = st.transfer, rf0 = st.reflect;
       if (act) {
-        load_phonon(id, p, rng, meta);
+        load_state(id, p, rng, meta);
         hid = ((uint64_t)rng.id_hi << 32) | rng.id_lo;
         Pending ev;
         ev.vel = 0.0, ev.face = (int)((meta >> 1) & 7u) - 1, ev.flags = (meta >> 8) & 0xFFu;
-        if (q == Q_RT) step_event<KIND, EV_RT>(a, T, p, rng, st, ev);
-        else if (q == Q_BEND) step_event<KIND, EV_BEND>(a, T, p, rng, st, ev);
+        if (q == Q_RT) step_event<KIND, EV_RT>(a, T, p, rng, st, ev, (int)fu[FU_NBR * S + id]);
         else step_event<KIND, EV_SCATTER>(a, T, p, rng, st, ev);
-        Slot& s = pool[id];
-        s.dir[0] = p.dir.x, s.dir[1] = p.dir.y, s.dir[2] = p.dir.z;
-        s.pc = p.pc, s.ps = p.ps;
-        s.cell = (uint32_t)p.cell, s.k = rng.k;
-        s.meta = meta_pack(p.type, -1, 0u, Q_MOVE);
+        double* d = fd + id;
+        d[FD_DX * S] = p.dir.x, d[FD_DY * S] = p.dir.y, d[FD_DZ * S] = p.dir.z;
+        d[FD_PC * S] = p.pc, d[FD_PS * S] = p.ps;
+        fu[FU_CELL * S + id] = (uint32_t)p.cell, fu[FU_K * S + id] = rng.k;
+        fu[FU_META * S + id] = meta_pack(p.type, -1, 0u, Q_MOVE);
+        dest = Q_MOVE;
       }
-      if (q == Q_SCATTER) {
-        tally_n(kEv + R3D_EV_SCATTER, k);
-        report(act, 1, p, hid);   // SCT
-      } else {
-        if (q == Q_RT) tally_n(kEv + R3D_EV_RTSOLVE, k);
-        tally(st.reflect != 0, kEv + R3D_EV_REFLECT);
-        tally(st.transfer != 0, kEv + R3D_EV_TRANSFER);
-        report(st.reflect != 0, 2, p, hid);    // REF
-        report(st.transfer != 0, 4, p, hid);   // CEL
+      if (TRACE) {
+        report(act && q == Q_SCATTER, 1, p, hid);   // SCT
+        report(st.reflect != rf0, 2, p, hid);       // REF
+        report(st.transfer != tr0, 4, p, hid);      // CEL
       }
-      q_push(ctl, ring(Q_MOVE), rmask, Q_MOVE, lane, act, id);
     }
+    q_push_all(ctl, rings, rcap, lane, act, dest, id);
 #ifdef R3D_PHASE_TIMING
     if (lane == 0) {
       atomicAdd(&s_stats[0][q], 1ull);
@@ -598,10 +652,21 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 
   __syncthreads();
   if (a.carry_out) {   // park the pool for the engine's next launch
-    Slot* img = reinterpret_cast<Slot*>(a.carry_out) + (size_t)blockIdx.x * S;
-    for (uint32_t s = tid; s < S; s += kPoolBlock) img[s] = pool[s];
+    uint32_t* img = reinterpret_cast<uint32_t*>(a.carry_out) + (size_t)blockIdx.x * image_words;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(fd);
+    for (size_t i = tid; i < image_words; i += kPoolBlock) img[i] = src[i];
   }
-  // ---- the block's bin accumulators and tallies to HBM ----
+  // ---- the lanes' running tallies, then the block's bin accumulators and tallies to HBM ----
+  {
+    auto add = [&](int slot, uint32_t v) {
+      if (v) atomicAdd(&s_tally[slot], (unsigned long long)v);
+    };
+    add(0, n_lost), add(1, n_timeout), add(2, n_invalid);
+    add(kEv + R3D_EV_ITERATIONS, st.iterations), add(kEv + R3D_EV_SCATTER, st.scatter);
+    add(kEv + R3D_EV_REFLECT, st.reflect), add(kEv + R3D_EV_TRANSFER, st.transfer);
+    add(kEv + R3D_EV_RTSOLVE, st.rtsolve);
+  }
+  __syncthreads();
   if (bc.on) {
     for (uint32_t i = tid; i <= bc.mask; i += kPoolBlock) {
       const uint32_t bin = bc.key[i];

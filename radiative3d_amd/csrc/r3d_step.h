@@ -199,6 +199,7 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
   TetArc tarc;
   TetExit texit;
   SphArc sarc;
+  SphExit sexit;
   if constexpr (KIND == CELL_CYL) {
     e = cyl_exit(c, a.cyl_radius2, p);
   } else if constexpr (KIND == CELL_TET) {
@@ -208,7 +209,8 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
     e.len = tet_exit_length(tarc, texit);
   } else {
     sarc = sph_arc(c, a.earth_center, p);
-    e = sph_exit(c, sarc, p);
+    sexit = sph_exit(c, sarc, p);
+    e.face = sexit.face, e.len = sexit.len;
   }
   if (e.len == pos_inf()) return FATE_TIMEOUT;  // phonons.cpp:595-598
 
@@ -230,12 +232,18 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
     double s1 = texit.s, c1 = texit.c;   // a boundary leg ends at the exit point itself
     if (scatters || !(e.len > -pos_inf())) {
       double sd, cd;                      // scatter leg: rotate the start angle by len / R
-      sincos(len / tarc.R, &sd, &cd);
+      rotation(len / tarc.R, &sd, &cd);
       s1 = tarc.s0 * cd + tarc.c0 * sd, c1 = tarc.c0 * cd - tarc.s0 * sd;
     }
     tet_advance(c, tarc, p, len, s1, c1);
   } else {
-    sph_advance(c, sarc, p, len);
+    double s1 = sexit.sx, c1 = sexit.cx;  // a boundary leg ends at the exit point itself
+    if (scatters || !sexit.on_arc) {
+      double sd, cd;                      // scatter leg (or a squashed one): rotate by len / R
+      rotation(len / sarc.radius, &sd, &cd);
+      s1 = sarc.s0 * cd + sarc.c0 * sd, c1 = sarc.c0 * cd - sarc.s0 * sd;
+    }
+    sph_advance(c, sarc, p, len, s1, c1);
   }
 
   ev.face = scatters ? -1 : e.face;
@@ -257,7 +265,7 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
 enum { EV_ALL = 0, EV_LIGHT = 1, EV_RT = 2, EV_SCATTER = 3, EV_BEND = 4 };
 template <int KIND, int PART = EV_ALL>
 R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng, LaneStats& st,
-                      const Pending& ev) {
+                      const Pending& ev, int nbr_known = -2) {
   using Cell = typename CellOf<KIND>::type;
   const Cell& c = T.cells[p.cell];
   if (PART == EV_SCATTER || (PART != EV_RT && PART != EV_BEND && ev.face < 0)) {
@@ -285,7 +293,9 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
   if (PART == EV_SCATTER) return FATE_ALIVE;   // (not reached)
   const uint32_t fl = ev.flags;
   if (!(fl & (F_REFLECT | F_ADJOIN))) return FATE_LOST;  // phonons.cpp:675
-  const int nbr = cell_neighbor(c, ev.face);
+  // (a caller that already knows the neighbour passes it, so that both cells' records can be
+  //  fetched at once instead of the neighbour's waiting for this cell's)
+  const int nbr = (nbr_known != -2) ? nbr_known : cell_neighbor(c, ev.face);
   const bool adjoin = (fl & F_ADJOIN) != 0;
   bool crossed;
   if (PART != EV_LIGHT && PART != EV_BEND && (PART == EV_RT || (fl & F_REFLECT) || (fl & F_DISCON))) {
