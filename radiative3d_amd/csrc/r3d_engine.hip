@@ -1,28 +1,19 @@
-// r3d_engine.hip -- the MI355X (gfx950) phonon-transport engine: persistent
-// traversal kernel + the C-ABI of include/r3d.h.
+// r3d_engine.hip -- the MI355X (gfx950) phonon-transport engine: the C-ABI of include/r3d.h
+// around the traversal kernel of r3d_pool.h.
 //
-// Kernel design (one phonon per work-item, 64-wide wavefronts):
-//   * persistent grid, one 768-thread workgroup per CU; each WAVE pulls chunks of
-//     history ids from one global counter (one atomic per 256 histories) and
-//     deals them to its lanes with a ballot + prefix-popcount, so a lane whose
-//     history ended is refilled within a few iterations and the wave stays full
-//     until the id range is exhausted; what is still in flight then can be carried
-//     into the engine's next launch instead of draining the GPU (CarrySlot);
-//   * every iteration all running lanes do the same thing: boundary search ->
-//     free-path draw -> advance (up to three times when a move ends in a plain
-//     hand-over); then the receivers, the light events, and -- for the lanes that
-//     parked for it -- the reflection / transmission solve;
-//   * small read-only tables (cells of layered and spherical models, scatterer
-//     heads, receiver scan / hit records, the receiver hash) are staged in LDS once
-//     per workgroup; tetra cells (0.6 MB for the crust-pinch model), CDFs
-//     (GBs at TOA degree 9) and bins stay in HBM / L2;
-//   * bins are accumulated through per-workgroup LDS accumulators and per-wave
-//     catch queues into native fp64 / u64 global atomics;
-//   * RNG is counter-based Philox keyed by history id (r3d_rng.h): results are
-//     independent of lane, wave, launch geometry, launch boundaries and GPU count.
+// Kernel design in one paragraph (details: r3d_pool.h): persistent grid, one
+// 512-thread workgroup per CU; the histories in flight live in LDS (a pool of ~1000 slots per
+// workgroup) and sit in one of five queues -- MOVE, COLLECT, RT, SCATTER, FREE; a wave takes 64
+// slots of ONE queue and runs that phase for all of them at once, so every phase executes at
+// (nearly) full width instead of under the partial masks of a one-phonon-per-lane loop; small
+// read-only tables (cells of layered and spherical models, scatterer heads) are staged in LDS,
+// tetra cells, receiver tables, CDFs (GBs at TOA degree 9) and bins stay in HBM / L2; bins are
+// accumulated through per-workgroup LDS accumulators into native fp64 / u64 global atomics; RNG
+// is counter-based Philox keyed by history id (r3d_rng.h): results are independent of lane, wave,
+// launch geometry, launch boundaries and GPU count.
 //
-// The product has no CPU path: without a HIP device every entry point fails
-// with an error message.
+// The product has no CPU path: without a HIP device every entry point fails with an error
+// message.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -42,52 +33,6 @@
 
 namespace r3d {
 
-#ifndef R3D_BLOCK
-#define R3D_BLOCK 768
-#endif
-// One workgroup per CU shares one copy of the LDS tables.  12 waves = 3 per SIMD, i.e. a
-// budget of 168 registers per lane (__launch_bounds__).  Measured on the four models
-// (TOA degree 9): 512 threads (2 per SIMD, 183 registers, no spills) 31.6 / 35.5 / 78.4 /
-// 10.9 ms, 768 threads (a few spills in the R/T solve) 30.2 / 33.6 / 67.5 / 8.8 ms,
-// 1024 threads (128 registers, heavy spills) slower than either.
-constexpr int kBlock = R3D_BLOCK;
-constexpr int kWaves = kBlock / 64;
-constexpr unsigned kQueueCap = 128;  // per-wave catch queue entries (flushed 64 at a time)
-constexpr unsigned kChunk = 256;     // history ids a wave claims per global atomic
-#ifndef R3D_REFILL_MIN
-#define R3D_REFILL_MIN 8
-#endif
-constexpr unsigned kRefillMin = R3D_REFILL_MIN;   // idle lanes that trigger a refill
-#ifndef R3D_RT_BATCH
-#define R3D_RT_BATCH 24
-#endif
-constexpr unsigned kRtBatch = R3D_RT_BATCH;      // parked R/T lanes that trigger the solve (<= 1: no parking)
-#ifndef R3D_MOVES_PER_ITER
-#define R3D_MOVES_PER_ITER 3
-#endif
-// Moves a lane may make per loop iteration (see the loop).  Measured at TOA degree 9 on chained
-// launches, 1 / 2 / 3 / 4 moves: NSCP 19.5 / 16.8 / 16.4 / 16.5 ms per 1e7; LopNor flat; on
-// self-contained launches SphereEarth 60.8 -> 66 ms with 2 (few plain hand-overs there, and the
-// loop costs registers): the spherical kernel keeps one move per iteration.
-constexpr int kMovesPerIterLayeredTetra = R3D_MOVES_PER_ITER;
-#ifndef R3D_MOVE_AGAIN_MIN
-#define R3D_MOVE_AGAIN_MIN 16
-#endif
-constexpr unsigned kMoveAgainMin = R3D_MOVE_AGAIN_MIN;   // lanes that make an extra move worth its while
-
-// ---- optional in-kernel phase timing (diagnostic build only: -DR3D_PHASE_TIMING) ----
-#ifdef R3D_PHASE_TIMING
-__device__ unsigned long long g_phase_cycles[8];
-#define R3D_STAMP(slot)                                                        \
-  do {                                                                         \
-    unsigned long long now__ = __builtin_readcyclecounter();                   \
-    if (lane == 0) atomicAdd(&s_phase[slot], now__ - t_phase);                 \
-    t_phase = now__;                                                           \
-  } while (0)
-#else
-#define R3D_STAMP(slot) do { } while (0)
-#endif
-
 // ---------------------------------------------------- wave-level helpers ----
 // number of set bits of m below this lane
 __device__ __forceinline__ unsigned rank_in(unsigned long long m) {
@@ -99,34 +44,6 @@ __device__ __forceinline__ double bcast(double v, int src) {
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ V3 bcast(V3 v, int src) { return v3(bcast(v.x, src), bcast(v.y, src), bcast(v.z, src)); }
-
-// Per-wave queue of seismometer catches, in LDS.  Bin updates are global atomics,
-// and on CDNA a wave's vector-memory operations retire in issue order: a load
-// issued after an atomic waits for it (~1-3 us under load).  Issuing the five
-// atomics of every catch where it happens would stall the next cell fetch a couple
-// of times per iteration.  Instead catches are parked here and flushed 64 at a
-// time, one catch per lane: one such stall per 64 catches, and full-width atomics.
-struct CatchQueue {
-  uint32_t slot[kQueueCap];      // (seismometer * n_bins + bin) * 2 + type
-  double e[4][kQueueCap];        // energy on X, Y, Z and total
-};
-
-__device__ __forceinline__ void flush_catches(const KArgs& a, CatchQueue& q, unsigned n, unsigned lane) {
-#ifdef R3D_ABLATE_CATCH   // timing-only developer build: drop the bin updates
-  return;
-#endif
-  if (lane < n) {
-    const uint32_t sl = q.slot[lane];
-    const size_t bin = sl >> 1;
-    const uint32_t type = sl & 1u;
-    double* e = a.energy + bin * 5;
-    unsafeAtomicAdd(e + 0, q.e[0][lane]);
-    unsafeAtomicAdd(e + 1, q.e[1][lane]);
-    unsafeAtomicAdd(e + 2, q.e[2][lane]);
-    unsafeAtomicAdd(e + 3 + type, q.e[3][lane]);
-    atomicAdd(a.counts + bin * 2 + type, 1ull);
-  }
-}
 
 // Per-workgroup accumulators for seismometer bins, in LDS.  First arrivals pile
 // onto a handful of (seismometer, time-bin) records -- in the LopNor runs one bin
@@ -165,502 +82,11 @@ __device__ __forceinline__ bool bin_cache_add(const BinCache& bc, uint32_t bin, 
   return false;
 }
 
-// Seismometer collection for all of the wave's arrivals at once: same tests and same bin
-// updates as collect() in r3d_step.h (reference dataout.cpp:103-216, :545-568).  Lane l
-// arrives with the candidate receivers [k0, k1) of its hash cell (k0 == k1: none).  The
-// (arrival, candidate) pairs of the whole wave are numbered through a prefix sum of the
-// candidate counts and dealt to the 64 lanes, 64 pairs per pass: a pair's lane finds its
-// arrival by bisection over the prefix sums and fetches the arrival's state from that lane
-// (ds_bpermute).  A typical iteration has 3-4 arrivals with a few candidates each, i.e.
-// one pass, where serving the arrivals one after the other took one pass each.
-// q_count is the wave-uniform fill of the wave's catch queue.
-template <int KIND, bool TRACE>
-__device__ __forceinline__ void collect_pairs(const KArgs& a, const Tables<KIND>& T, const Phonon& p,
-                                              double vel_lane, uint32_t k0, uint32_t k1,
-                                              const uint16_t* lds_items /* or null: a.grid.items */,
-                                              unsigned lane, uint32_t& lane_catches,
-                                              const BinCache& bc, CatchQueue& q, unsigned& q_count) {
-  const uint32_t cnt = k1 - k0;
-  uint32_t incl = cnt;   // inclusive prefix sum over the wave
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t y = __shfl_up(incl, off);
-    if (lane >= (unsigned)off) incl += y;
-  }
-  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-  const uint32_t excl = incl - cnt;
-  // this lane's arrival record (meaningful where cnt > 0): Phonon::DirectionOfMotion,
-  // squared amplitude, and direction / velocity for the plane-wave arrival correction
-  V3 dopm = p.dir;
-  if (cnt && p.type != RAY_P) {
-    V3 th, ph;
-    sph_basis(p.dir, th, ph);
-    dopm = p.pc * th + p.ps * ph;
-  }
-  const double amp2 = p.amp * p.amp;
-  const double inv_vel = 1.0 / vel_lane;
-  for (uint32_t base = 0; base < total; base += 64u) {
-    const uint32_t j = base + lane;
-    uint32_t src = 0;   // smallest lane whose inclusive sum exceeds j
-#pragma unroll
-    for (uint32_t step = 32u; step; step >>= 1) {
-      const uint32_t v = (uint32_t)__shfl((int)incl, (int)(src + step - 1u));
-      if (v <= j) src += step;
-    }
-    const bool valid = j < total;
-    src = valid ? src : lane;
-    const uint32_t k = (uint32_t)__shfl((int)k0, (int)src) + (j - (uint32_t)__shfl((int)excl, (int)src));
-    const V3 loc = v3(__shfl(p.loc.x, (int)src), __shfl(p.loc.y, (int)src), __shfl(p.loc.z, (int)src));
-    const V3 dir = v3(__shfl(p.dir.x, (int)src), __shfl(p.dir.y, (int)src), __shfl(p.dir.z, (int)src));
-    const V3 dm = v3(__shfl(dopm.x, (int)src), __shfl(dopm.y, (int)src), __shfl(dopm.z, (int)src));
-    const double t = __shfl(p.t, (int)src), a2 = __shfl(amp2, (int)src), iv = __shfl(inv_vel, (int)src);
-    const int type = __shfl(p.type, (int)src);
-    bool hit = false;
-    uint32_t hit_slot = 0;
-    double ex = 0, ey = 0, ez = 0, et = 0;
-    if (valid) {
-      const uint32_t s = lds_items ? (uint32_t)lds_items[k] : a.grid.items[k];
-      const SeisScan& S = T.seis_scan[s];
-      const V3 to = v3(S.loc) - loc;
-      const double dist = mag(to);
-      if (!(dist > S.r_out[type] || dist < S.r_in[type])) {
-        double arv = t;
-        if (S.r_in[type] <= 0) arv += dot(to, dir) * iv;
-        const double scaled = arv / a.time_per_bin;
-        const double fl = floor(scaled);
-        if (scaled >= 0.0 && fl < a.n_bins_f) {
-          const uint32_t bin = (uint32_t)fl;
-          const SeisHit& H = T.seis_hit[s];
-          const double xf = dot(dm, v3(H.axes[0])), yf = dot(dm, v3(H.axes[1])), zf = dot(dm, v3(H.axes[2]));
-          et = a2 * H.inv_norm[type];
-          ex = et * (xf * xf), ey = et * (yf * yf), ez = et * (zf * zf);
-          hit_slot = ((s * a.n_bins + bin) << 1) | (uint32_t)type;
-          hit = true;
-        }
-      }
-    }
-    unsigned long long hm = __ballot(hit);
-    if (!hm) continue;
-    if (TRACE) {   // per-history catch counts for the final records
-      for (unsigned long long r = hm; r; r &= r - 1ull) {
-        const int b = __ffsll((long long)r) - 1;
-        if ((int)lane == __builtin_amdgcn_readlane((int)src, b)) lane_catches++;
-      }
-    } else if (lane == 0) {
-      lane_catches += (uint32_t)__popcll(hm);   // (only the wave's total is tallied)
-    }
-    if (bc.on && hit && bin_cache_add(bc, hit_slot >> 1, (uint32_t)type, ex, ey, ez, et)) hit = false;
-    const unsigned long long m = __ballot(hit);   // catches the accumulators did not take
-    if (m) {
-      if (hit) {
-        const unsigned at = q_count + rank_in(m);
-        q.slot[at] = hit_slot;
-        q.e[0][at] = ex, q.e[1][at] = ey, q.e[2][at] = ez, q.e[3][at] = et;
-      }
-      q_count += (unsigned)__popcll(m);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (q_count >= 64u) {   // flush the oldest 64, slide the rest down
-        flush_catches(a, q, 64u, lane);
-        const unsigned rest = q_count - 64u;
-        uint32_t ms = 0;
-        double m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-        if (lane < rest) {
-          ms = q.slot[64u + lane];
-          m0 = q.e[0][64u + lane], m1 = q.e[1][64u + lane], m2 = q.e[2][64u + lane], m3 = q.e[3][64u + lane];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane < rest) {
-          q.slot[lane] = ms;
-          q.e[0][lane] = m0, q.e[1][lane] = m1, q.e[2][lane] = m2, q.e[3][lane] = m3;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        q_count = rest;
-      }
-    }
-  }
-}
-
-// --------------------------------------------------------------- the kernel --
-// A batch ends in a drain phase: the work counter is exhausted, ever fewer lanes still
-// carry a history, and the longest histories are ~40 times the mean -- about 8 of a lone
-// 1e7-history NSCP launch's 25 ms.  With carry-over a wave that finds the counter
-// exhausted parks each unfinished history in its work-item's own slot in HBM and exits;
-// the engine's next launch resumes it in the same work-item before handing out new ids.
-// Histories are keyed by id and draw from per-history counters, so which launch runs
-// which part of a history changes no result.
-struct CarrySlot {
-  Phonon p;
-  Rng rng;
-  Pending ev;
-  uint32_t state;   // 0 empty, 1 in flight, 3 in flight and parked on a reflection/transmission
-};
-
 // RES: which of the small tables are staged in LDS.  RES_ALL: the cell records and the
-// scatterer / receiver tables (layered and spherical models: a few dozen cells);
-// RES_TABLES: the tables only (tetra models: the cell records come through L1 / L2);
-// RES_NONE: neither (models with thousands of scatterers or receivers, whose tables
-// alone would not fit the CU's 160 KB).
+// scatterer heads (layered and spherical models: a few dozen cells); RES_TABLES: the scatterer
+// heads only (tetra models: the cell records come through L1 / L2); RES_NONE: neither (models
+// with thousands of scatterers, whose heads alone would crowd out the phonon pool).
 enum { RES_ALL = 0, RES_TABLES = 1, RES_NONE = 2 };
-template <int KIND, int RES, bool TRACE>
-__device__ __forceinline__ void propagate_body(const KArgs& a) {
-  using Cell = typename CellOf<KIND>::type;
-  constexpr bool LDS_CELLS = (RES == RES_ALL), LDS_TABLES = (RES != RES_NONE);
-  extern __shared__ __align__(16) unsigned char smem[];
-
-  // ---- stage the small tables in LDS ----
-  {
-    auto copy_words = [&](void* dst, const void* src, size_t bytes) {
-      unsigned long long* d = reinterpret_cast<unsigned long long*>(dst);
-      const unsigned long long* s = reinterpret_cast<const unsigned long long*>(src);
-      for (size_t i = threadIdx.x; i < bytes / 8; i += kBlock) d[i] = s[i];
-    };
-    if (LDS_CELLS) copy_words(smem + a.lds_cells_off, a.cells, (size_t)a.n_cells * sizeof(Cell));
-    if (LDS_TABLES) {
-      copy_words(smem + a.lds_scat_off, a.scat_head, (size_t)a.n_scat * sizeof(ScatHead));
-      copy_words(smem + a.lds_seis_off, a.seis_scan, (size_t)a.n_seis * sizeof(SeisScan));
-    }
-    if (a.lds_hit_off != 0xFFFFFFFFu)
-      copy_words(smem + a.lds_hit_off, a.seis_hit, (size_t)a.n_seis * sizeof(SeisHit));
-    if (a.lds_grid_off != 0xFFFFFFFFu) {   // seismometer hash: offsets as they are, items as u16
-      uint32_t* gs = reinterpret_cast<uint32_t*>(smem + a.lds_grid_off);
-      for (uint32_t i = threadIdx.x; i <= (uint32_t)a.grid.n_cells; i += kBlock) gs[i] = a.grid.start[i];
-      uint16_t* gi = reinterpret_cast<uint16_t*>(gs + a.grid.n_cells + 1);
-      for (uint32_t i = threadIdx.x; i < a.grid_n_items; i += kBlock) gi[i] = (uint16_t)a.grid.items[i];
-    }
-    if (a.acc_bits) {   // energies and counts zero, keys empty
-      const size_t n = (size_t)1 << a.acc_bits;
-      unsigned long long* z = reinterpret_cast<unsigned long long*>(smem + a.lds_acc_off);
-      for (size_t i = threadIdx.x; i < n * 5; i += kBlock) z[i] = 0ull;
-      uint32_t* k = reinterpret_cast<uint32_t*>(smem + a.lds_acc_off + n * 5 * sizeof(double));
-      for (size_t i = threadIdx.x; i < n * 3; i += kBlock) k[i] = (i < n) ? kEmpty : 0u;
-    }
-    __syncthreads();
-  }
-  const bool grid_in_lds = a.lds_grid_off != 0xFFFFFFFFu;   // wave-uniform
-  const uint32_t* lds_gstart = reinterpret_cast<const uint32_t*>(smem + (grid_in_lds ? a.lds_grid_off : 0u));
-  const uint16_t* lds_gitems = reinterpret_cast<const uint16_t*>(lds_gstart + a.grid.n_cells + 1);
-  BinCache bc;
-  bc.on = a.acc_bits != 0;
-  bc.e = reinterpret_cast<double*>(smem + a.lds_acc_off);
-  bc.key = reinterpret_cast<uint32_t*>(smem + a.lds_acc_off + ((size_t)5 * sizeof(double) << a.acc_bits));
-  bc.cnt = bc.key + ((size_t)1 << a.acc_bits);
-  bc.mask = (1u << a.acc_bits) - 1u, bc.shift = 32u - a.acc_bits;
-  const unsigned lane = threadIdx.x & 63u;
-  Tables<KIND> T;
-  T.cells = LDS_CELLS ? reinterpret_cast<const Cell*>(smem + a.lds_cells_off)
-                      : reinterpret_cast<const Cell*>(a.cells);
-  T.scat_head = LDS_TABLES ? reinterpret_cast<const ScatHead*>(smem + a.lds_scat_off) : a.scat_head;
-  T.seis_scan = LDS_TABLES ? reinterpret_cast<const SeisScan*>(smem + a.lds_seis_off) : a.seis_scan;
-  T.seis_hit = (a.lds_hit_off != 0xFFFFFFFFu) ? reinterpret_cast<const SeisHit*>(smem + a.lds_hit_off)
-                                              : a.seis_hit;
-
-  // Tallies live in LDS, not in registers: each iteration the wave adds its lanes'
-  // 0/1 events with one ballot + one LDS atomic per counter; the block flushes them
-  // to HBM once at the end.  Slot order = r3d_run_device's d_scalars.
-  __shared__ CatchQueue s_queue[kWaves];
-  CatchQueue& queue = s_queue[threadIdx.x >> 6];
-  unsigned q_count = 0;   // wave-uniform
-  __shared__ unsigned long long s_tally[R3D_N_SCALARS];
-  if (threadIdx.x < R3D_N_SCALARS) s_tally[threadIdx.x] = 0ull;
-  __syncthreads();
-  auto tally = [&](bool cond, int slot) {
-    const unsigned long long m = __ballot(cond);
-    if (lane == 0 && m) atomicAdd(&s_tally[slot], (unsigned long long)__popcll(m));
-  };
-  constexpr int kEv = 3 + R3D_INV_NUM;
-  // Report stream (diagnostic kernel only; include/r3d.h r3d_event): the lanes for which
-  // `cond` holds append one record each; the wave claims the slots with one atomic.
-  uint64_t my_id = 0;        // (only read when TRACE)
-  auto report = [&](bool cond, int tag, const Phonon& q) {
-    if (!TRACE || !a.evlog || !((a.evlog_mask >> tag) & 1u)) return;
-    const unsigned long long m = __ballot(cond);
-    if (!m) return;
-    const int first = __ffsll((long long)m) - 1;
-    unsigned long long base = 0;
-    if ((int)lane == first) base = atomicAdd(a.evlog_count, (unsigned long long)__popcll(m));
-    base = __shfl(base, first);
-    const unsigned long long at = base + (unsigned long long)rank_in(m);
-    if (cond && at < a.evlog_cap) {
-      r3d_event* r = reinterpret_cast<r3d_event*>(a.evlog) + at;
-      r->id = my_id;
-      r->time = q.t, r->path = q.path, r->amp = q.amp;
-      r->loc[0] = q.loc.x, r->loc[1] = q.loc.y, r->loc[2] = q.loc.z;
-      r->dir[0] = q.dir.x, r->dir[1] = q.dir.y, r->dir[2] = q.dir.z;
-      r->cell = (uint32_t)q.cell, r->moves = q.moves;
-      r->tag = (uint8_t)tag, r->type = (uint8_t)q.type;
-    }
-  };
-#ifdef R3D_PHASE_TIMING
-  __shared__ unsigned long long s_phase[8];
-  if (threadIdx.x < 8) s_phase[threadIdx.x] = 0ull;
-  __syncthreads();
-  unsigned long long t_phase = __builtin_readcyclecounter();
-#endif
-
-  Phonon p;
-  Rng rng;
-  uint32_t lane_catches = 0; // catches of the current history (only read when TRACE)
-  bool alive = false;
-  bool parked = false;   // holds a reflection/transmission event in `ev`, waiting for company
-  Pending ev;
-  ev.vel = 0.0, ev.face = -1, ev.flags = 0u;
-  unsigned long long w_next = 0, w_end = 0;  // wave-uniform: ids this wave still owns
-  bool drained = false;                      // wave-uniform: the global counter ran out
-  const size_t gtid = (size_t)blockIdx.x * kBlock + threadIdx.x;
-  if (a.carry_in) {   // resume the history this work-item parked at the end of the previous launch
-    CarrySlot* c = reinterpret_cast<CarrySlot*>(a.carry_in) + gtid;
-    const uint32_t state = c->state;
-    if (state) {
-      p = c->p, rng = c->rng, ev = c->ev;
-      alive = true, parked = (state & 2u) != 0;
-      my_id = ((uint64_t)rng.id_hi << 32) | rng.id_lo;
-      c->state = 0u;
-    }
-  }
-
-  for (;;) {
-    // ---- refill idle lanes from the wave's id range.  A refill costs a dependent
-    //      table search, so wait until kRefillMin lanes are idle -- or none is left
-    //      running -- and serve them together ----
-    unsigned long long need = __ballot(!alive);
-    const bool refill_now = (unsigned)__popcll(need) >= a.refill_min || need == ~0ull;
-    while (refill_now && need != 0ull && !drained) {
-      if (w_next == w_end) {
-        // claim ids: 256 at a time while the batch is far from its end, tapering to 64 so
-        // that no wave sits on unstarted histories while others have run dry (judged from
-        // where this wave's previous claim ended: no extra look at the counter)
-        unsigned long long base = 0, chunk = kChunk;
-        if (lane == 0) {
-          const unsigned long long seen = w_end;   // (where this wave's previous claim ended: a lower bound)
-          const unsigned long long left = (seen < a.n) ? a.n - seen : 0ull;
-          const unsigned long long share = left / (2ull * gridDim.x * kWaves);   // per wave, halved
-          chunk = (share >= kChunk) ? kChunk : (share >= 128ull ? 128ull : 64ull);
-          base = atomicAdd(a.next, chunk);
-        }
-        base = __shfl(base, 0), chunk = __shfl(chunk, 0);
-        if (base >= a.n) {
-          drained = true;
-          break;
-        }
-        w_next = base;
-        w_end = (base + chunk < a.n) ? base + chunk : a.n;
-      }
-      const unsigned want = (unsigned)__popcll(need);
-      const unsigned long long avail = w_end - w_next;
-      const unsigned take = (avail < want) ? (unsigned)avail : want;
-      const unsigned rank = rank_in(need);
-      const bool fresh = !alive && rank < take;
-      if (fresh) {
-        my_id = a.first_id + w_next + rank;
-        rng_init(rng, my_id);
-        spray(a, p, rng);
-        alive = true;
-        lane_catches = 0;
-      }
-      report(fresh, 0, p);   // GEN
-      if (lane == 0 && take) atomicAdd(&s_tally[kEv + R3D_EV_GENERATED], (unsigned long long)take);
-      w_next += take;
-      need = __ballot(!alive);
-    }
-    if (drained && a.carry_out) {   // no ids left: park what is in flight for the next launch
-      if (alive) {
-        CarrySlot* c = reinterpret_cast<CarrySlot*>(a.carry_out) + gtid;
-        c->p = p, c->rng = rng, c->ev = ev;
-        c->state = parked ? 3u : 1u;
-      }
-      break;
-    }
-    if (!__any(alive)) break;  // every lane idle and nothing left to hand out
-    R3D_STAMP(0);  // refill
-
-    // ---- first half of the iteration for every running lane: search, draw, advance ----
-    int fate = FATE_ALIVE, reason = 0;
-    LaneStats st = {0, 0, 0, 0, 0, 0, 0};   // this iteration's events of this lane
-    const bool run = alive && !parked;
-#if defined(R3D_PHASE_TIMING) && defined(R3D_PROBE_FETCH)
-    if (run) {   // exposed latency of the cell fetch: touch both cache lines of the record, wait
-      const volatile double* rec = reinterpret_cast<const volatile double*>(&T.cells[p.cell]);
-      double x0 = rec[0], x1 = rec[sizeof(Cell) / 8 - 1];
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(x0), "v"(x1));
-    }
-    R3D_STAMP(6);
-#endif
-    // Most moves end on a face with nothing to do but hand the phonon to the neighbour cell
-    // (velocity step below 1e-5 everywhere on the face, no receiver surface, no discontinuity:
-    // 86 % of the NSCP iterations).  Those lanes take the hand-over here and move again right
-    // away, up to kMovesPerIter moves per iteration, so that the per-iteration phases below
-    // (receivers, events, refill, book-keeping) are paid once for more than one move.  The
-    // order of operations within a history does not change.  (One call site in a loop that
-    // is kept rolled: a second copy of the move code would not fit the instruction cache.)
-    {
-      constexpr int kMovesPerIter = (KIND == CELL_SPH) ? 1 : kMovesPerIterLayeredTetra;
-      bool go = run;
-      int rep = 0;
-#pragma nounroll
-      for (;;) {
-        if (go) fate = step_move<KIND>(a, T, p, rng, st, &reason, ev);
-        if (++rep >= kMovesPerIter) break;
-        const bool again = go && fate == FATE_ALIVE && ev.face >= 0 && (ev.flags & F_SMOOTH) != 0 &&
-                           (ev.flags & F_ADJOIN) != 0 && (ev.flags & (F_COLLECT | F_REFLECT | F_DISCON)) == 0;
-        // worth it for kMoveAgainMin lanes of a full wave -- or for half of the lanes that moved, in
-        // a wave that is running thin (the drain of a launch, the flush of a chain)
-        const unsigned n_again = (unsigned)__popcll(__ballot(again)), n_went = (unsigned)__popcll(__ballot(go));
-        if (n_again < kMoveAgainMin && 2u * n_again < n_went) break;
-        tally(st.iterations != 0, kEv + R3D_EV_ITERATIONS);   // the move just made ...
-        st.iterations = 0;
-        tally(again, kEv + R3D_EV_TRANSFER);                  // ... and the hand-over taken here
-        if (again) p.cell = cell_neighbor(T.cells[p.cell], ev.face);
-        report(again, 4, p);   // CEL
-        go = again;
-      }
-    }
-    const bool moved = run && fate == FATE_ALIVE;
-    R3D_STAMP(1);  // move
-    report(moved && (ev.flags & F_COLLECT) != 0, 3, p);   // COL: the incident state
-
-    // ---- seismometers.  Each arriving lane looks up its own hash cell; the wave then deals
-    //      all (arrival, candidate receiver) pairs to its lanes, 64 per pass (collect_pairs) ----
-    uint32_t k0 = 0, k1 = 0;
-    if (moved && (ev.flags & F_COLLECT)) {
-      st.collect++;
-      const SeisGrid& g = a.grid;
-      const double fx = (p.loc.x - g.origin[0]) * g.inv_h;
-      const double fy = (p.loc.y - g.origin[1]) * g.inv_h;
-      const double fz = (p.loc.z - g.origin[2]) * g.inv_h;
-      if (fx >= 0 && fy >= 0 && fz >= 0 && fx < g.dim_f[0] && fy < g.dim_f[1] && fz < g.dim_f[2]) {
-        const int cellid = ((int)fz * g.dim[1] + (int)fy) * g.dim[0] + (int)fx;
-        if (grid_in_lds) k0 = lds_gstart[cellid], k1 = lds_gstart[cellid + 1];
-        else k0 = g.start[cellid], k1 = g.start[cellid + 1];
-      }
-    }
-#ifdef R3D_ABLATE_COLLECT  // timing-only developer build
-    k1 = k0;
-#endif
-    if (__any(k1 > k0))
-      collect_pairs<KIND, TRACE>(a, T, p, ev.vel, k0, k1, grid_in_lds ? lds_gitems : nullptr, lane,
-                                 st.n_catch, bc, queue, q_count);
-
-    R3D_STAMP(2);  // collect
-
-    // ---- second half.  Scatter, bend and hand-over are served at once.  The
-    //      reflection/transmission solve is the one long divergent branch (in the tetra
-    //      models about a fifth of the lanes per iteration): lanes that need it park until
-    //      rt_batch of them have gathered -- or nothing else can run -- and then take it
-    //      together.  Draws are per-history counters, so the order in which lanes are
-    //      served does not change any history.  (Parking the scattering draw the same way
-    //      was tried and measured: no gain on any model.) ----
-    constexpr bool kPark = (KIND == CELL_TET);   // (see r3d_engine_create: measured per cell kind)
-    if (moved) {
-      const bool heavy = kPark && ev.face >= 0 && (ev.flags & (F_REFLECT | F_DISCON)) != 0;
-      if (heavy) parked = true;
-      else fate = step_event<KIND, kPark ? EV_LIGHT : EV_ALL>(a, T, p, rng, st, ev);
-    }
-    R3D_STAMP(3);  // light events
-    if (kPark) {
-      const unsigned n_parked = (unsigned)__popcll(__ballot(parked));
-      // (in a wave that is running thin -- the drain of a launch, the flush of a chain -- a third
-      //  of the lanes still alive is company enough: waiting for rt_batch there would stretch
-      //  the longest histories, which are what the drain waits for)
-      const unsigned n_alive = (unsigned)__popcll(__ballot(alive && fate == FATE_ALIVE));
-      if (n_parked >= a.rt_batch || (n_parked > 0 && 3u * n_parked >= n_alive)) {
-        if (parked) {
-          fate = step_event<KIND, EV_RT>(a, T, p, rng, st, ev);
-          parked = false;
-        }
-      }
-    }
-
-    R3D_STAMP(4);  // parked R/T
-    // ---- book-keeping: this iteration's events, and lanes whose history ended ----
-    const bool died = alive && fate != FATE_ALIVE;
-    if (TRACE && a.evlog) {
-      report(st.scatter != 0, 1, p);    // SCT
-      report(st.reflect != 0, 2, p);    // REF
-      report(st.transfer != 0, 4, p);   // CEL
-      report(died && fate == FATE_LOST, 5, p);
-      report(died && fate == FATE_TIMEOUT, 6, p);
-      report(died && fate == FATE_INVALID, 7, p);
-    }
-    tally(st.iterations != 0, kEv + R3D_EV_ITERATIONS);
-    tally(st.scatter != 0, kEv + R3D_EV_SCATTER);
-    tally(st.collect != 0, kEv + R3D_EV_COLLECT);
-    tally(st.reflect != 0, kEv + R3D_EV_REFLECT);
-    tally(st.transfer != 0, kEv + R3D_EV_TRANSFER);
-    tally(st.rtsolve != 0, kEv + R3D_EV_RTSOLVE);
-    if (__any(st.n_catch != 0)) {   // a lane can be caught by several receivers at once
-      unsigned long long c = st.n_catch;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
-      if (lane == 0) atomicAdd(&s_tally[kEv + R3D_EV_CATCH], c);
-    }
-    if (__any(died)) {
-      tally(died && fate == FATE_LOST, 0);
-      tally(died && fate == FATE_TIMEOUT, 1);
-    }
-    if (TRACE) lane_catches += st.n_catch;
-    if (__any(died && fate == FATE_INVALID)) {   // rare
-      tally(died && fate == FATE_INVALID, 2);
-#pragma unroll
-      for (int r = 0; r < R3D_INV_NUM; r++) tally(died && fate == FATE_INVALID && reason == r, 3 + r);
-    }
-    if (died) {
-      alive = false;
-      if (TRACE && a.finals) {   // (the diagnostic kernel also runs for the report stream alone)
-        r3d_final* f = reinterpret_cast<r3d_final*>(a.finals) + (my_id - a.first_id);
-        f->time = p.t, f->path = p.path, f->amp = p.amp;
-        f->loc[0] = p.loc.x, f->loc[1] = p.loc.y, f->loc[2] = p.loc.z;
-        f->dir[0] = p.dir.x, f->dir[1] = p.dir.y, f->dir[2] = p.dir.z;
-        f->moves = p.moves;
-        f->fate = (uint8_t)fate;
-        f->type = (uint8_t)p.type;
-        f->n_catch = (uint16_t)(lane_catches > 65535u ? 65535u : lane_catches);
-      }
-    }
-    R3D_STAMP(5);  // tallies + deaths
-  }
-
-  // ---- drain the wave's catch queue, then flush the block's tallies to HBM ----
-  flush_catches(a, queue, q_count, lane);
-  __syncthreads();
-  if (bc.on) {
-    for (uint32_t i = threadIdx.x; i <= bc.mask; i += kBlock) {
-      const uint32_t bin = bc.key[i];
-      if (bin == kEmpty) continue;
-      double* e = a.energy + (size_t)bin * 5;
-#pragma unroll
-      for (int c = 0; c < 5; c++) {
-        const double v = bc.e[i * 5u + c];
-        if (v != 0.0) unsafeAtomicAdd(e + c, v);
-      }
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const uint32_t n = bc.cnt[i * 2u + t];
-        if (n) atomicAdd(a.counts + (size_t)bin * 2 + t, (unsigned long long)n);
-      }
-    }
-  }
-#ifdef R3D_PHASE_TIMING
-  if (threadIdx.x < 8) atomicAdd(&g_phase_cycles[threadIdx.x], s_phase[threadIdx.x]);
-#endif
-  if (threadIdx.x < R3D_N_SCALARS && s_tally[threadIdx.x] != 0ull)
-    atomicAdd(a.scalars + threadIdx.x, s_tally[threadIdx.x]);
-}
-
-// The traversal kernel, and the same body under a second name for the flush launch of a carry
-// chain (no new ids, only the histories carried over), so that profiles list the two apart.
-template <int KIND, int RES, bool TRACE>
-__global__ __launch_bounds__(kBlock) void propagate_kernel(const KArgs a) {
-  propagate_body<KIND, RES, TRACE>(a);
-}
-template <int KIND, int RES>
-__global__ __launch_bounds__(kBlock) void drain_kernel(const KArgs a) {
-  propagate_body<KIND, RES, false>(a);
-}
 
 }  // namespace r3d
 #include "r3d_pool.h"
@@ -727,8 +153,7 @@ using namespace r3d;
 struct r3d_engine {
   int device = 0;
   int kind = 0;
-  int res = RES_ALL;   // which tables live in LDS (see propagate_kernel)
-  bool pool = true;    // the pool kernel (r3d_pool.h); false: the lane-resident kernel (R3D_KERNEL=lanes)
+  int res = RES_ALL;   // which tables live in LDS (RES_*)
   size_t carry_bytes = 0;
   int n_seis = 0;
   uint32_t n_bins = 0;
@@ -746,7 +171,7 @@ struct r3d_engine {
   // it names and not whichever recorded last
   hipEvent_t ev0[kCounters] = {}, ev1[kCounters] = {};
   uint64_t launches = 0;   // launches enqueued so far; launch id k used slot (k - 1) % kCounters
-  std::unique_ptr<DevBuf> d_carry;   // CarrySlot per work-item of the grid (r3d_run_device_carry)
+  std::unique_ptr<DevBuf> d_carry;   // pool image per workgroup of the grid (r3d_run_device_carry)
   bool carry_pending = false;
   uint64_t carry_seed = 0;
   std::unique_ptr<DevBuf> d_volume;
@@ -799,78 +224,53 @@ hipError_t with_kernel(const r3d_engine* e, F&& f) {
       default: return f(kind, std::integral_constant<int, RES_NONE>{});
     }
   };
+#ifdef R3D_DEV_ONLY_KIND   // developer builds: one cell kind only (a sixth of the compile time)
+  if (e->kind != R3D_DEV_ONLY_KIND) return hipErrorInvalidValue;
+  return by_res(std::integral_constant<int, R3D_DEV_ONLY_KIND>{});
+#else
   switch (e->kind) {
     case R3D_CELL_CYLINDER: return by_res(std::integral_constant<int, CELL_CYL>{});
     case R3D_CELL_TETRA: return by_res(std::integral_constant<int, CELL_TET>{});
     default: return by_res(std::integral_constant<int, CELL_SPH>{});
   }
+#endif
 }
 
 // pool kernels: res 0 = cell records + scatterer heads in LDS, 1 = scatterer heads only, 2 = neither
 template <class F>
 hipError_t with_pool_kernel(const r3d_engine* e, F&& f) {
   return with_kernel(e, [&](auto kind, auto res) {
-    constexpr int K = decltype(kind)::value, R = decltype(res)::value;
+    constexpr int R = decltype(res)::value;
     return f(kind, std::integral_constant<bool, R == RES_ALL>{}, std::integral_constant<bool, R != RES_NONE>{});
   });
 }
 
 hipError_t launch_any(r3d_engine* e, const KArgs& a, bool trace, hipStream_t s, bool drain_only = false) {
-  if (e->pool)
-    return with_pool_kernel(e, [&](auto kind, auto cells, auto scat) {
-      constexpr int K = decltype(kind)::value;
-      constexpr bool C = decltype(cells)::value, H = decltype(scat)::value;
-      if (drain_only && !trace)
-        hipLaunchKernelGGL((pool_drain_kernel<K, C, H>), dim3(e->grid_blocks), dim3(kPoolBlock), e->lds_bytes, s, a);
-      else if (trace)
-        hipLaunchKernelGGL((pool_kernel<K, C, H, true>), dim3(e->grid_blocks), dim3(kPoolBlock), e->lds_bytes, s, a);
-      else
-        hipLaunchKernelGGL((pool_kernel<K, C, H, false>), dim3(e->grid_blocks), dim3(kPoolBlock), e->lds_bytes, s, a);
-      return hipGetLastError();
-    });
-  return with_kernel(e, [&](auto kind, auto res) {
-    constexpr int K = decltype(kind)::value, R = decltype(res)::value;
+  return with_pool_kernel(e, [&](auto kind, auto cells, auto scat) {
+    constexpr int K = decltype(kind)::value;
+    constexpr bool C = decltype(cells)::value, H = decltype(scat)::value;
     if (drain_only && !trace)
-      hipLaunchKernelGGL((drain_kernel<K, R>), dim3(e->grid_blocks), dim3(kBlock), e->lds_bytes, s, a);
+      hipLaunchKernelGGL((pool_drain_kernel<K, C, H>), dim3(e->grid_blocks), dim3(kPoolBlock), e->lds_bytes, s, a);
     else if (trace)
-      hipLaunchKernelGGL((propagate_kernel<K, R, true>), dim3(e->grid_blocks), dim3(kBlock), e->lds_bytes, s, a);
+      hipLaunchKernelGGL((pool_kernel<K, C, H, true>), dim3(e->grid_blocks), dim3(kPoolBlock), e->lds_bytes, s, a);
     else
-      hipLaunchKernelGGL((propagate_kernel<K, R, false>), dim3(e->grid_blocks), dim3(kBlock), e->lds_bytes, s, a);
+      hipLaunchKernelGGL((pool_kernel<K, C, H, false>), dim3(e->grid_blocks), dim3(kPoolBlock), e->lds_bytes, s, a);
     return hipGetLastError();
   });
 }
 
 hipError_t set_lds_attr(const r3d_engine* e) {
-  if (e->pool)
-    return with_pool_kernel(e, [&](auto kind, auto cells, auto scat) {
-      constexpr int K = decltype(kind)::value;
-      constexpr bool C = decltype(cells)::value, H = decltype(scat)::value;
-      hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_kernel<K, C, H, false>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
-      if (r != hipSuccess) return r;
-      r = hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_drain_kernel<K, C, H>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
-      if (r != hipSuccess) return r;
-      return hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_kernel<K, C, H, true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
-    });
-  return with_kernel(e, [&](auto kind, auto res) {
-    constexpr int K = decltype(kind)::value, R = decltype(res)::value;
-    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_kernel<K, R, false>),
+  return with_pool_kernel(e, [&](auto kind, auto cells, auto scat) {
+    constexpr int K = decltype(kind)::value;
+    constexpr bool C = decltype(cells)::value, H = decltype(scat)::value;
+    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_kernel<K, C, H, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
     if (r != hipSuccess) return r;
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(&drain_kernel<K, R>),
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_drain_kernel<K, C, H>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
     if (r != hipSuccess) return r;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&propagate_kernel<K, R, true>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_kernel<K, C, H, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
-  });
-}
-
-hipError_t blocks_per_cu(const r3d_engine* e, int* per_cu) {
-  return with_kernel(e, [&](auto kind, auto res) {
-    constexpr int K = decltype(kind)::value, R = decltype(res)::value;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, propagate_kernel<K, R, false>, kBlock, e->lds_bytes);
   });
 }
 
@@ -937,14 +337,6 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   pack_model(*m, pm);
   a = pm.args;
   const size_t cell_bytes = pm.cell_bytes();
-  // Scheduling knobs.  Parking pays where the R/T solve is a minority branch (tetra models:
-  // ~1/5 of the lanes per iteration, measured -10 %); in the layered and spherical models it
-  // is taken by most lanes anyway (measured +5 % with parking), so they do not park.
-  // (compiled in: the tetra kernel parks, the others do not; rt_batch is its trigger level)
-  a.rt_batch = (m->cell_kind == R3D_CELL_TETRA) ? kRtBatch : 1u;
-  a.refill_min = kRefillMin;
-  if (const char* s = getenv("R3D_RT_BATCH")) a.rt_batch = (uint32_t)std::max(1, atoi(s));   // developer tuning
-  if (const char* s = getenv("R3D_REFILL_MIN")) a.refill_min = (uint32_t)std::max(1, atoi(s));
   hipError_t err = hipSuccess;
   // ---- move every table into HBM and point the launch arguments at it ----
   switch (m->cell_kind) {
@@ -1045,9 +437,8 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   }
 
   // ---- LDS carve-up and launch geometry ----
-  if (const char* k = getenv("R3D_KERNEL")) e->pool = std::string(k) != "lanes";   // developer A/B
   a.grid_n_items = (uint32_t)pm.grid_items.size();
-  if (e->pool) {
+  {
     // Pool kernel (r3d_pool.h): the cell records (when there are few of them) and the scatterer
     // heads are staged in LDS, then a minimum of bin accumulators, and everything else goes to
     // the pool: S slots of 124 B (field-major) plus the rings of 16-bit slot numbers.
@@ -1096,67 +487,14 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
       g_error = "internal error: LDS carve-up exceeds the 160 KB of a CU";
       return nullptr;
     }
-  } else {
-    auto align16 = [](size_t x) { return (x + 15) & ~size_t(15); };
-    size_t off = 0;
-    // static LDS of the kernel: the waves' catch queues and the block's tallies
-    const size_t kStaticLds = sizeof(CatchQueue) * kWaves + 1024;
-    const size_t scat_bytes = (size_t)m->n_scatterers * sizeof(ScatHead);
-    const size_t scan_bytes = (size_t)std::max(1, m->n_seismometers) * sizeof(SeisScan);
-    // The scatterer heads and the receiver scan records go to LDS unless they would leave
-    // less than 16 KB for everything else (thousands of scatterers or receivers); the cell
-    // records go with them when they are small (layered and spherical models).
-    const bool tables_fit = scat_bytes + scan_bytes + kStaticLds + 16 * 1024 <= 160 * 1024;
-    const bool cells_fit = tables_fit && cell_bytes <= 48 * 1024 &&
-                           cell_bytes + scat_bytes + scan_bytes + kStaticLds + 16 * 1024 <= 160 * 1024;
-    e->res = cells_fit ? RES_ALL : tables_fit ? RES_TABLES : RES_NONE;
-    a.lds_cells_off = a.lds_scat_off = a.lds_seis_off = 0xFFFFFFFFu;
-    if (cells_fit) a.lds_cells_off = (uint32_t)off, off = align16(off + cell_bytes);
-    if (tables_fit) {
-      a.lds_scat_off = (uint32_t)off, off = align16(off + scat_bytes);
-      a.lds_seis_off = (uint32_t)off, off = align16(off + scan_bytes);
-    }
-    // the receiver "hit" records go to LDS only if everything still fits in the CU's 160 KB
-    const size_t hit_bytes = (size_t)std::max(1, m->n_seismometers) * sizeof(SeisHit);
-    a.lds_hit_off = 0xFFFFFFFFu;
-    if (tables_fit && off + hit_bytes + kStaticLds + 8192 <= 160 * 1024)
-      a.lds_hit_off = (uint32_t)off, off = align16(off + hit_bytes);
-    // the seismometer hash, when it is small (it is for the reference's survey lines and arrays:
-    // a few thousand cells): both levels of the lookup become LDS reads instead of two
-    // dependent global loads in every collecting iteration
-    a.lds_grid_off = 0xFFFFFFFFu, a.grid_n_items = (uint32_t)pm.grid_items.size();
-    {
-      const size_t grid_bytes = ((size_t)a.grid.n_cells + 1) * sizeof(uint32_t) + pm.grid_items.size() * sizeof(uint16_t);
-      if (m->n_seismometers > 0 && m->n_seismometers <= 65535 && grid_bytes <= 40 * 1024 &&
-          off + grid_bytes + kStaticLds + 8192 <= 160 * 1024)
-        a.lds_grid_off = (uint32_t)off, off = align16(off + grid_bytes);
-    }
-    // what is left (minus a little slack) goes to the bin accumulators
-    a.lds_acc_off = (uint32_t)off, a.acc_bits = 0;
-    if (m->n_seismometers > 0) {
-      const size_t left = 160 * 1024 - std::min<size_t>(160 * 1024, off + kStaticLds + 2048);
-      uint32_t bits = 0;
-      while (bits < 11 && (kAccEntryBytes << (bits + 1)) <= left) bits++;
-      if (const char* s = getenv("R3D_ACC_BITS")) bits = std::min<uint32_t>(bits, (uint32_t)atoi(s));   // developer tuning
-      if (bits >= 5) a.acc_bits = bits, off = align16(off + (kAccEntryBytes << bits));
-    }
-    e->lds_bytes = off;
-    if (e->lds_bytes + kStaticLds > 160 * 1024) {
-      g_error = "internal error: LDS carve-up exceeds the 160 KB of a CU";
-      return nullptr;
-    }
   }
   hipDeviceProp_t prop;
   R3D_HIP_OK(hipGetDeviceProperties(&prop, device));
   if (e->lds_bytes > 64 * 1024) R3D_HIP_OK(set_lds_attr(e.get()));
-  // persistent grid: exactly the workgroups that can be resident at once (register- and
-  // LDS-limited), so every block is running while there is work and none queues behind
-  int per_cu = 1;
-  if (!e->pool) R3D_HIP_OK(blocks_per_cu(e.get(), &per_cu));   // (the pool takes the CU's whole LDS: one workgroup)
-  per_cu = std::max(1, std::min(per_cu, 8));
-  e->grid_blocks = prop.multiProcessorCount * per_cu;
-  e->carry_bytes = e->pool ? (size_t)e->grid_blocks * a.pool_slots * kSlotBytes
-                           : (size_t)e->grid_blocks * kBlock * sizeof(CarrySlot);
+  // persistent grid: one workgroup per CU (the pool takes the CU's whole LDS), all resident at
+  // once, so every workgroup is running while there is work and none queues behind
+  e->grid_blocks = prop.multiProcessorCount;
+  e->carry_bytes = (size_t)e->grid_blocks * a.pool_slots * kSlotBytes;
 
   // ---- result scratch, work counter, stream, events ----
   R3D_HIP_OK(e->d_energy.alloc_zero((size_t)std::max(1, e->n_seis) * e->n_bins * R3D_N_ENERGY * sizeof(double)));
@@ -1341,16 +679,10 @@ int r3d_run_traced(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, 
 #ifdef R3D_PHASE_TIMING
 // diagnostic builds only: per queue of the pool kernel, batches served / lanes filled / wave cycles
 // since the last call (slot 6 of the first row: idle polls)
-int r3d_debug_pool_stats(unsigned long long out[24]) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pool_stats), 24 * sizeof(unsigned long long)) != hipSuccess) return 1;
-  unsigned long long zero[24] = {};
+int r3d_debug_pool_stats(unsigned long long out[40]) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pool_stats), 40 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  unsigned long long zero[40] = {};
   return hipMemcpyToSymbol(HIP_SYMBOL(g_pool_stats), zero, sizeof zero) != hipSuccess;
-}
-// diagnostic builds only: cumulative per-phase wave cycles since the last call
-int r3d_debug_phase_cycles(unsigned long long out[8]) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_cycles), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
-  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), zero, sizeof zero) != hipSuccess;
 }
 #endif
 

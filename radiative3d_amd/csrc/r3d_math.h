@@ -18,6 +18,15 @@
 #define R3D_HD inline
 #endif
 
+// A point the instruction scheduler may not move code across (device builds).  The long
+// straight-line solves are otherwise interleaved for instruction-level parallelism until their
+// temporaries no longer fit the register budget of three waves per SIMD.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(R3D_NO_SCHED_FENCE)
+#define R3D_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define R3D_SCHED_FENCE() ((void)0)
+#endif
+
 namespace r3d {
 
 constexpr double kPi = 3.14159265358979323846;
@@ -102,6 +111,43 @@ R3D_HD double exp_lean(double x) {
   p = __builtin_fma(p, r, 1.0);
   return ldexp(p, (int)k);
 }
+// log(x) for finite x > 0 (no zero / negative / subnormal handling: the callers' arguments are
+// uniforms in (0, 1] and ratios near 1): x = 2^e m, m in [sqrt(1/2), sqrt(2)), then the classical
+// kernel  log m = f - (hfsq - s (hfsq + R)),  f = m - 1, s = f / (2 + f)  (fdlibm e_log.c
+// coefficients, error below one ulp).
+R3D_HD double log_lean(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const long long bits = __double_as_longlong(x);
+#else
+  long long bits;
+  __builtin_memcpy(&bits, &x, 8);
+#endif
+  int e = (int)((bits >> 52) & 0x7FF) - 1023;
+  long long mant = bits & 0x000FFFFFFFFFFFFFll;
+  const bool upper = mant >= 0x6A09E667F3BCDll;          // m >= sqrt(2): take it as m / 2, e + 1
+  e += upper ? 1 : 0;
+  mant |= upper ? 0x3FE0000000000000ll : 0x3FF0000000000000ll;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double m = __longlong_as_double(mant);
+#else
+  double m;
+  __builtin_memcpy(&m, &mant, 8);
+#endif
+  const double f = m - 1.0;
+  const double s_ = f / (2.0 + f);
+  const double z = s_ * s_;
+  double r = 1.479819860511658591e-01;
+  r = __builtin_fma(r, z, 1.531383769920937332e-01);
+  r = __builtin_fma(r, z, 1.818357216161805012e-01);
+  r = __builtin_fma(r, z, 2.222219843214978396e-01);
+  r = __builtin_fma(r, z, 2.857142874366239149e-01);
+  r = __builtin_fma(r, z, 3.999999999940941908e-01);
+  r = __builtin_fma(r, z, 6.666666666666735130e-01);
+  r *= z;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)e;
+  return dk * 6.93147180369123816490e-01 - ((hfsq - (s_ * (hfsq + r) + dk * 1.90821492927058770002e-10)) - f);
+}
 // atanh(y) for |y| <= 0.2 by its odd series y + y^3/3 + ... + y^23/23 (first term left out:
 // y^25 / 25, below 1e-18 relative to y on this interval).
 R3D_HD double atanh_small(double y) {
@@ -142,8 +188,16 @@ R3D_HD void sincos_small(double x, double* s, double* c) {
 // sin and cos of a rotation angle: the small-argument kernels where they apply (a scatter leg is a
 // fraction of a cell), else the library's.
 R3D_HD void rotation(double x, double* s, double* c) {
-  if (fabs(x) <= 0.78539816339744830962) sincos_small(x, s, c);
-  else sincos(x, s, c);
+  if (fabs(x) <= 0.78539816339744830962) {
+    sincos_small(x, s, c);
+  } else if (fabs(x) <= 3.14159265358979323846) {   // a quarter of the angle, doubled twice
+    double s4, c4;
+    sincos_small(0.25 * x, &s4, &c4);
+    const double s2 = 2.0 * s4 * c4, c2 = 1.0 - 2.0 * s4 * s4;
+    *s = 2.0 * s2 * c2, *c = 1.0 - 2.0 * s2 * s2;
+  } else {
+    sincos(x, s, c);
+  }
 }
 
 struct V3 {

@@ -245,7 +245,7 @@ R3D_HD void tet_advance(const CellTet& c, const TetArc& A, Phonon& p, double len
   // atanh(s1) - atanh(s0) = atanh(y), y = (s1 - s0) / (1 - s0 s1): a leg spans a few degrees, so y
   // is small and the series does (one division, no logarithm)
   const double y = (s1 - A.s0) / (1.0 - A.s0 * s1);
-  double time = c.inv_gmag[t] * ((fabs(y) <= 0.2) ? atanh_small(y) : 0.5 * log((1.0 + y) / (1.0 - y)));
+  double time = c.inv_gmag[t] * ((fabs(y) <= 0.2) ? atanh_small(y) : 0.5 * log_lean((1.0 + y) / (1.0 - y)));
   p.path += len, p.t += time, p.recent += time;
   p.loc = nl;
   // (nd = c1 v1 - s1 v3 with v1, v3 orthonormal is unit to rounding; the reference's
@@ -338,6 +338,10 @@ R3D_HD SphArc sph_arc(const CellSph& c, const double ec[3], const Phonon& p) {
 // it applies (a leg rarely spans more than a few degrees), else the general function.
 R3D_HD double angle_from_sincos(double s, double c) {
   if (c > 0 && fabs(s) <= 0.5) return asin_small(s);
+  // up to 60 degrees either way: the half angle, cos(d/2) = sqrt((1 + c) / 2), sin(d/2) = s / (2 cos(d/2))
+  const double ch = fsqrt(0.5 * (1.0 + c));
+  const double sh = 0.5 * s / ch;
+  if (c > -0.5 && fabs(sh) <= 0.5) return 2.0 * asin_small(sh);
   return atan2(s, c);
 }
 // reference SphereShell::GetPathToBoundary, media.cpp:668-757 (search part), with
@@ -414,7 +418,7 @@ R3D_HD void sph_advance(const CellSph& c, const SphArc& A, Phonon& p, double len
     const double x0 = A.CotZetaBy2 * (A.s0 / (1.0 + A.c0));
     const double x1 = A.CotZetaBy2 * (s1 / (1.0 + c1));
     const double y = (x1 - x0) / (1.0 - x0 * x1);
-    time = att_time = A.timeCoef * ((fabs(y) <= 0.2) ? atanh_small(y) : 0.5 * log((1.0 + y) / (1.0 - y)));
+    time = att_time = A.timeCoef * ((fabs(y) <= 0.2) ? atanh_small(y) : 0.5 * log_lean((1.0 + y) / (1.0 - y)));
     p.dir = through_angles(unit(nd));
   }
   p.path += len, p.t += time, p.recent += time;
@@ -450,65 +454,91 @@ enum { R_P, R_SV, R_SH, T_P, T_SV, T_SH, RT_NUM };
 // explicitly.
 // Outcome weights of one interface for incidence sine `sini` and incident type
 // `intype` (0 P, 1 SH, 2 SV): w[k] = |det|^2 x the reference's mProb[k]
-// (rtcoef.cpp:207-278, :107-198, :289-393); sn / cr = sine and real cosine of each
-// outgoing ray; det2 = |determinant|^2.  Outcome order R_P, R_SV, R_SH, T_P, T_SV,
-// T_SH (rtcoef.hpp:79-87).
-R3D_HD void rt_weights(const Iface& f, double sini, int intype, double w[RT_NUM], double sn[RT_NUM],
-                       double cr[RT_NUM], double& det2) {
+// (rtcoef.cpp:207-278, :107-198, :289-393); det2 = |determinant|^2.  Outcome order R_P, R_SV,
+// R_SH, T_P, T_SV, T_SH (rtcoef.hpp:79-87).  (Only the weights leave this function: the sine and
+// cosine of the one outgoing ray that is chosen are formed afterwards, rt_ray() -- carrying all six
+// pairs through the solve cost two dozen registers.)
+R3D_HD void rt_weights(const Iface& f, double sini, int intype, double w[RT_NUM], double& det2) {
   const double rho1 = f.rhoR, rho2 = f.rhoT;
   const double a1 = f.vR[0], a2 = f.vT[0], b1 = f.vR[1], b2 = f.vT[1];
 #pragma unroll
-  for (int i = 0; i < RT_NUM; i++) w[i] = 0, sn[i] = 0, cr[i] = 0;
+  for (int i = 0; i < RT_NUM; i++) w[i] = 0;
   if (intype == 1) {  // GetCoefs_SH, rtcoef.cpp:207-278
-    sn[R_SH] = sini;
-    sn[T_SH] = (b2 / b1) * sini;
-    const Cx cj1 = sqrt_real(1.0 - sn[R_SH] * sn[R_SH]);
-    const Cx cj2 = sqrt_real(1.0 - sn[T_SH] * sn[T_SH]);
+    const double s2 = (b2 / b1) * sini;
+    const Cx cj1 = sqrt_real(1.0 - sini * sini);
+    const Cx cj2 = sqrt_real(1.0 - s2 * s2);
     const Cx a = (rho1 * b1) * cj1, b = (rho2 * b2) * cj2;
-    cr[R_SH] = cj1.re, cr[T_SH] = cj2.re;
     det2 = norm(a + b);
     w[R_SH] = rho1 * b1 * cj1.re * norm(a - b);
     w[T_SH] = rho2 * b2 * cj2.re * (4.0 * norm(a));
   } else {  // GetCoefs_PSV, rtcoef.cpp:107-198, :289-393
+    // (Written for a small register footprint: the velocities, densities and reciprocals are
+    //  folded into the four vertical slownesses, four real prefactors and a, b, c, d as early as
+    //  possible, and the numerators are formed one outcome at a time.)
     const bool in_p = (intype == 0);
-    const double ia1 = 1.0 / a1, ia2 = 1.0 / a2, ib1 = 1.0 / b1, ib2 = 1.0 / b2;
-    const double pp = sini * (in_p ? ia1 : ib1);  // horizontal slowness
-    sn[T_P] = a2 * pp, sn[T_SV] = b2 * pp, sn[R_SV] = b1 * pp, sn[R_P] = a1 * pp;
-    const Cx cTP = sqrt_real(1.0 - sn[T_P] * sn[T_P]);
-    const Cx cTS = sqrt_real(1.0 - sn[T_SV] * sn[T_SV]);
-    const Cx cRS = sqrt_real(1.0 - sn[R_SV] * sn[R_SV]);
-    const Cx cRP = sqrt_real(1.0 - sn[R_P] * sn[R_P]);
-    cr[T_P] = cTP.re, cr[T_SV] = cTS.re, cr[R_SV] = cRS.re, cr[R_P] = cRP.re;
-    const double b1s = b1 * b1, b2s = b2 * b2, psq = pp * pp;
-    const double t1 = rho1 * (1. - 2. * b1s * psq), t2 = rho2 * (1. - 2. * b2s * psq);
-    const double t3 = 2. * rho1 * b1s, t4 = 2. * rho2 * b2s;
-    const double a = t2 - t1, b = t2 + t3 * psq, c = t1 + t4 * psq, d = t4 - t3;
-    const Cx ci1 = ia1 * cRP, ci2 = ia2 * cTP, cj1 = ib1 * cRS, cj2 = ib2 * cTS;
+    double kRP, kRS, kTP, kTS;       // rho v Re(cos) x the velocity-ratio factors of rtcoef.cpp:150-186
+    Cx ci1, ci2, cj1, cj2;           // vertical slownesses cos / v of the four outgoing rays
+    double a, b, c, d, pp, psq, t_in;
+    {
+      const double ia1 = 1.0 / a1, ia2 = 1.0 / a2, ib1 = 1.0 / b1, ib2 = 1.0 / b2;
+      pp = sini * (in_p ? ia1 : ib1);  // horizontal slowness
+      psq = pp * pp;
+      const double sTP = a2 * pp, sTS = b2 * pp, sRS = b1 * pp, sRP = a1 * pp;   // the outgoing rays' sines
+      const Cx cTP = sqrt_real(1.0 - sTP * sTP);
+      const Cx cTS = sqrt_real(1.0 - sTS * sTS);
+      const Cx cRS = sqrt_real(1.0 - sRS * sRS);
+      const Cx cRP = sqrt_real(1.0 - sRP * sRP);
+      ci1 = ia1 * cRP, ci2 = ia2 * cTP, cj1 = ib1 * cRS, cj2 = ib2 * cTS;
+      kRP = rho1 * a1 * cRP.re * (in_p ? 1.0 : ia1 * ia1);
+      kRS = rho1 * b1 * cRS.re * (in_p ? ib1 * ib1 : 1.0);
+      kTP = rho2 * a2 * cTP.re * (ia2 * ia2);
+      kTS = rho2 * b2 * cTS.re * (ib2 * ib2);
+      const double b1s = b1 * b1, b2s = b2 * b2;
+      const double t1 = rho1 * (1. - 2. * b1s * psq), t2 = rho2 * (1. - 2. * b2s * psq);
+      const double t3 = 2. * rho1 * b1s, t4 = 2. * rho2 * b2s;
+      a = t2 - t1, b = t2 + t3 * psq, c = t1 + t4 * psq, d = t4 - t3;
+      t_in = rho1 * (in_p ? a1 : b1);
+      R3D_SCHED_FENCE();
+    }
     const Cx E = b * ci1 + c * ci2, F = b * cj1 + c * cj2;
     const Cx G = a - (d * ci1) * cj2, H = a - (d * ci2) * cj1;
-    const Cx D = E * F + (G * H) * psq;
-    det2 = norm(D);
-    Cx nRP, nRS, nTP, nTS;   // amplitude numerators (times the velocity ratio factors below)
-    if (in_p) {
-      nRP = (b * ci1 - c * ci2) * F - ((a + (d * ci1) * cj2) * H) * psq;
-      nRS = ((-2.0 * pp * a1) * ci1) * ((a * b) + ((c * d) * ci2) * cj2);
-      const Cx T1 = (2.0 * rho1 * a1) * ci1;
-      nTP = T1 * F;
-      nTS = (T1 * H) * pp;
-    } else {
-      nRP = ((-2.0 * pp * b1) * cj1) * ((a * b) + ((c * d) * ci2) * cj2);
-      nRS = (b * cj1 - c * cj2) * E - ((a + (d * ci2) * cj1) * G) * psq;
-      const Cx T1 = (2.0 * rho1 * b1) * cj1;
-      nTP = (T1 * G) * pp;
-      nTS = T1 * E;
+    {
+      const Cx D = E * F + (G * H) * psq;
+      det2 = norm(D);
     }
-    // |A|^2 |D|^2: R_P and R_SV numerators carry 1/b1 resp. 1/a1 when the type converts,
-    // the transmitted ones 1/a2, 1/b2 (rtcoef.cpp:150-186)
-    const double sRP = in_p ? 1.0 : ia1 * ia1, sRS = in_p ? ib1 * ib1 : 1.0;
-    w[R_P] = rho1 * a1 * cRP.re * (norm(nRP) * sRP);
-    w[R_SV] = rho1 * b1 * cRS.re * (norm(nRS) * sRS);
-    w[T_P] = rho2 * a2 * cTP.re * (norm(nTP) * (ia2 * ia2));
-    w[T_SV] = rho2 * b2 * cTS.re * (norm(nTS) * (ib2 * ib2));
+    const Cx inc = in_p ? ci1 : cj1;                    // the incident wave's own vertical slowness
+    const double v_in = in_p ? a1 : b1;
+    R3D_SCHED_FENCE();
+    {
+      const Cx conv = ((-2.0 * pp * v_in) * inc) * ((a * b) + ((c * d) * ci2) * cj2);   // converted reflection
+      const Cx same = in_p ? (b * ci1 - c * ci2) * F - ((a + (d * ci1) * cj2) * H) * psq
+                           : (b * cj1 - c * cj2) * E - ((a + (d * ci2) * cj1) * G) * psq;   // same-type reflection
+      w[R_P] = kRP * norm(in_p ? same : conv);
+      w[R_SV] = kRS * norm(in_p ? conv : same);
+    }
+    R3D_SCHED_FENCE();
+    {
+      const Cx T1 = (2.0 * t_in) * inc;
+      const Cx nTP = in_p ? T1 * F : (T1 * G) * pp;
+      w[T_P] = kTP * norm(nTP);
+      const Cx nTS = in_p ? (T1 * H) * pp : T1 * E;
+      w[T_SV] = kTS * norm(nTS);
+    }
+    R3D_SCHED_FENCE();
+  }
+}
+// Sine and real cosine of outgoing ray `choice` (Snell: sine = outgoing velocity x the horizontal
+// slowness; the same expressions the weights were formed from).
+R3D_HD void rt_ray(const Iface& f, double sini, int intype, int choice, double& sn, double& cr) {
+  const double v_in = (intype == 0) ? f.vR[0] : f.vR[1];
+  const double v_out = (choice == R_P) ? f.vR[0] : (choice == T_P) ? f.vT[0] : (choice >= T_P) ? f.vT[1] : f.vR[1];
+  if (intype == 1) {   // (b2 / b1) sini as in rt_weights; the reflected SH ray keeps the incidence sine
+    sn = (choice == R_SH) ? sini : (f.vT[1] / f.vR[1]) * sini;
+    cr = sqrt_real(1.0 - sn * sn).re;
+  } else {
+    const double pp = sini * (1.0 / v_in);
+    sn = v_out * pp;
+    cr = sqrt_real(1.0 - sn * sn).re;
   }
 }
 
@@ -532,8 +562,15 @@ bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
     double sh = dot(direction_of_motion(p), fparash);
     intype = (rng_draw(rng, key) <= sh * sh) ? 1 : 2;
   }
-  double w[RT_NUM], sn[RT_NUM], cr[RT_NUM], det2;
-  rt_weights(f, sini, intype, w, sn, cr, det2);
+  double w[RT_NUM], det2;
+  R3D_SCHED_FENCE();
+#ifdef R3D_STUB_RTW   // register-pressure experiment (compile-only)
+  for (int i = 0; i < RT_NUM; i++) w[i] = sini * (i + 1) * f.vR[i & 1];
+  det2 = f.rhoT + f.vT[0] + f.vT[1] + f.rhoR;
+#else
+  rt_weights(f, sini, intype, w, det2);
+#endif
+  R3D_SCHED_FENCE();
   const int defchoice = intype == 0 ? R_P : intype == 1 ? R_SH : R_SV;   // GetCoefs, rtcoef.cpp:76-97
   // Choose, rtcoef.cpp:436-475
   double cum[RT_NUM];
@@ -549,11 +586,10 @@ bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
   if (total == 0 || (total - total) != 0 || !(det2 > 0) || (det2 - det2) != 0) choice = defchoice;
   if (no_transmit && choice >= T_P) choice -= 3;  // T_x -> R_x
   const bool reflected = choice < T_P;
+  R3D_SCHED_FENCE();
   // GetChosenRayDirection, rtcoef.cpp:529-548
-  double comp_para = 0, comp_norm = 0;
-#pragma unroll
-  for (int i = 0; i < RT_NUM; i++)
-    if (i == choice) comp_para = sn[i], comp_norm = cr[i];
+  double comp_para, comp_norm;
+  rt_ray(f, sini, intype, choice, comp_para, comp_norm);
   if (comp_para > 1.0) comp_para = 1.0;
   if (reflected) comp_norm = -comp_norm;
   V3 out = comp_para * fpara + comp_norm * fnorm;
@@ -619,8 +655,19 @@ R3D_HD uint64_t sample_cdf(const double* __restrict__ cdf, uint64_t n, double u)
 // finds -- instead of two or three probes that each wait for the one before: the draw costs two
 // dependent memory round trips (guide, bracket) where the bisection cost three to four.  Only
 // a bracket longer than eight entries falls back to bisecting its remainder.
-R3D_HD uint64_t sample_cdf_guided(const double* __restrict__ cdf, const uint32_t* __restrict__ guide,
+R3D_HD uint64_t sample_cdf_guided(const double* __restrict__ cdf_, const uint32_t* __restrict__ guide_,
                                   uint32_t bits, double total, double u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the tables live in HBM: say so, or pointers that were themselves loaded from memory become
+  // FLAT loads (which also count against the LDS counter and wait with it)
+  typedef __attribute__((address_space(1))) const double gdouble;
+  typedef __attribute__((address_space(1))) const uint32_t gu32;
+  gdouble* cdf = (gdouble*)cdf_;
+  gu32* guide = (gu32*)guide_;
+#else
+  const double* cdf = cdf_;
+  const uint32_t* guide = guide_;
+#endif
   const double r = total * u;
   uint32_t j = (uint32_t)(u * (double)(1u << bits));
   if (j > (1u << bits) - 1u) j = (1u << bits) - 1u;

@@ -47,6 +47,11 @@ constexpr int kPoolWaves = kPoolBlock / 64;
 
 enum { Q_MOVE = 0, Q_COLLECT = 1, Q_RT = 2, Q_SCATTER = 3, Q_FREE = 4, Q_NUM = 5 };
 constexpr uint16_t kRingEmpty = 0xFFFFu;
+// The rings are polled with volatile accesses.  Through a plain (generic) pointer those compile to
+// FLAT instructions with system-scope cache bits and a wait for every outstanding memory operation
+// of the wave -- a thousand cycles per take and per hand-off, measured; through a pointer in the
+// LDS address space they are the ds_read_u16 / ds_write_b16 they should be.
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
 // One history in flight = one slot number; its state is spread over field-major arrays in LDS
 // (fd[field][slot] doubles, fu[field][slot] words), so that a batch of neighbouring slot numbers
@@ -75,7 +80,7 @@ __device__ __forceinline__ uint32_t meta_pack(int type, int face, uint32_t flags
 
 // Take up to 64 slot numbers from queue q, whose control word was last seen as `seen`; returns how
 // many (wave-uniform); lane l < k gets its slot in `id`.
-__device__ __forceinline__ unsigned q_pop(PoolCtl& ctl, uint16_t* ring, uint32_t mask, int q, unsigned lane,
+__device__ __forceinline__ unsigned q_pop(PoolCtl& ctl, lds_u16* ring, uint32_t mask, int q, unsigned lane,
                                           uint32_t seen, unsigned& id) {
   unsigned k = 0, pos = 0;
   if (lane == 0) {
@@ -95,7 +100,7 @@ __device__ __forceinline__ unsigned q_pop(PoolCtl& ctl, uint16_t* ring, uint32_t
   pos = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
   id = 0;
   if (lane < k) {
-    volatile uint16_t* e = ring + ((pos + lane) & mask);
+    volatile lds_u16* e = ring + ((pos + lane) & mask);
     uint16_t v;
     do {
       v = *e;
@@ -110,7 +115,7 @@ __device__ __forceinline__ unsigned q_pop(PoolCtl& ctl, uint16_t* ring, uint32_t
 // Hand every active lane's slot to the queue named in its `dest` (all queues in one go: lane q
 // takes the tail tickets of queue q and publishes its count, so the whole distribution costs one
 // round of LDS atomics each way).
-__device__ __forceinline__ void q_push_all(PoolCtl& ctl, uint16_t* rings, uint32_t rcap, unsigned lane, bool act,
+__device__ __forceinline__ void q_push_all(PoolCtl& ctl, lds_u16* rings, uint32_t rcap, unsigned lane, bool act,
                                            int dest, unsigned id) {
   unsigned long long m[Q_NUM];
   uint32_t kq = 0, rank = 0;
@@ -125,7 +130,7 @@ __device__ __forceinline__ void q_push_all(PoolCtl& ctl, uint16_t* rings, uint32
   if (lane < Q_NUM && kq) pos = atomicAdd(&ctl.tail[lane], kq);
   const uint32_t mine = (uint32_t)__shfl((int)pos, act ? dest : 0);
   if (act) {
-    volatile uint16_t* e = rings + (size_t)dest * rcap + ((mine + rank) & (rcap - 1u));
+    volatile lds_u16* e = rings + (uint32_t)dest * rcap + ((mine + rank) & (rcap - 1u));
     while (*e != kRingEmpty) {
     }
     *e = (uint16_t)id;
@@ -230,7 +235,7 @@ __device__ __forceinline__ uint32_t pool_collect_pairs(const KArgs& a, const Tab
 #ifdef R3D_PHASE_TIMING
 // diagnostic build: per queue, batches served, lanes filled, wave cycles spent; slot 6: idle polls;
 // slot 7 of rows 0 / 1: move sub-iterations run / lanes live in them
-__device__ unsigned long long g_pool_stats[3][8];
+__device__ unsigned long long g_pool_stats[5][8];   // rows 3 / 4: cycles in the take / in the hand-off
 #endif
 
 // Moves a batch may make before its slots go back to the queues: lanes whose move ends with nothing
@@ -297,14 +302,14 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   const uint32_t S = a.pool_slots, rcap = a.pool_ring_mask + 1u, rmask = a.pool_ring_mask;
   double* const fd = reinterpret_cast<double*>(smem + a.lds_pool_off);          // [FD_NUM][S]
   uint32_t* const fu = reinterpret_cast<uint32_t*>(fd + (size_t)FD_NUM * S);    // [FU_NUM][S]
-  uint16_t* const rings = reinterpret_cast<uint16_t*>(smem + a.lds_ring_off);   // [Q_NUM][rcap]
+  lds_u16* const rings = (lds_u16*)(smem + a.lds_ring_off);                      // [Q_NUM][rcap]
   __shared__ PoolCtl ctl;
   __shared__ unsigned long long s_tally[R3D_N_SCALARS];
   for (uint32_t i = tid; i < Q_NUM * rcap; i += kPoolBlock) rings[i] = kRingEmpty;
   if (tid < R3D_N_SCALARS) s_tally[tid] = 0ull;
   if (tid < 8) ctl.word[tid] = 0u, ctl.tail[tid] = 0u;
   __syncthreads();
-  auto ring = [&](int q) { return rings + (size_t)q * rcap; };
+  auto ring = [&](int q) { return rings + (uint32_t)q * rcap; };
   const size_t image_words = (size_t)S * (kSlotBytes / 4);   // the pool's state as 32-bit words
   if (a.carry_in) {
     // resume: the pool image this workgroup parked at the end of the engine's previous launch;
@@ -407,8 +412,8 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
     u[FU_CELL * S] = (uint32_t)p.cell, u[FU_MOVES * S] = p.moves, u[FU_K * S] = rng.k, u[FU_META * S] = meta;
   };
 #ifdef R3D_PHASE_TIMING
-  __shared__ unsigned long long s_stats[3][8];
-  if (tid < 24) s_stats[tid / 8][tid % 8] = 0ull;
+  __shared__ unsigned long long s_stats[5][8];
+  if (tid < 40) s_stats[tid / 8][tid % 8] = 0ull;
   __syncthreads();
 #endif
 
@@ -448,6 +453,9 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #pragma unroll
     for (int j = 0; j < Q_NUM; j++) wq = (q == j) ? w[j] : wq;
     unsigned id;
+#ifdef R3D_PHASE_TIMING
+    const unsigned long long t_pop = __builtin_readcyclecounter();
+#endif
     const unsigned k = q_pop(ctl, ring(q), rmask, q, lane, wq, id);
     if (k == 0) continue;   // another wave was quicker
     const bool act = lane < k;
@@ -498,7 +506,9 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         ev.vel = 0.0, ev.face = -1, ev.flags = 0u;
         bool leaving = false;
         if (live) {
+#ifndef R3D_NO_MOVE
           fate = step_move<KIND>(a, T, p, rng, st, &reason, ev);
+#endif
           leaving = true;
           if (fate != FATE_ALIVE) {
             dest = Q_FREE;
@@ -576,7 +586,12 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #endif
       report(act, 3, p, hid);   // COL: the incident state
       tally_n(kEv + R3D_EV_COLLECT, k);
-      if (__any(k1 > k0)) {
+#ifndef R3D_NO_COLLECT
+      if (__any(k1 > k0))
+#else
+      if (false)
+#endif
+      {
         const uint32_t hits = pool_collect_pairs<KIND, TRACE>(a, T, p, vel, k0, k1, LDS_SEIS ? lds_gitems : nullptr,
                                                               lane, catches, bc);
         tally_n(kEv + R3D_EV_CATCH, hits);
@@ -625,8 +640,12 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         hid = ((uint64_t)rng.id_hi << 32) | rng.id_lo;
         Pending ev;
         ev.vel = 0.0, ev.face = (int)((meta >> 1) & 7u) - 1, ev.flags = (meta >> 8) & 0xFFu;
+#ifndef R3D_NO_RT
         if (q == Q_RT) step_event<KIND, EV_RT>(a, T, p, rng, st, ev, (int)fu[FU_NBR * S + id]);
-        else step_event<KIND, EV_SCATTER>(a, T, p, rng, st, ev);
+#endif
+#ifndef R3D_NO_SCATTER
+        if (q != Q_RT) step_event<KIND, EV_SCATTER>(a, T, p, rng, st, ev);
+#endif
         double* d = fd + id;
         d[FD_DX * S] = p.dir.x, d[FD_DY * S] = p.dir.y, d[FD_DZ * S] = p.dir.z;
         d[FD_PC * S] = p.pc, d[FD_PS * S] = p.ps;
@@ -640,12 +659,18 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         report(st.transfer != tr0, 4, p, hid);      // CEL
       }
     }
+#ifdef R3D_PHASE_TIMING
+    const unsigned long long t_push = __builtin_readcyclecounter();
+#endif
     q_push_all(ctl, rings, rcap, lane, act, dest, id);
 #ifdef R3D_PHASE_TIMING
     if (lane == 0) {
+      const unsigned long long t_end = __builtin_readcyclecounter();
       atomicAdd(&s_stats[0][q], 1ull);
       atomicAdd(&s_stats[1][q], (unsigned long long)k);
-      atomicAdd(&s_stats[2][q], __builtin_readcyclecounter() - t_begin);
+      atomicAdd(&s_stats[2][q], t_end - t_pop);
+      atomicAdd(&s_stats[3][q], t_begin - t_pop);
+      atomicAdd(&s_stats[4][q], t_end - t_push);
     }
 #endif
   }
@@ -685,7 +710,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
     }
   }
 #ifdef R3D_PHASE_TIMING
-  if (tid < 24) atomicAdd(&g_pool_stats[tid / 8][tid % 8], s_stats[tid / 8][tid % 8]);
+  if (tid < 40) atomicAdd(&g_pool_stats[tid / 8][tid % 8], s_stats[tid / 8][tid % 8]);
 #endif
   if (tid < R3D_N_SCALARS && s_tally[tid] != 0ull) atomicAdd(a.scalars + tid, s_tally[tid]);
 }

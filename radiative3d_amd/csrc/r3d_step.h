@@ -221,7 +221,7 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
   const double u_free = rng_draw(rng, rng_key(a.seed));
   const double mfp = T.scat_head[c.scat].mfp[p.type];
   double scatlen = pos_inf();
-  if (!((1.0 - u_free) * mfp >= e.len)) scatlen = -log(u_free) * mfp;
+  if (!((1.0 - u_free) * mfp >= e.len)) scatlen = -log_lean(u_free) * mfp;
   const bool scatters = scatlen < e.len;
   const double len = scatters ? scatlen : e.len;
 
@@ -284,7 +284,14 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
                                      rng_draw(rng, rng_key(a.seed)));
 #endif
       double rc = 1.0, rs = 0.0;      // relative polarisation 0 except S->S (scatterers.cpp:341-356)
-      if (conv == 3) sincos(sp->spol[k], &rs, &rc);
+      if (conv == 3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef __attribute__((address_space(1))) const double gdouble;   // (HBM: a global, not a FLAT, load)
+        sincos(((gdouble*)sp->spol)[k], &rs, &rc);
+#else
+        sincos(sp->spol[k], &rs, &rc);
+#endif
+      }
       scatter_transform(p, v3(a.toa_xyz + 3 * k), rc, rs, (conv & 1) ? RAY_S : RAY_P);
     }
     volume_count(a, p);   // SCT

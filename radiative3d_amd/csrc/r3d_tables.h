@@ -157,9 +157,6 @@ struct KArgs {
   // per work-item of the grid, see r3d_engine.hip
   void* carry_in;
   void* carry_out;
-  // scheduling knobs (wave-uniform)
-  uint32_t rt_batch;         // parked R/T lanes that trigger the solve (<= 1: never park)
-  uint32_t refill_min;       // idle lanes that trigger a refill
   // LDS carve-up (bytes from the start of dynamic shared memory)
   uint32_t lds_cells_off;    // 0xFFFFFFFF: cells stay in HBM
   uint32_t lds_scat_off;

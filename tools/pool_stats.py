@@ -10,15 +10,17 @@ from radiative3d_amd.parallel import DeviceResult
 from radiative3d_amd.configs import CONFIGS
 name, deg, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 m = Model(CONFIGS[name](deg) + ["--device-tables"]); e = Engine(m)
-L = _ffi.hip_lib(); out = (C.c_ulonglong * 24)()
+L = _ffi.hip_lib(); out = (C.c_ulonglong * 40)()
 buf = DeviceResult(m, "cuda:0")
 e.run_device(n, 0, 0x5EED, *buf.pointers(), carry="carry"); torch.cuda.synchronize(); L.r3d_debug_pool_stats(out)
 e.run_device(n, n, 0x5EED, *buf.pointers(), carry="carry"); torch.cuda.synchronize(); ms = e.last_kernel_ms(); L.r3d_debug_pool_stats(out)
 e.run_device(0, 0, 0x5EED, *buf.pointers(), carry="final"); torch.cuda.synchronize()
-names = ["MOVE", "COLLECT", "RT", "BEND", "SCATTER", "FREE/refill"]
-tot = sum(out[16:22])
+names = ["MOVE", "COLLECT", "RT", "SCATTER", "FREE/refill"]
+tot = sum(out[16:21])
 print(f"{name} deg {deg} n {n}: chained launch {ms:.2f} ms (instrumented build); idle polls {out[6]}")
 for q, nm in enumerate(names):
     b, l, c = out[q], out[8 + q], out[16 + q]
+    if q == 0 and out[7]:
+        print(f"  move sub-iterations {out[7]} ({out[7] / max(1, b):.2f} per batch), lanes still live after one {out[15] / out[7]:.1f}")
     if b:
-        print(f"  {nm:12s} batches {b:9d}  lanes/batch {l / b:5.1f}  cycles/batch {c / b:8.0f}  share {100.0 * c / tot:5.1f} %")
+        print(f"  {nm:12s} batches {b:9d}  lanes/batch {l / b:5.1f}  cycles/batch {c / b:8.0f} (take {out[24 + q] / b:6.0f}, hand-off {out[32 + q] / b:6.0f})  share {100.0 * c / tot:5.1f} %")
