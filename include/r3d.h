@@ -111,6 +111,12 @@ typedef struct r3d_source {
   int32_t       pad_;
   double        whole_cdf[3];
   const double* cdf[3];      /* each n_toa long                             */
+  /* Build-on-device form.  With cdf[0] == NULL the engine evaluates the three
+   * radiation patterns itself, in HBM, from the moment tensor rotated into
+   * the local north-east-down frame at the source (what
+   * ShearDislocation::ShearDislocation does on the host, events.cpp:66-105);
+   * whole_cdf is then an output (r3d_engine_download_source).               */
+  double        moment[6];   /* xx, yy, zz, xy, xz, yz                       */
 } r3d_source;
 
 /* Seismometer (reference dataout.hpp:102-129, ctor dataout.cpp:42-71).     */
@@ -151,6 +157,12 @@ typedef struct r3d_model_desc {
   const double*          toa;        /* n_toa x (theta, phi)                 */
   r3d_source             source;
   r3d_params             params;
+  /* Build-on-device form of the take-off set.  With toa == NULL the engine
+   * generates it itself: the icosahedron-based tessellation of the sphere of
+   * degree toa_degree (reference S2::TesselSphere, geom_s2.cpp:60-292;
+   * n_toa must be 20 * 4^toa_degree), in the order of the host builder's.   */
+  int32_t                toa_degree;
+  int32_t                pad_;
 } r3d_model_desc;
 
 /* Invalid-phonon reason slots (reference dataout.hpp:229-237, bit order).  */
@@ -227,6 +239,13 @@ int r3d_engine_scatterer_stats(const r3d_engine* e, int s, double out[8]);
 /* Copy scatterer s's tables from HBM (n_toa doubles each; any pointer may be
  * NULL to skip): for parity tests of the build-on-device form.              */
 int r3d_engine_download_scatterer(r3d_engine* e, int s, double* cdf[4], double* spol);
+
+/* The source tables and the take-off set as the engine holds them (for parity
+ * tests of their build-on-device forms): cdf[k] n_toa doubles each, whole[3]
+ * the cumulative P / SH / SV totals, toa n_toa (theta, phi) pairs; any pointer
+ * may be NULL to skip.                                                       */
+int r3d_engine_download_source(r3d_engine* e, double* cdf[3], double whole[3]);
+int r3d_engine_download_toa(r3d_engine* e, double* toa);
 
 /* Sizes of the result block for this engine's model.                       */
 size_t r3d_energy_len(const r3d_engine* e);   /* doubles                    */

@@ -43,7 +43,7 @@ class Scatterer(C.Structure):
 
 class Source(C.Structure):
     _fields_ = [("loc", C.c_double * 3), ("cell", C.c_int32), ("pad_", C.c_int32),
-                ("whole_cdf", C.c_double * 3), ("cdf", _dp * 3)]
+                ("whole_cdf", C.c_double * 3), ("cdf", _dp * 3), ("moment", C.c_double * 6)]
 
 
 class Seismometer(C.Structure):
@@ -62,7 +62,8 @@ class ModelDesc(C.Structure):
     _fields_ = [("cell_kind", C.c_int32), ("n_cells", C.c_int32), ("cells", C.POINTER(Cell)),
                 ("n_scatterers", C.c_int32), ("n_seismometers", C.c_int32),
                 ("scatterers", C.POINTER(Scatterer)), ("seismometers", C.POINTER(Seismometer)),
-                ("n_toa", C.c_uint64), ("toa", _dp), ("source", Source), ("params", Params)]
+                ("n_toa", C.c_uint64), ("toa", _dp), ("source", Source), ("params", Params),
+                ("toa_degree", C.c_int32), ("pad_", C.c_int32)]
 
 
 class Result(C.Structure):
@@ -193,6 +194,10 @@ def hip_lib():
         L.r3d_engine_scatterer_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
         L.r3d_engine_download_scatterer.restype = C.c_int
         L.r3d_engine_download_scatterer.argtypes = [C.c_void_p, C.c_int, C.POINTER(_dp), _dp]
+        L.r3d_engine_download_source.restype = C.c_int
+        L.r3d_engine_download_source.argtypes = [C.c_void_p, C.POINTER(_dp), _dp]
+        L.r3d_engine_download_toa.restype = C.c_int
+        L.r3d_engine_download_toa.argtypes = [C.c_void_p, _dp]
         L.r3d_engine_set_event_log.restype = C.c_int
         L.r3d_engine_set_event_log.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
         L.r3d_event_log_count.restype = C.c_uint64

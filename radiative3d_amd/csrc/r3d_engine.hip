@@ -184,6 +184,9 @@ struct r3d_engine {
   std::vector<ScatStats> scat_stats;
   std::vector<ScatPtrs> scat_ptrs;   // device addresses of every scatterer's tables
   uint64_t n_toa = 0;
+  const double* d_toa = nullptr;     // the take-off set, (theta, phi) pairs
+  const double* d_src[3] = {nullptr, nullptr, nullptr};
+  double src_whole[3] = {0, 0, 0};
 
   DevBuf* keep(std::unique_ptr<DevBuf> b) {
     bufs.push_back(std::move(b));
@@ -279,7 +282,9 @@ bool check_model(const r3d_model_desc* m) {
   if (m->cell_kind < 0 || m->cell_kind > 2) return g_error = "unknown cell kind", false;
   if (m->n_cells <= 0 || !m->cells) return g_error = "model has no cells", false;
   if (m->n_scatterers <= 0 || !m->scatterers) return g_error = "model has no scatterers", false;
-  if (m->n_toa == 0 || !m->toa) return g_error = "model has no take-off angles", false;
+  if (m->n_toa == 0) return g_error = "model has no take-off angles", false;
+  if (!m->toa && (m->toa_degree < 0 || m->toa_degree > 12 || m->n_toa != ((uint64_t)20 << (2 * m->toa_degree))))
+    return g_error = "take-off set to be generated: n_toa must be 20 * 4^toa_degree, degree 0..12", false;
   if (m->params.n_bins == 0) return g_error = "zero time bins", false;
   // index widths of the device layout: guides and samplers hold take-off indices in 32 bits,
   // a catch's (seismometer, bin, type) travels as one 32-bit word
@@ -303,7 +308,7 @@ bool check_model(const r3d_model_desc* m) {
       if (m->scatterers[s].cdf[0] && (!m->scatterers[s].cdf[k] || !m->scatterers[s].spol))
         return g_error = "scatterer table missing", false;
   for (int k = 0; k < 3; k++)
-    if (!m->source.cdf[k]) return g_error = "source table missing", false;
+    if (m->source.cdf[0] && !m->source.cdf[k]) return g_error = "source table missing", false;
   return true;
 }
 
@@ -334,7 +339,7 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   e->n_bins = m->params.n_bins;
   KArgs& a = e->args;
   PackedModel pm;
-  pack_model(*m, pm);
+  pack_model(*m, pm, /*for_engine*/ true);
   a = pm.args;
   const size_t cell_bytes = pm.cell_bytes();
   hipError_t err = hipSuccess;
@@ -349,8 +354,21 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   }
   e->n_toa = m->n_toa;
   e->scat_stats.resize(m->n_scatterers);
-  const double* d_toa = nullptr;   // (theta, phi) pairs, only while tables are built here
-  std::unique_ptr<DevBuf> toa_buf;
+  // ---- the take-off set: uploaded, or generated here (r3d_tables_build.hip) ----
+  const double* d_toa = nullptr;   // (theta, phi) pairs
+  {
+    auto toa_buf = std::make_unique<DevBuf>();
+    if (m->toa) {
+      if (hipError_t r = toa_buf->upload(m->toa, m->n_toa * 2 * sizeof(double)); r != hipSuccess) err = r;
+    } else {
+      if (hipError_t r = toa_buf->alloc_zero(m->n_toa * 2 * sizeof(double)); r != hipSuccess) err = r;
+      if (err == hipSuccess)
+        err = build_toa_on_device(m->toa_degree, m->n_toa, reinterpret_cast<double*>(toa_buf->p), nullptr);
+    }
+    d_toa = reinterpret_cast<const double*>(toa_buf->p);
+    e->d_toa = d_toa;
+    e->keep(std::move(toa_buf));
+  }
   for (int s = 0; s < m->n_scatterers; s++) {
     const r3d_scatterer& S = m->scatterers[s];
     r3d_engine::ScatStats& st = e->scat_stats[s];
@@ -366,11 +384,6 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
       continue;
     }
     // build-on-device form (r3d_tables_build.hip)
-    if (!d_toa) {
-      toa_buf = std::make_unique<DevBuf>();
-      if (hipError_t r = toa_buf->upload(m->toa, m->n_toa * 2 * sizeof(double)); r != hipSuccess) err = r;
-      d_toa = reinterpret_cast<const double*>(toa_buf->p);
-    }
     double* d_cdf[4];
     for (int k = 0; k < 4; k++) {
       auto b = std::make_unique<DevBuf>();
@@ -417,15 +430,45 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
       for (int k = 0; k < 4; k++) pm.scat_head[s].whole[t][k] = (acc += wp[t][k]);
     }
   }
-  if (err == hipSuccess && d_toa) err = hipDeviceSynchronize();   // guides done before toa_buf goes
-  toa_buf.reset();
+  if (err == hipSuccess) err = hipDeviceSynchronize();
   e->scat_ptrs = pm.scat_ptrs;
   a.scat_head = upload_vec(e.get(), pm.scat_head, &err);
   a.scat_ptrs = upload_vec(e.get(), pm.scat_ptrs, &err);
-  a.toa_xyz = upload_vec(e.get(), pm.toa_xyz, &err);
-  for (int k = 0; k < 3; k++) {
-    a.src_cdf[k] = upload_doubles(e.get(), m->source.cdf[k], m->n_toa, &err);
-    a.src_guide[k] = upload_vec(e.get(), pm.src_guide[k], &err);
+  {   // unit vectors of the take-off directions: evaluated in HBM from the (theta, phi) pairs
+    auto b = std::make_unique<DevBuf>();
+    if (hipError_t r = b->alloc_zero(m->n_toa * 3 * sizeof(double)); r != hipSuccess) err = r;
+    if (err == hipSuccess)
+      err = build_toa_xyz_on_device(d_toa, m->n_toa, m->params.min_theta, m->params.max_theta,
+                                    reinterpret_cast<double*>(b->p), nullptr);
+    a.toa_xyz = reinterpret_cast<const double*>(e->keep(std::move(b))->p);
+  }
+  {   // the source's cumulative radiation patterns: copied in, or evaluated here; guides made here
+    double* d_src[3] = {nullptr, nullptr, nullptr};
+    for (int k = 0; k < 3; k++) {
+      auto b = std::make_unique<DevBuf>();
+      if (m->source.cdf[0]) {
+        if (hipError_t r = b->upload(m->source.cdf[k], m->n_toa * sizeof(double)); r != hipSuccess) err = r;
+      } else if (hipError_t r = b->alloc_zero(m->n_toa * sizeof(double)); r != hipSuccess) {
+        err = r;
+      }
+      d_src[k] = reinterpret_cast<double*>(e->keep(std::move(b))->p);
+      a.src_cdf[k] = d_src[k], e->d_src[k] = d_src[k];
+    }
+    if (!m->source.cdf[0] && err == hipSuccess) {
+      double tot[3];
+      err = build_source_tables(m->source.moment, d_toa, m->n_toa, d_src, tot, nullptr);
+      double acc = 0;
+      for (int k = 0; k < 3; k++) a.src_total[k] = tot[k], a.src_whole[k] = (acc += tot[k]);
+    }
+    for (int k = 0; k < 3; k++) e->src_whole[k] = a.src_whole[k];
+    for (int k = 0; k < 3 && err == hipSuccess; k++) {
+      auto g = std::make_unique<DevBuf>();
+      if (hipError_t r = g->alloc_zero(((size_t(1) << a.guide_bits) + 1) * sizeof(uint32_t)); r != hipSuccess) err = r;
+      uint32_t* d_guide = reinterpret_cast<uint32_t*>(e->keep(std::move(g))->p);
+      if (err == hipSuccess) err = build_guide_on_device(d_src[k], m->n_toa, a.guide_bits, d_guide, nullptr);
+      a.src_guide[k] = d_guide;
+    }
+    if (err == hipSuccess) err = hipDeviceSynchronize();
   }
   a.seis_scan = upload_vec(e.get(), pm.seis_scan, &err);
   a.seis_hit = upload_vec(e.get(), pm.seis_hit, &err);
@@ -702,6 +745,25 @@ int r3d_engine_download_scatterer(r3d_engine* e, int s, double* cdf[4], double* 
   for (int k = 0; k < 4; k++)
     if (cdf && cdf[k]) R3D_HIP_OK(hipMemcpy(cdf[k], e->scat_ptrs[s].cdf[k], bytes, hipMemcpyDeviceToHost));
   if (spol) R3D_HIP_OK(hipMemcpy(spol, e->scat_ptrs[s].spol, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int r3d_engine_download_source(r3d_engine* e, double* cdf[3], double whole[3]) {
+  const int fail_value = 1;
+  if (!e) return g_error = "null engine", 1;
+  R3D_ON_DEVICE(e->device);
+  for (int k = 0; k < 3; k++) {
+    if (cdf && cdf[k]) R3D_HIP_OK(hipMemcpy(cdf[k], e->d_src[k], e->n_toa * sizeof(double), hipMemcpyDeviceToHost));
+    if (whole) whole[k] = e->src_whole[k];
+  }
+  return 0;
+}
+
+int r3d_engine_download_toa(r3d_engine* e, double* toa) {
+  const int fail_value = 1;
+  if (!e || !toa) return g_error = "null argument", 1;
+  R3D_ON_DEVICE(e->device);
+  R3D_HIP_OK(hipMemcpy(toa, e->d_toa, e->n_toa * 2 * sizeof(double), hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -226,7 +226,10 @@ inline uint32_t pack_flags_classified(const r3d_model_desc& m, int ci) {
   return f;
 }
 
-inline void pack_model(const r3d_model_desc& m, PackedModel& pm) {
+// for_engine: the engine evaluates the unit vectors of the take-off set and the source's search
+// guides in HBM itself (and may be given neither the set nor the source tables: their
+// build-on-device forms), so those are left out here; the test-only host emulation packs everything.
+inline void pack_model(const r3d_model_desc& m, PackedModel& pm, bool for_engine = false) {
   KArgs& a = pm.args;
   std::memset(&a, 0, sizeof a);
   const r3d_params& par = m.params;
@@ -329,8 +332,8 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm) {
 
   // ---- take-off directions as unit vectors; theta nudged away from the poles
   //      as Phonon::nudge_if_singular does (phonons.hpp:335-344) ----
-  pm.toa_xyz.resize(m.n_toa * 3);
-  for (uint64_t k = 0; k < m.n_toa; k++) {
+  if (!for_engine) pm.toa_xyz.resize(m.n_toa * 3);
+  for (uint64_t k = 0; k < m.n_toa && !for_engine; k++) {
     double th = m.toa[2 * k], ph = m.toa[2 * k + 1];
     if (th < par.min_theta) th = par.min_theta;
     if (th > par.max_theta) th = par.max_theta;
@@ -347,9 +350,11 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm) {
   // ---- source ----
   for (int k = 0; k < 3; k++) {
     a.src_cdf[k] = m.source.cdf[k];
-    a.src_total[k] = m.source.cdf[k][m.n_toa - 1];
-    build_guide(m.source.cdf[k], m.n_toa, a.guide_bits, pm.src_guide[k]);
-    a.src_guide[k] = pm.src_guide[k].data();
+    a.src_total[k] = m.source.cdf[0] ? m.source.cdf[k][m.n_toa - 1] : 0.0;
+    if (!for_engine) {
+      build_guide(m.source.cdf[k], m.n_toa, a.guide_bits, pm.src_guide[k]);
+      a.src_guide[k] = pm.src_guide[k].data();
+    }
     a.src_whole[k] = m.source.whole_cdf[k];
     a.src_loc[k] = m.source.loc[k];
     a.earth_center[k] = par.earth_center[k];

@@ -248,6 +248,7 @@ __device__ unsigned long long g_pool_stats[5][8];   // rows 3 / 4: cycles in the
 #define R3D_POOL_MOVE_AGAIN 44
 #endif
 constexpr int kPoolMoves = R3D_POOL_MOVES;
+constexpr int kPoolMovesThin = 32;   // (bounded, so that a drained launch with carry-over still parks promptly)
 constexpr unsigned kMoveAgainLanes = R3D_POOL_MOVE_AGAIN;
 
 // LDS_CELLS / LDS_SCAT: the cell records / the scatterer heads are staged in LDS (models with a few
@@ -537,7 +538,12 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         }
         live = light;
         const unsigned n_live = (unsigned)__popcll(__ballot(live));
-        const bool last = (rep + 1 >= kPoolMoves) || (n_live < kMoveAgainLanes);
+        // a full batch goes on while most of its lanes can (the others' slots are wanted by the
+        // queues); a thin one -- the tail of a launch, where nobody waits for these lanes -- goes on
+        // while any can: the longest histories are what a drain waits for, and a move in registers
+        // costs a fraction of a round trip through the pool
+        const bool last = (k == 64u) ? (rep + 1 >= kPoolMoves) || (n_live < kMoveAgainLanes)
+                                     : (rep + 1 >= kPoolMovesThin) || (n_live == 0u);
 #ifdef R3D_PHASE_TIMING
         if (lane == 0) atomicAdd(&s_stats[0][7], 1ull), atomicAdd(&s_stats[1][7], (unsigned long long)(n_live));
 #endif

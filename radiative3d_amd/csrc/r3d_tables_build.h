@@ -17,6 +17,17 @@ hipError_t build_scatterer_tables(const double het[6], double psdf_numer, const 
                                   double* d_cdf[4], double* d_spol, double totals[4], double cos_sums[4],
                                   hipStream_t stream);
 
+// The take-off set of degree `degree` ((theta, phi) pairs, n = 20 * 4^degree) in the host
+// builder's order (asynchronous).
+hipError_t build_toa_on_device(int degree, uint64_t n, double* d_toa, hipStream_t stream);
+// Unit vectors of the take-off directions, theta clamped to [min_theta, max_theta] (asynchronous).
+hipError_t build_toa_xyz_on_device(const double* d_toa, uint64_t n, double min_theta, double max_theta,
+                                   double* d_xyz, hipStream_t stream);
+// Cumulative P / SH / SV radiation patterns of the moment tensor (xx, yy, zz, xy, xz, yz; local
+// north-east-down frame) over the take-off set; totals[c] = d_cdf[c][n-1].  Blocks until done.
+hipError_t build_source_tables(const double moment[6], const double* d_toa, uint64_t n, double* d_cdf[3],
+                               double totals[3], hipStream_t stream);
+
 // guide[j] = smallest k with total * j / 2^bits <= cdf[k], j = 0 .. 2^bits (asynchronous).
 hipError_t build_guide_on_device(const double* d_cdf, uint64_t n, uint32_t bits, uint32_t* d_guide,
                                  hipStream_t stream);

@@ -176,7 +176,131 @@ __global__ __launch_bounds__(kThreads) void guide_kernel(const double* __restric
   guide[j] = (uint32_t)lo;
 }
 
+// ---- take-off set -------------------------------------------------------------------------
+// The icosahedron-based tessellation of the unit sphere the host builder makes recursively
+// (host/model.cpp TesselSphereIco / split; reference S2::TesselSphere, geom_s2.cpp:60-292): 20
+// faces, each split `degree` times into four by the normalised edge mid-points, a leaf's
+// direction = the normalised sum of its corners, leaves in depth-first order.  Leaf k is
+// therefore reached by reading k in base 4 from the top: no recursion, one work-item per leaf.
+// (No fused multiply-adds here, so that the corner arithmetic matches the host's bit for bit;
+// theta and phi still differ from the host's in the last place where acos / atan2 do.)
+struct P3 {
+  double x, y, z;
+};
+__device__ __forceinline__ P3 unit_sum2(P3 a, P3 b) {
+#pragma clang fp contract(off)
+  const double sx = a.x + b.x, sy = a.y + b.y, sz = a.z + b.z;
+  const double m = sqrt(sx * sx + sy * sy + sz * sz);
+  return P3{sx / m, sy / m, sz / m};
+}
+__global__ __launch_bounds__(kThreads) void toa_kernel(int degree, uint64_t n, double* __restrict__ toa) {
+#pragma clang fp contract(off)
+  const uint64_t k = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (k >= n) return;
+  // twelve icosahedron vertices: cyclic permutations of (+-1, 0, +-g), normalised
+  const double g = (1. + sqrt(5.0)) / 2.0;
+  const double m1 = sqrt(1.0 + g * g);
+  const double u = 1.0 / m1, w = g / m1;
+  const P3 v[12] = {{u, 0, w},  {-u, 0, w}, {u, 0, -w}, {-u, 0, -w}, {w, -u, 0}, {w, u, 0},
+                    {-w, -u, 0}, {-w, u, 0}, {0, w, u},  {0, w, -u},  {0, -w, u}, {0, -w, -u}};
+  const int face[20][3] = {{0, 1, 10}, {0, 1, 8},  {2, 3, 11}, {2, 3, 9},  {4, 5, 0},  {4, 5, 2},  {7, 6, 1},
+                           {7, 6, 3},  {10, 11, 4}, {10, 11, 6}, {8, 9, 5},  {8, 9, 7},  {0, 10, 4}, {0, 8, 5},
+                           {1, 10, 6}, {1, 8, 7},  {2, 11, 4}, {2, 9, 5},  {3, 11, 6}, {3, 9, 7}};
+  const uint32_t f = (uint32_t)(k >> (2 * degree));
+  P3 a = v[face[f][0]], b = v[face[f][1]], c = v[face[f][2]];
+  for (int level = degree - 1; level >= 0; level--) {
+    const uint32_t d = (uint32_t)(k >> (2 * level)) & 3u;
+    const P3 ab = unit_sum2(a, b), bc = unit_sum2(b, c), ca = unit_sum2(c, a);
+    if (d == 0) b = ab, c = ca;
+    else if (d == 1) a = ab, c = bc;
+    else if (d == 2) a = ca, b = bc;
+    else a = bc, b = ca, c = ab;
+  }
+  const double sx = a.x + b.x + c.x, sy = a.y + b.y + c.y, sz = a.z + b.z + c.z;
+  const double m = sqrt(sx * sx + sy * sy + sz * sz);
+  toa[2 * k] = acos(sz / m);
+  toa[2 * k + 1] = atan2(sy / m, sx / m);
+}
+// Unit vectors of the take-off directions, theta nudged away from the poles as
+// Phonon::nudge_if_singular does (phonons.hpp:335-344; r3d_pack.h pack_model).
+__global__ __launch_bounds__(kThreads) void toa_xyz_kernel(const double* __restrict__ toa, uint64_t n, double min_theta,
+                                                           double max_theta, double* __restrict__ xyz) {
+#pragma clang fp contract(off)
+  const uint64_t k = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (k >= n) return;
+  double th = toa[2 * k];
+  const double ph = toa[2 * k + 1];
+  if (th < min_theta) th = min_theta;
+  if (th > max_theta) th = max_theta;
+  xyz[3 * k] = sin(th) * cos(ph);
+  xyz[3 * k + 1] = sin(th) * sin(ph);
+  xyz[3 * k + 2] = cos(th);
+}
+// ---- source radiation patterns --------------------------------------------------------------
+// P, SH and SV energy radiated into each take-off direction by a moment tensor given in the local
+// north-east-down frame (host/model.cpp BuildSource; reference ShearDislocation, events.cpp:66-105).
+struct Moment {
+  double xx, yy, zz, xy, xz, yz;
+};
+__global__ __launch_bounds__(kThreads) void source_kernel(Moment mt, const double* __restrict__ toa, uint64_t n,
+                                                          double* __restrict__ w0, double* __restrict__ w1,
+                                                          double* __restrict__ w2) {
+  const uint64_t k = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (k >= n) return;
+  const double th = toa[2 * k], az = toa[2 * k + 1];
+  const double st = sin(th), ct = cos(th), sa = sin(az), ca = cos(az);
+  const double horiz = mt.xx * ca * ca + mt.xy * sin(2 * az) + mt.yy * sa * sa - mt.zz;
+  const double vert = mt.xz * ca + mt.yz * sa;
+  const double p = st * st * horiz + 2 * st * ct * vert + mt.zz;
+  const double sh = st * (0.5 * sin(2 * az) * (mt.yy - mt.xx) + cos(2 * az) * mt.xy) + ct * (ca * mt.yz - sa * mt.xz);
+  const double sv = st * ct * horiz + (1.0 - 2 * st * st) * vert;
+  w0[k] = p * p, w1[k] = sh * sh, w2[k] = sv * sv;
+}
+
+// In-place cumulative sums of `count` arrays of n doubles (device pointers in host array d_arr).
+hipError_t scan_arrays(double* const* d_arr, int count, uint64_t n, hipStream_t stream) {
+  const uint32_t s_blocks = (uint32_t)((n + kScanBlock - 1) / kScanBlock);
+  double* d_sums = nullptr;
+  double** d_arrays = nullptr;
+  hipError_t err = hipMalloc(&d_sums, (size_t)s_blocks * count * sizeof(double));
+  if (err == hipSuccess) err = hipMalloc(&d_arrays, count * sizeof(double*));
+  if (err == hipSuccess) err = hipMemcpyAsync(d_arrays, d_arr, count * sizeof(double*), hipMemcpyHostToDevice, stream);
+  if (err == hipSuccess) {
+    scan_blocks<<<dim3(s_blocks, count), kThreads, 0, stream>>>(d_arrays, n, d_sums, s_blocks);
+    scan_block_sums<<<count, 64, 0, stream>>>(d_sums, s_blocks);
+    add_offsets<<<dim3(s_blocks, count), kThreads, 0, stream>>>(d_arrays, n, d_sums, s_blocks);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess) err = hipStreamSynchronize(stream);
+  (void)hipFree(d_sums), (void)hipFree(d_arrays);
+  return err;
+}
+
 }  // namespace
+
+hipError_t build_toa_on_device(int degree, uint64_t n, double* d_toa, hipStream_t stream) {
+  if (degree < 0 || degree > 12 || n != ((uint64_t)20 << (2 * degree))) return hipErrorInvalidValue;
+  toa_kernel<<<(uint32_t)((n + kThreads - 1) / kThreads), kThreads, 0, stream>>>(degree, n, d_toa);
+  return hipGetLastError();
+}
+
+hipError_t build_toa_xyz_on_device(const double* d_toa, uint64_t n, double min_theta, double max_theta,
+                                   double* d_xyz, hipStream_t stream) {
+  toa_xyz_kernel<<<(uint32_t)((n + kThreads - 1) / kThreads), kThreads, 0, stream>>>(d_toa, n, min_theta, max_theta, d_xyz);
+  return hipGetLastError();
+}
+
+hipError_t build_source_tables(const double moment[6], const double* d_toa, uint64_t n, double* d_cdf[3],
+                               double totals[3], hipStream_t stream) {
+  if (n == 0) return hipErrorInvalidValue;
+  const Moment mt{moment[0], moment[1], moment[2], moment[3], moment[4], moment[5]};
+  source_kernel<<<(uint32_t)((n + kThreads - 1) / kThreads), kThreads, 0, stream>>>(mt, d_toa, n, d_cdf[0], d_cdf[1], d_cdf[2]);
+  hipError_t err = hipGetLastError();
+  if (err == hipSuccess) err = scan_arrays(d_cdf, 3, n, stream);
+  for (int c = 0; c < 3 && err == hipSuccess; c++)
+    err = hipMemcpy(&totals[c], d_cdf[c] + (n - 1), sizeof(double), hipMemcpyDeviceToHost);
+  return err;
+}
 
 hipError_t build_scatterer_tables(const double het[6], double psdf_numer, const double* d_toa, uint64_t n,
                                   double* d_cdf[4], double* d_spol, double totals[4], double cos_sums[4],

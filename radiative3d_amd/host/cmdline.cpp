@@ -14,7 +14,7 @@ enum OptID {
   OPT_FLATTEN, OPT_EARTHRAD, OPT_EVENT_MT, OPT_EVENT_LOC, OPT_OVR_MFP, OPT_NODEFLECT,
   OPT_REPORTS, OPT_REPORT_FILE, OPT_OUTDIR, OPT_OCSRAW, OPT_SEISBINS, OPT_SEISBINSIZE,
   OPT_SEISARRAY, OPT_SEIS_P2P, OPT_SEIS_P2PW, OPTM_HELP, OPTM_DUMPGRID, OPTM_PARAMOUTFN,
-  OPTM_RTTEST, OPTM_EVENTTEST, OPTM_RUNSIM, OPTX_SEED, OPTX_GPUS, OPTX_DEVTABLES
+  OPTM_RTTEST, OPTM_EVENTTEST, OPTM_RUNSIM, OPTX_SEED, OPTX_GPUS, OPTX_DEVTABLES, OPTX_HOSTTABLES
 };
 
 const std::map<std::string, OptID>& option_table() {
@@ -43,7 +43,8 @@ const std::map<std::string, OptID>& option_table() {
       {"--mparams-outfile", OPTM_PARAMOUTFN},
       {"--rtcoef-test", OPTM_RTTEST}, {"--event-test", OPTM_EVENTTEST},
       {"--run-simulation", OPTM_RUNSIM}, {"--run-sim", OPTM_RUNSIM},
-      {"--seed", OPTX_SEED}, {"--gpus", OPTX_GPUS}, {"--device-tables", OPTX_DEVTABLES}};
+      {"--seed", OPTX_SEED}, {"--gpus", OPTX_GPUS}, {"--device-tables", OPTX_DEVTABLES},
+      {"--host-tables", OPTX_HOSTTABLES}};
   return t;
 }
 
@@ -259,6 +260,7 @@ void ParseCommandLine(const std::vector<std::string>& tokens, ModelParams& par,
       case OPTX_SEED: mission.Seed = (unsigned long)std::strtoull(o.text().c_str(), nullptr, 0); break;
       case OPTX_GPUS: mission.Gpus = (int)o.integer(); break;
       case OPTX_DEVTABLES: par.DeviceTables = true; break;
+      case OPTX_HOSTTABLES: par.HostTables = true, par.DeviceTables = false; break;
     }
   }
 }

@@ -56,8 +56,8 @@ void run_rtcoef_test(unsigned n_sini, double rho1, double a1, double b1, double 
       Iface f;
       f.normal = fnorm, f.has_neighbor = true;
       f.rhoR = rho1, f.vR[0] = a1, f.vR[1] = b1, f.rhoT = rho2, f.vT[0] = a2, f.vT[1] = b2;
-      double w[RT_NUM], sn[RT_NUM], cr[RT_NUM], det2;
-      rt_weights(f, sini, irt, w, sn, cr, det2);
+      double w[RT_NUM], det2;
+      rt_weights(f, sini, irt, w, det2);
       if (i == 0)
         std::cout << "##" << std::setw(width) << "Sine_in" << std::setw(width) << "Prob_R_P"
                   << std::setw(width) << "Prob_T_P" << std::setw(width) << "Prob_R_SV"
@@ -79,6 +79,7 @@ void run_event_test(const ModelParams& par) {
   p.GridSource = ModelParams::GRID_COMPILED;
   if (p.CompiledSelector == 0) p.CompiledSelector = 40, p.CompiledArgs.clear();
   std::ostringstream sink;
+  p.DeviceTables = false;   // (this mission prints the host builder's source tables)
   Model m(p, &sink);
   const r3d_source& s = m.Desc().source;
   const size_t n = m.Desc().n_toa;
@@ -171,9 +172,14 @@ int main(int argc, char* argv[]) {
   }
   if (mission.bHelpMsg) {
     std::cout << "\nOptions follow the Radiative3D manual (doc/MANUAL.md of the reference);\n"
-              << "additional: --seed=<n>  --gpus=<n>  --device-tables\n\n";
+              << "additional: --seed=<n>  --gpus=<n>  --host-tables (a simulation run builds the take-off\n"
+              << "set, source and scattering tables in HBM unless told otherwise)  --device-tables\n\n";
     return 0;
   }
+  // A simulation run makes its tables where it uses them (seconds of host work and GBs of upload
+  // at TOA degree 9 become milliseconds); the diagnostic missions, which print host tables and
+  // must work without a GPU, keep the host builder.
+  if (mission.bRunSim && !par.HostTables) par.DeviceTables = true;
   OutputModelParams(par, std::cout);
   if (mission.bOutputModParamsOctv) {
     std::string fn = mission.OutputDir.empty() ? mission.FNModParamsOctv

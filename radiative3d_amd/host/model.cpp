@@ -198,11 +198,15 @@ Model::Model(const ModelParams& par, std::ostream* logp) {
   if (par.OcsRaw) ECS.SetOCSMapping(EarthCoords::OUT_NOTRANSFORM);
 
   log << "@@ __DISCRETIZING_TOA__" << std::endl;
-  mTOA = S2::TesselSphereIco(par.TOA_Degree);
-  mTOAFlat.resize(mTOA.size() * 2);
-  for (size_t i = 0; i < mTOA.size(); i++)
-    mTOAFlat[2 * i] = mTOA[i].theta, mTOAFlat[2 * i + 1] = mTOA[i].phi;
-  log << "|\n|" << std::setw(8) << mTOA.size()
+  if (par.TOA_Degree < 0 || par.TOA_Degree > 12) throw Runtime("TOA degree out of range [0,12].");
+  mNumTOA = (size_t)20 << (2 * par.TOA_Degree);
+  if (!mDeviceTables) {   // (with --device-tables the engine generates the set itself, in HBM)
+    mTOA = S2::TesselSphereIco(par.TOA_Degree);
+    mTOAFlat.resize(mTOA.size() * 2);
+    for (size_t i = 0; i < mTOA.size(); i++)
+      mTOAFlat[2 * i] = mTOA[i].theta, mTOAFlat[2 * i + 1] = mTOA[i].phi;
+  }
+  log << "|\n|" << std::setw(8) << mNumTOA
       << "  Take-off angles initialized for event and scattering sources.\n"
       << "|          (TesselSphere of degree " << par.TOA_Degree << ".)\n|\n";
 
@@ -296,8 +300,9 @@ Model::Model(const ModelParams& par, std::ostream* logp) {
   mDesc.scatterers = mScatDesc.data();
   mDesc.n_seismometers = (int32_t)mSeis.size();
   mDesc.seismometers = mSeis.data();
-  mDesc.n_toa = mTOA.size();
-  mDesc.toa = mTOAFlat.data();
+  mDesc.n_toa = mNumTOA;
+  mDesc.toa = mDeviceTables ? nullptr : mTOAFlat.data();
+  mDesc.toa_degree = par.TOA_Degree;
 
   r3d_params& p = mDesc.params;
   p.ttl = par.PhononTTL;
@@ -323,7 +328,7 @@ int Model::ScattererFor(const ScatterParams& requested) {
   for (size_t i = 0; i < mScatParams.size(); i++)
     if (par.CompareRoughly(mScatParams[i]) <= 0) return (int)i;
 
-  const size_t n = mTOA.size();
+  const size_t n = mNumTOA;
   auto store = std::make_unique<ScatStore>();
   if (mDeviceTables) {   // the engine evaluates the tables in HBM; only the parameters travel
     const double nan = std::nan("");
@@ -580,6 +585,16 @@ void Model::BuildSource(const ModelParams& par) {
   mt.Transform(ECS.GetXYZToLocalNEDRotation(mEventLoc));
   const Real mxx = mt.xx(), myy = mt.yy(), mzz = mt.zz();
   const Real mxy = mt.xy(), mxz = mt.xz(), myz = mt.yz();
+  r3d_source& s = mDesc.source;
+  const double moment[6] = {mxx, myy, mzz, mxy, mxz, myz};
+  for (int k = 0; k < 6; k++) s.moment[k] = moment[k];
+  put3(s.loc, mEventLoc);
+  s.cell = FindCellContainingPoint(mEventLoc);
+  if (s.cell < 0) throw Runtime("Event source location is not inside any model cell.");
+  if (mDeviceTables) {   // the engine evaluates the patterns in HBM; only the moment tensor travels
+    for (int t = 0; t < 3; t++) s.whole_cdf[t] = std::nan(""), s.cdf[t] = nullptr;
+    return;
+  }
   const size_t n = mTOA.size();
   for (auto& v : mSrcCdf) v.resize(n);
   parallel_for(n, [&](size_t lo, size_t hi) {
@@ -596,10 +611,6 @@ void Model::BuildSource(const ModelParams& par) {
     }
   });
   for (auto& v : mSrcCdf) integrate(v);
-  r3d_source& s = mDesc.source;
-  put3(s.loc, mEventLoc);
-  s.cell = FindCellContainingPoint(mEventLoc);
-  if (s.cell < 0) throw Runtime("Event source location is not inside any model cell.");
   double acc = 0;
   for (int t = 0; t < 3; t++) {
     s.whole_cdf[t] = (acc += mSrcCdf[t].back());

@@ -60,6 +60,8 @@ class ModelParams {
   // --device-tables (not a reference option): leave the scattering tables to the engine,
   // which evaluates them in HBM (include/r3d.h r3d_scatterer, build-on-device form).
   bool DeviceTables = false;
+  // --host-tables: keep them on the host even where the device build is the default (./main runs)
+  bool HostTables = false;
 
   void AddSeismometerByWavelength(EarthCoords::Generic loc, axes_scheme_e ax, Real radius_wl);
   void AddSeismometerFixedRadius(EarthCoords::Generic loc, axes_scheme_e ax, Real radius);
@@ -123,6 +125,7 @@ class Model {
 
   Grid mGrid;
   long mNumPhonons = 0;
+  size_t mNumTOA = 0;   // 20 * 4^degree (the set itself is only built when the tables are made on the host)
   std::vector<S2::ThetaPhi> mTOA;
   std::vector<double> mTOAFlat;
   std::vector<r3d_cell> mCells;

@@ -304,6 +304,22 @@ class Engine:
             raise RuntimeError("download failed: " + self._lib.r3d_last_error().decode())
         return cdf, spol
 
+    def download_source(self):
+        """(cdf[3, n_toa], whole[3]): the source's cumulative P / SH / SV tables as the engine holds them."""
+        n = self.model.n_toa
+        cdf, whole = np.zeros((3, n)), np.zeros(3)
+        ptrs = (_ffi._dp * 3)(*[cdf[k].ctypes.data_as(_ffi._dp) for k in range(3)])
+        if self._lib.r3d_engine_download_source(self._e, ptrs, whole.ctypes.data_as(_ffi._dp)):
+            raise RuntimeError("download failed: " + self._lib.r3d_last_error().decode())
+        return cdf, whole
+
+    def download_toa(self):
+        """toa[n_toa, 2]: the take-off set (theta, phi) as the engine holds it."""
+        toa = np.zeros((self.model.n_toa, 2))
+        if self._lib.r3d_engine_download_toa(self._e, toa.ctypes.data_as(_ffi._dp)):
+            raise RuntimeError("download failed: " + self._lib.r3d_last_error().decode())
+        return toa
+
     # -- per-event report stream (the reference's --reports) -------------------
     def set_event_log(self, mask=_ffi.R3D_RPT_ALL, capacity=1 << 20):
         """Attach an HBM buffer of `capacity` r3d_event records for the tags in `mask`."""

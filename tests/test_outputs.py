@@ -105,7 +105,9 @@ def test_main_cli_missions_without_gpu(tmp_path):
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(MAIN), reason="./main not built")
 def test_main_cli_end_to_end_on_gpu(tmp_path):
-    args = [a for a in halfspace(4)] + ["--num-phonons=200K", "--seed=7", f"--output-dir={tmp_path}",
+    # (--host-tables: the comparison below is history by history against the oracle on host-built
+    #  tables; by default a ./main run builds its tables in HBM, equal to 1e-12, not to the bit)
+    args = [a for a in halfspace(4)] + ["--num-phonons=200K", "--seed=7", f"--output-dir={tmp_path}", "--host-tables",
                                         "--mparams-outfile=out_mparams.octv", "--reports=INV", "--dump-grid"]
     run = subprocess.run([MAIN] + args, capture_output=True, text=True, cwd=tmp_path)
     assert run.returncode == 0, run.stdout[-2000:]
@@ -129,7 +131,7 @@ def test_main_cli_end_to_end_on_gpu(tmp_path):
 def test_main_cli_report_file_on_gpu(tmp_path):
     """--reports / --report-file (reference main.cpp:223-263): the file holds one line per
     requested event, in the reference's line format, grouped by history."""
-    args = [a for a in halfspace(4)] + ["--num-phonons=500", "--seed=11", f"--output-dir={tmp_path}",
+    args = [a for a in halfspace(4)] + ["--num-phonons=500", "--seed=11", f"--output-dir={tmp_path}", "--host-tables",
                                         "--reports=GEN,LST,TMO", "--report-file=reports.dat"]
     run = subprocess.run([MAIN] + args, capture_output=True, text=True, cwd=tmp_path)
     assert run.returncode == 0, run.stdout[-2000:]
@@ -148,6 +150,23 @@ def test_main_cli_report_file_on_gpu(tmp_path):
         assert num.sub("#", a).split() == num.sub("#", b).split(), (a, b)
         va, vb = [float(x) for x in num.findall(a)], [float(x) for x in num.findall(b)]
         assert np.allclose(va, vb, rtol=1e-5, atol=1e-9), (a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(MAIN), reason="./main not built")
+def test_main_cli_builds_its_tables_on_the_device_by_default(tmp_path):
+    """A plain ./main run (no --host-tables): take-off set, source and scattering tables made in HBM;
+    same physics as the host-table run (statistically: the tables agree to 1e-12, not to the bit)."""
+    base = [a for a in halfspace(5)] + ["--num-phonons=400K", "--seed=5", f"--output-dir={tmp_path}"]
+    runs = {}
+    for tag, extra in (("device", []), ("host", ["--host-tables"])):
+        run = subprocess.run([MAIN] + base + extra, capture_output=True, text=True, cwd=tmp_path)
+        assert run.returncode == 0, run.stdout[-2000:]
+        runs[tag] = (int(re.search(r"Loss surfaces:\s+(\d+)", run.stdout).group(1)),
+                     int(re.search(r"Timeout:\s+(\d+)", run.stdout).group(1)), run.stdout)
+    assert sum(runs["device"][:2]) == sum(runs["host"][:2]) == 400000
+    assert runs["device"][0] == pytest.approx(runs["host"][0], rel=0.01)
+    assert "SCATTERER" in runs["device"][2].upper()          # (the dump shows the engine's mean free paths)
 
 
 @pytest.mark.gpu
