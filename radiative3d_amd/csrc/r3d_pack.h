@@ -44,11 +44,13 @@ inline double dot3(const double a[3], const double b[3]) {
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
 }
 
-// Uniform hash over the seismometers' gather spheres.  Cell edge ~ twice the
-// median outer radius, grown until the grid has at most ~2M cells.  Insertion
-// is conservative (bounding box of the sphere plus a rounding margin), so the
-// candidates of a cell are a superset of the seismometers that can catch a
-// phonon arriving anywhere inside it.
+// Uniform hash over the seismometers' gather spheres.  Cell edge ~ a quarter of the median
+// outer radius -- the tables live in HBM / L2, not in LDS, so the grid can be fine: an arrival then
+// finds little more than the receivers it really lies in (with an edge of twice the radius, as the
+// LDS-resident hash had it, the crust-pinch arrays gave ~20 candidates per arrival for 0.7
+// catches) -- grown until the grid has at most ~4M cells and ~8M entries.  Insertion is
+// conservative (bounding box of the sphere plus a rounding margin), so the candidates of a cell
+// are a superset of the seismometers that can catch a phonon arriving anywhere inside it.
 inline void build_seis_grid(const r3d_model_desc& m, SeisGrid& g, std::vector<uint32_t>& start,
                             std::vector<uint32_t>& items) {
   const int n = m.n_seismometers;
@@ -72,7 +74,8 @@ inline void build_seis_grid(const r3d_model_desc& m, SeisGrid& g, std::vector<ui
   }
   std::vector<double> sorted = rad;
   std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
-  double h = std::max(2.0 * sorted[n / 2], 1e-6);
+  double h = std::max(0.25 * sorted[n / 2], 1e-6);
+  if (const char* e = getenv("R3D_SEIS_GRID_FACTOR")) h = std::max(atof(e) * sorted[n / 2], 1e-6);   // developer tuning
   int d[3];
   auto dims_for = [&](double hh) {
     double cells = 1;
@@ -82,7 +85,15 @@ inline void build_seis_grid(const r3d_model_desc& m, SeisGrid& g, std::vector<ui
     }
     return cells;
   };
-  while (dims_for(h) > 2.0e6) h *= 1.5;
+  auto entries_for = [&](double hh) {   // cells each sphere's bounding box covers, summed
+    double e = 0;
+    for (int s = 0; s < n; s++) {
+      const double w = 2.0 * rad[s] / hh + 2.0;
+      e += w * w * w;
+    }
+    return e;
+  };
+  while (dims_for(h) > 4.0e6 || entries_for(h) > 8.0e6) h *= 1.25;
   for (int k = 0; k < 3; k++) g.origin[k] = lo[k], g.dim[k] = d[k], g.dim_f[k] = (double)d[k];
   g.inv_h = 1.0 / h;
   g.n_cells = d[0] * d[1] * d[2];

@@ -193,6 +193,11 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
   }
   st.iterations++;
   const Cell& c = T.cells[p.cell];
+  // The move's one uniform (for the free path, below) is drawn here: it depends on nothing, and
+  // its hundred integer instructions fill the wait for the cell record, which everything else
+  // in the move needs.
+  const double u_free = rng_draw(rng, rng_key(a.seed));
+  R3D_SCHED_FENCE();
 
   // --- where does the ray leave the cell? (phonons.cpp:590)
   Exit e;
@@ -218,7 +223,6 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
   //     (scatterers.cpp:297-307, phonons.cpp:601)
   // scatlen = -ln(u) mfp.  Since -ln(u) >= 1 - u, (1-u) mfp >= len already rules a scatter
   // out, and the logarithm is only taken for the lanes that pass this screen.
-  const double u_free = rng_draw(rng, rng_key(a.seed));
   const double mfp = T.scat_head[c.scat].mfp[p.type];
   double scatlen = pos_inf();
   if (!((1.0 - u_free) * mfp >= e.len)) scatlen = -log_lean(u_free) * mfp;
