@@ -542,12 +542,7 @@ R3D_HD void rt_ray(const Iface& f, double sini, int intype, int choice, double& 
   }
 }
 
-#if defined(__HIPCC__) && defined(R3D_NOINLINE_RT)
-__host__ __device__ __attribute__((noinline))
-#else
-R3D_HD
-#endif
-bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
+R3D_HD bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
   const V3 fnorm = f.normal;
   const V3 fpara = in_plane_unit_perp(fnorm, p.dir);
   const V3 fparash = cross(fnorm, fpara);
@@ -564,12 +559,7 @@ bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
   }
   double w[RT_NUM], det2;
   R3D_SCHED_FENCE();
-#ifdef R3D_STUB_RTW   // register-pressure experiment (compile-only)
-  for (int i = 0; i < RT_NUM; i++) w[i] = sini * (i + 1) * f.vR[i & 1];
-  det2 = f.rhoT + f.vT[0] + f.vT[1] + f.rhoR;
-#else
   rt_weights(f, sini, intype, w, det2);
-#endif
   R3D_SCHED_FENCE();
   const int defchoice = intype == 0 ? R_P : intype == 1 ? R_SH : R_SV;   // GetCoefs, rtcoef.cpp:76-97
   // Choose, rtcoef.cpp:436-475

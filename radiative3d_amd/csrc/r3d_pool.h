@@ -248,6 +248,10 @@ __device__ unsigned long long g_pool_stats[5][8];   // rows 3 / 4: cycles in the
 #define R3D_POOL_MOVE_AGAIN 44
 #endif
 constexpr int kPoolMoves = R3D_POOL_MOVES;
+#ifndef R3D_POOL_CHAIN
+#define R3D_POOL_CHAIN 0
+#endif
+constexpr bool kPoolChainThin = R3D_POOL_CHAIN != 0;   // see the scheduler loop: measured, no gain
 constexpr int kPoolMovesThin = 32;   // (bounded, so that a drained launch with carry-over still parks promptly)
 constexpr unsigned kMoveAgainLanes = R3D_POOL_MOVE_AGAIN;
 
@@ -418,48 +422,65 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   __syncthreads();
 #endif
 
+  // In the tail of a launch (the id counter has run out, the queues are short) a thin batch that has
+  // served one phase goes straight on to the next phase of the same slots instead of handing them
+  // to the queues and taking them back: the longest histories -- a reverberating phonon hops MOVE
+  // -> COLLECT -> RT thousands of times -- are what a drain waits for, and a hop through the queues
+  // costs as much as the phase itself.  chain_q >= 0: the next loop pass serves chain_act's slots.
+  int chain_q = -1;
+  unsigned chain_id = 0;
+  bool chain_act = false;
   for (;;) {
-    // ---- choose a queue: a full batch of a minor phase first (they all feed MOVE), then a
-    //      refill, then MOVE; with no full batch anywhere, the fullest queue ----
-    const uint32_t snap = lane < 8 ? lds_ld(&ctl.word[lane]) : 0u;
-    const uint32_t drained = (uint32_t)__builtin_amdgcn_readlane((int)snap, kDrainedWord);
-    if (drained && a.carry_out) break;   // no ids left: the pool is parked as it is for the next launch
-    uint32_t w[Q_NUM], c[Q_NUM];
-#pragma unroll
-    for (int q = 0; q < Q_NUM; q++) w[q] = (uint32_t)__builtin_amdgcn_readlane((int)snap, q), c[q] = w[q] & 0xFFFFu;
-    if (drained) {
-      if (c[Q_FREE] == S) break;   // every slot is free and nothing is left to hand out
-      c[Q_FREE] = 0u;              // (free slots are of no use any more)
-    }
-    int q = -1;
-    if (c[Q_RT] >= 64u) q = Q_RT;
-    else if (c[Q_COLLECT] >= 64u) q = Q_COLLECT;
-    else if (c[Q_SCATTER] >= 64u) q = Q_SCATTER;
-    else if (c[Q_FREE] >= 64u) q = Q_FREE;
-    else if (c[Q_MOVE] >= 64u) q = Q_MOVE;
-    else {
-      uint32_t best = 0u;
-#pragma unroll
-      for (int j = 0; j < Q_NUM; j++)
-        if (c[j] > best) best = c[j], q = j;
-    }
-    if (q < 0) {   // everything in flight is in other waves' hands
+    int q;
+    unsigned id, k;
+    bool act;
 #ifdef R3D_PHASE_TIMING
-      if (lane == 0) atomicAdd(&s_stats[0][6], 1ull);
+    unsigned long long t_pop = __builtin_readcyclecounter();
 #endif
-      __builtin_amdgcn_s_sleep(8);
-      continue;
-    }
-    uint32_t wq = 0;
+    if (chain_q >= 0) {
+      q = chain_q, id = chain_id, act = chain_act;
+      k = (unsigned)__popcll(__ballot(act));
+      chain_q = -1;
+    } else {
+      // ---- choose a queue: a full batch of a minor phase first (they all feed MOVE), then a
+      //      refill, then MOVE; with no full batch anywhere, the fullest queue ----
+      const uint32_t snap = lane < 8 ? lds_ld(&ctl.word[lane]) : 0u;
+      const uint32_t drained = (uint32_t)__builtin_amdgcn_readlane((int)snap, kDrainedWord);
+      if (drained && a.carry_out) break;   // no ids left: the pool is parked as it is for the next launch
+      uint32_t w[Q_NUM], c[Q_NUM];
 #pragma unroll
-    for (int j = 0; j < Q_NUM; j++) wq = (q == j) ? w[j] : wq;
-    unsigned id;
+      for (int j = 0; j < Q_NUM; j++) w[j] = (uint32_t)__builtin_amdgcn_readlane((int)snap, j), c[j] = w[j] & 0xFFFFu;
+      if (drained) {
+        if (c[Q_FREE] == S) break;   // every slot is free and nothing is left to hand out
+        c[Q_FREE] = 0u;              // (free slots are of no use any more)
+      }
+      q = -1;
+      if (c[Q_RT] >= 64u) q = Q_RT;
+      else if (c[Q_COLLECT] >= 64u) q = Q_COLLECT;
+      else if (c[Q_SCATTER] >= 64u) q = Q_SCATTER;
+      else if (c[Q_FREE] >= 64u) q = Q_FREE;
+      else if (c[Q_MOVE] >= 64u) q = Q_MOVE;
+      else {
+        uint32_t best = 0u;
+#pragma unroll
+        for (int j = 0; j < Q_NUM; j++)
+          if (c[j] > best) best = c[j], q = j;
+      }
+      if (q < 0) {   // everything in flight is in other waves' hands
 #ifdef R3D_PHASE_TIMING
-    const unsigned long long t_pop = __builtin_readcyclecounter();
+        if (lane == 0) atomicAdd(&s_stats[0][6], 1ull);
 #endif
-    const unsigned k = q_pop(ctl, ring(q), rmask, q, lane, wq, id);
-    if (k == 0) continue;   // another wave was quicker
-    const bool act = lane < k;
+        __builtin_amdgcn_s_sleep(8);
+        continue;
+      }
+      uint32_t wq = 0;
+#pragma unroll
+      for (int j = 0; j < Q_NUM; j++) wq = (q == j) ? w[j] : wq;
+      k = q_pop(ctl, ring(q), rmask, q, lane, wq, id);
+      if (k == 0) continue;   // another wave was quicker
+      act = lane < k;
+    }
+    const bool thin = k < 64u;
 #ifdef R3D_PHASE_TIMING
     const unsigned long long t_begin = __builtin_readcyclecounter();
 #endif
@@ -507,9 +528,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         ev.vel = 0.0, ev.face = -1, ev.flags = 0u;
         bool leaving = false;
         if (live) {
-#ifndef R3D_NO_MOVE
           fate = step_move<KIND>(a, T, p, rng, st, &reason, ev);
-#endif
           leaving = true;
           if (fate != FATE_ALIVE) {
             dest = Q_FREE;
@@ -542,8 +561,8 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         // queues); a thin one -- the tail of a launch, where nobody waits for these lanes -- goes on
         // while any can: the longest histories are what a drain waits for, and a move in registers
         // costs a fraction of a round trip through the pool
-        const bool last = (k == 64u) ? (rep + 1 >= kPoolMoves) || (n_live < kMoveAgainLanes)
-                                     : (rep + 1 >= kPoolMovesThin) || (n_live == 0u);
+        const bool last = !thin ? (rep + 1 >= kPoolMoves) || (n_live < kMoveAgainLanes)
+                                : (rep + 1 >= kPoolMovesThin) || (n_live == 0u);
 #ifdef R3D_PHASE_TIMING
         if (lane == 0) atomicAdd(&s_stats[0][7], 1ull), atomicAdd(&s_stats[1][7], (unsigned long long)(n_live));
 #endif
@@ -592,12 +611,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #endif
       report(act, 3, p, hid);   // COL: the incident state
       tally_n(kEv + R3D_EV_COLLECT, k);
-#ifndef R3D_NO_COLLECT
-      if (__any(k1 > k0))
-#else
-      if (false)
-#endif
-      {
+      if (__any(k1 > k0)) {
         const uint32_t hits = pool_collect_pairs<KIND, TRACE>(a, T, p, vel, k0, k1, LDS_SEIS ? lds_gitems : nullptr,
                                                               lane, catches, bc);
         tally_n(kEv + R3D_EV_CATCH, hits);
@@ -646,12 +660,8 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         hid = ((uint64_t)rng.id_hi << 32) | rng.id_lo;
         Pending ev;
         ev.vel = 0.0, ev.face = (int)((meta >> 1) & 7u) - 1, ev.flags = (meta >> 8) & 0xFFu;
-#ifndef R3D_NO_RT
         if (q == Q_RT) step_event<KIND, EV_RT>(a, T, p, rng, st, ev, (int)fu[FU_NBR * S + id]);
-#endif
-#ifndef R3D_NO_SCATTER
-        if (q != Q_RT) step_event<KIND, EV_SCATTER>(a, T, p, rng, st, ev);
-#endif
+        else step_event<KIND, EV_SCATTER>(a, T, p, rng, st, ev);
         double* d = fd + id;
         d[FD_DX * S] = p.dir.x, d[FD_DY * S] = p.dir.y, d[FD_DZ * S] = p.dir.z;
         d[FD_PC * S] = p.pc, d[FD_PS * S] = p.ps;
@@ -668,6 +678,18 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #ifdef R3D_PHASE_TIMING
     const unsigned long long t_push = __builtin_readcyclecounter();
 #endif
+    if (kPoolChainThin && thin && !a.carry_out && lds_ld(&ctl.word[kDrainedWord]) != 0u) {
+      // the launch is running out (no ids left, and no parking for a next launch): the slots that
+      // go on -- to one and the same phase -- stay with this wave.  (Not in the steady state: minor
+      // phases are served a little short of 64 all the time, and a wave that wandered off with
+      // those few lanes would run every following phase at their width.)
+      const unsigned long long on = __ballot(act && dest != Q_FREE);
+      if (on) {
+        const int next = __builtin_amdgcn_readlane(dest, __ffsll((long long)on) - 1);
+        chain_q = next, chain_id = id, chain_act = act && dest == next;
+        act = act && dest != next;   // the rest goes to the queues as usual
+      }
+    }
     q_push_all(ctl, rings, rcap, lane, act, dest, id);
 #ifdef R3D_PHASE_TIMING
     if (lane == 0) {
