@@ -487,14 +487,19 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
     // the pool: S slots of 124 B (field-major) plus the rings of 16-bit slot numbers.
     auto align16 = [](size_t x) { return (x + 15) & ~size_t(15); };
     const size_t kLds = 160 * 1024, kStatic = 1024;   // static: queue control words, tallies
-    const size_t scat_bytes = (size_t)m->n_scatterers * sizeof(ScatHead);
+    const size_t head_bytes = (size_t)m->n_scatterers * sizeof(ScatHead);
+    const size_t scat_bytes = head_bytes + (size_t)m->n_scatterers * sizeof(ScatPtrs);   // heads + table addresses
     const bool scat_fit = scat_bytes <= 24 * 1024;
     const bool cells_fit = scat_fit && cell_bytes + scat_bytes <= 24 * 1024;
     e->res = cells_fit ? RES_ALL : scat_fit ? RES_TABLES : RES_NONE;
     size_t off = 0;
     a.lds_cells_off = a.lds_scat_off = a.lds_seis_off = a.lds_hit_off = a.lds_grid_off = 0xFFFFFFFFu;
     if (cells_fit) a.lds_cells_off = (uint32_t)off, off = align16(off + cell_bytes);
-    if (scat_fit) a.lds_scat_off = (uint32_t)off, off = align16(off + scat_bytes);
+    a.lds_scatptr_off = 0xFFFFFFFFu;
+    if (scat_fit) {
+      a.lds_scat_off = (uint32_t)off, off = align16(off + head_bytes);
+      a.lds_scatptr_off = (uint32_t)off, off = align16(off + scat_bytes - head_bytes);
+    }
     uint32_t acc_bits = m->n_seismometers > 0 ? 8u : 0u;   // 256 accumulators = 13 KB ...
     if (const char* s = getenv("R3D_ACC_BITS")) acc_bits = (uint32_t)atoi(s);   // developer tuning
     if (acc_bits && acc_bits < 5) acc_bits = 0;

@@ -248,11 +248,11 @@ __device__ unsigned long long g_pool_stats[5][8];   // rows 3 / 4: cycles in the
 #define R3D_POOL_MOVE_AGAIN 44
 #endif
 constexpr int kPoolMoves = R3D_POOL_MOVES;
-#ifndef R3D_POOL_CHAIN
-#define R3D_POOL_CHAIN 0
+constexpr int kPoolMovesThin = 32;
+#ifndef R3D_POOL_SCATTER_PAIR
+#define R3D_POOL_SCATTER_PAIR 1
 #endif
-constexpr bool kPoolChainThin = R3D_POOL_CHAIN != 0;   // see the scheduler loop: measured, no gain
-constexpr int kPoolMovesThin = 32;   // (bounded, so that a drained launch with carry-over still parks promptly)
+constexpr bool kScatterPair = R3D_POOL_SCATTER_PAIR != 0;   // the scatter phase serves two batches at a time   // (bounded, so that a drained launch with carry-over still parks promptly)
 constexpr unsigned kMoveAgainLanes = R3D_POOL_MOVE_AGAIN;
 
 // LDS_CELLS / LDS_SCAT: the cell records / the scatterer heads are staged in LDS (models with a few
@@ -273,7 +273,10 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       for (size_t i = tid; i < bytes / 8; i += kPoolBlock) d[i] = s[i];
     };
     if (LDS_CELLS) copy_words(smem + a.lds_cells_off, a.cells, (size_t)a.n_cells * sizeof(Cell));
-    if (LDS_SCAT) copy_words(smem + a.lds_scat_off, a.scat_head, (size_t)a.n_scat * sizeof(ScatHead));
+    if (LDS_SCAT) {
+      copy_words(smem + a.lds_scat_off, a.scat_head, (size_t)a.n_scat * sizeof(ScatHead));
+      copy_words(smem + a.lds_scatptr_off, a.scat_ptrs, (size_t)a.n_scat * sizeof(ScatPtrs));
+    }
     if (LDS_SEIS) {
       copy_words(smem + a.lds_seis_off, a.seis_scan, (size_t)a.n_seis * sizeof(SeisScan));
       uint32_t* gs = reinterpret_cast<uint32_t*>(smem + a.lds_grid_off);
@@ -300,6 +303,9 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   Tables<KIND> T;
   T.cells = LDS_CELLS ? reinterpret_cast<const Cell*>(smem + a.lds_cells_off) : reinterpret_cast<const Cell*>(a.cells);
   T.scat_head = LDS_SCAT ? reinterpret_cast<const ScatHead*>(smem + a.lds_scat_off) : a.scat_head;
+  // (the table addresses too: a scatter then starts its guide fetch after an LDS read instead of a
+  //  round trip to L2 for the pointer)
+  T.scat_ptrs = LDS_SCAT ? reinterpret_cast<const ScatPtrs*>(smem + a.lds_scatptr_off) : a.scat_ptrs;
   T.seis_scan = LDS_SEIS ? reinterpret_cast<const SeisScan*>(smem + a.lds_seis_off) : a.seis_scan;
   T.seis_hit = a.seis_hit;   // fetched on a hit only: stays in HBM / L2
 
@@ -422,14 +428,6 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   __syncthreads();
 #endif
 
-  // In the tail of a launch (the id counter has run out, the queues are short) a thin batch that has
-  // served one phase goes straight on to the next phase of the same slots instead of handing them
-  // to the queues and taking them back: the longest histories -- a reverberating phonon hops MOVE
-  // -> COLLECT -> RT thousands of times -- are what a drain waits for, and a hop through the queues
-  // costs as much as the phase itself.  chain_q >= 0: the next loop pass serves chain_act's slots.
-  int chain_q = -1;
-  unsigned chain_id = 0;
-  bool chain_act = false;
   for (;;) {
     int q;
     unsigned id, k;
@@ -437,11 +435,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #ifdef R3D_PHASE_TIMING
     unsigned long long t_pop = __builtin_readcyclecounter();
 #endif
-    if (chain_q >= 0) {
-      q = chain_q, id = chain_id, act = chain_act;
-      k = (unsigned)__popcll(__ballot(act));
-      chain_q = -1;
-    } else {
+    {
       // ---- choose a queue: a full batch of a minor phase first (they all feed MOVE), then a
       //      refill, then MOVE; with no full batch anywhere, the fullest queue ----
       const uint32_t snap = lane < 8 ? lds_ld(&ctl.word[lane]) : 0u;
@@ -678,18 +672,6 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #ifdef R3D_PHASE_TIMING
     const unsigned long long t_push = __builtin_readcyclecounter();
 #endif
-    if (kPoolChainThin && thin && !a.carry_out && lds_ld(&ctl.word[kDrainedWord]) != 0u) {
-      // the launch is running out (no ids left, and no parking for a next launch): the slots that
-      // go on -- to one and the same phase -- stay with this wave.  (Not in the steady state: minor
-      // phases are served a little short of 64 all the time, and a wave that wandered off with
-      // those few lanes would run every following phase at their width.)
-      const unsigned long long on = __ballot(act && dest != Q_FREE);
-      if (on) {
-        const int next = __builtin_amdgcn_readlane(dest, __ffsll((long long)on) - 1);
-        chain_q = next, chain_id = id, chain_act = act && dest == next;
-        act = act && dest != next;   // the rest goes to the queues as usual
-      }
-    }
     q_push_all(ctl, rings, rcap, lane, act, dest, id);
 #ifdef R3D_PHASE_TIMING
     if (lane == 0) {

@@ -42,6 +42,7 @@ template <int KIND>
 struct Tables {
   const typename CellOf<KIND>::type* cells;
   const ScatHead* scat_head;
+  const ScatPtrs* scat_ptrs;   // where each scatterer's tables are (the pointers themselves: LDS or HBM)
   const SeisScan* seis_scan;
   const SeisHit* seis_hit;
 };
@@ -279,7 +280,7 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
       scatter_transform(p, v3(a.nodeflect_dir), 1.0, 0.0, p.type);
     } else {
       const ScatHead& sh = T.scat_head[c.scat];
-      const ScatPtrs* sp = a.scat_ptrs + c.scat;   // (indexed in place: a local copy would go to scratch)
+      const ScatPtrs* sp = T.scat_ptrs + c.scat;   // (indexed in place: a local copy would go to scratch)
       int conv = sample_small(sh.whole[p.type], 4, rng_draw(rng, rng_key(a.seed)));  // GPP GPS GSP GSS
 #ifdef R3D_ABLATE_SCATTER   // timing-only developer build: no table search
       uint64_t k = (uint64_t)(rng_draw(rng, rng_key(a.seed)) * (double)(a.n_toa - 1));

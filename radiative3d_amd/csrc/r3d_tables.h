@@ -160,6 +160,7 @@ struct KArgs {
   // LDS carve-up (bytes from the start of dynamic shared memory)
   uint32_t lds_cells_off;    // 0xFFFFFFFF: cells stay in HBM
   uint32_t lds_scat_off;
+  uint32_t lds_scatptr_off;  // ScatPtrs[n_scat] beside the heads
   uint32_t lds_seis_off;
   uint32_t lds_hit_off;
   uint32_t lds_grid_off;     // seismometer hash (start u32[n_cells+1], items u16[n_items]); 0xFFFFFFFF: in HBM

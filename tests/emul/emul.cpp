@@ -19,6 +19,7 @@ static void run_kind(const KArgs& a, uint64_t n, uint64_t first_id, uint64_t see
   Tables<KIND> T;
   T.cells = reinterpret_cast<const typename CellOf<KIND>::type*>(a.cells);
   T.scat_head = a.scat_head;
+  T.scat_ptrs = a.scat_ptrs;
   T.seis_scan = a.seis_scan;
   T.seis_hit = a.seis_hit;
   for (uint64_t i = 0; i < n; i++) {
