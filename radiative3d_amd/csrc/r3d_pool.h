@@ -248,11 +248,7 @@ __device__ unsigned long long g_pool_stats[5][8];   // rows 3 / 4: cycles in the
 #define R3D_POOL_MOVE_AGAIN 44
 #endif
 constexpr int kPoolMoves = R3D_POOL_MOVES;
-constexpr int kPoolMovesThin = 32;
-#ifndef R3D_POOL_SCATTER_PAIR
-#define R3D_POOL_SCATTER_PAIR 1
-#endif
-constexpr bool kScatterPair = R3D_POOL_SCATTER_PAIR != 0;   // the scatter phase serves two batches at a time   // (bounded, so that a drained launch with carry-over still parks promptly)
+constexpr int kPoolMovesThin = 32;   // (bounded, so that a drained launch with carry-over still parks promptly)
 constexpr unsigned kMoveAgainLanes = R3D_POOL_MOVE_AGAIN;
 
 // LDS_CELLS / LDS_SCAT: the cell records / the scatterer heads are staged in LDS (models with a few
