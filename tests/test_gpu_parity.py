@@ -418,3 +418,34 @@ def test_report_stream_over_a_carry_chain(engines):
     a, b = by_history(ev_o), by_history(ev_g)
     assert np.array_equal(a["id"], b["id"]) and np.array_equal(a["tag"], b["tag"])
     assert np.array_equal(a["moves"], b["moves"]) and np.allclose(a["time"], b["time"], rtol=1e-9, atol=1e-9)
+
+
+def test_small_pool_many_short_launches(models, monkeypatch):
+    """The pool kernel's queues under stress: the smallest pool the engine accepts (512 slots for
+    512 lanes, so the waves compete for every slot and the rings wrap constantly), no bin
+    accumulators, and a carry chain of many launches far smaller than the pool (most workgroups
+    find the id counter exhausted at once and park an almost empty pool) -- against the oracle
+    and against one self-contained run."""
+    monkeypatch.setenv("R3D_POOL_SLOTS", "512")
+    monkeypatch.setenv("R3D_ACC_BITS", "0")
+    for name, n in (("crustpinch", 20000), ("lopnor", 20000), ("sphere_deep", 2000)):
+        e = Engine(models(name))
+        check_against_oracle(e, n, first_id=3)
+        want = e.run(n, first_id=10**6, seed=21)
+        total, step = DeviceResult(e.model, "cuda:0"), DeviceResult(e.model, "cuda:0")
+        per = 777
+        first = 10**6
+        while first < 10**6 + n:
+            m = min(per, 10**6 + n - first)
+            step.zero_()
+            e.run_device(m, first, 21, *step.pointers(), carry="carry")
+            total.add_(step)
+            first += m
+        step.zero_()
+        e.run_device(0, 0, 21, *step.pointers(), carry="final")
+        torch.cuda.synchronize()
+        total.add_(step)
+        got = total.to_result()
+        assert (got.counts == want.counts).all() and got.events == want.events
+        assert np.allclose(got.energy, want.energy, rtol=1e-11, atol=1e-300)
+        e.close()
