@@ -530,10 +530,15 @@ R3D_HD void rt_weights(const Iface& f, double sini, int intype, double w[RT_NUM]
 // Sine and real cosine of outgoing ray `choice` (Snell: sine = outgoing velocity x the horizontal
 // slowness; the same expressions the weights were formed from).
 R3D_HD void rt_ray(const Iface& f, double sini, int intype, int choice, double& sn, double& cr) {
-  const double v_in = (intype == 0) ? f.vR[0] : f.vR[1];
-  const double v_out = (choice == R_P) ? f.vR[0] : (choice == T_P) ? f.vT[0] : (choice >= T_P) ? f.vT[1] : f.vR[1];
+  // (selected pairwise from scalars: a chain of selects over the arrays becomes a look-up table
+  //  in scratch memory)
+  const double a1 = f.vR[0], b1 = f.vR[1], a2 = f.vT[0], b2 = f.vT[1];
+  const bool out_p = (choice == R_P) | (choice == T_P), out_t = choice >= T_P;
+  const double v_in = (intype == 0) ? a1 : b1;
+  const double v_p = out_t ? a2 : a1, v_s = out_t ? b2 : b1;
+  const double v_out = out_p ? v_p : v_s;
   if (intype == 1) {   // (b2 / b1) sini as in rt_weights; the reflected SH ray keeps the incidence sine
-    sn = (choice == R_SH) ? sini : (f.vT[1] / f.vR[1]) * sini;
+    sn = (choice == R_SH) ? sini : (b2 / b1) * sini;
     cr = sqrt_real(1.0 - sn * sn).re;
   } else {
     const double pp = sini * (1.0 / v_in);
@@ -542,10 +547,19 @@ R3D_HD void rt_ray(const Iface& f, double sini, int intype, int choice, double& 
   }
 }
 
-R3D_HD bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
+// The solve in two halves, so that a caller short of registers can let go of everything but a
+// few words between them: rt_choose() draws the incident S polarisation type and the outcome
+// (all the random numbers, the weights, the chooser of rtcoef.cpp:436-475); rt_apply() turns the
+// chosen outcome into the new type, direction and polarisation from the SAME phonon and interface
+// (the interface basis and Snell's sine are simply formed again: same inputs, same arithmetic,
+// same values).
+struct RtChoice {
+  int choice;    // R_P .. T_SH, after the no-transmit fold
+  int intype;    // 0 P, 1 SH, 2 SV
+};
+R3D_HD RtChoice rt_choose(const Phonon& p, Iface f, Rng& rng, RngKey key) {
   const V3 fnorm = f.normal;
   const V3 fpara = in_plane_unit_perp(fnorm, p.dir);
-  const V3 fparash = cross(fnorm, fpara);
   const double sini = dot(fpara, p.dir);
   bool no_transmit = false;
   if (!f.has_neighbor) {  // free surface: vanishing medium on the far side
@@ -554,6 +568,7 @@ R3D_HD bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
   }
   int intype = 0;  // 0 P, 1 SH, 2 SV
   if (p.type == RAY_S) {  // ChooseSPolType, rtcoef.cpp:406-422
+    const V3 fparash = cross(fnorm, fpara);
     double sh = dot(direction_of_motion(p), fparash);
     intype = (rng_draw(rng, key) <= sh * sh) ? 1 : 2;
   }
@@ -575,11 +590,20 @@ R3D_HD bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
     if (ran <= cum[i]) choice = i;   // ends on the FIRST i with ran <= cum[i]
   if (total == 0 || (total - total) != 0 || !(det2 > 0) || (det2 - det2) != 0) choice = defchoice;
   if (no_transmit && choice >= T_P) choice -= 3;  // T_x -> R_x
+  return RtChoice{choice, intype};
+}
+// Returns true if the phonon crossed into the neighbour.
+R3D_HD bool rt_apply(Phonon& p, Iface f, RtChoice ch) {
+  const V3 fnorm = f.normal;
+  const V3 fpara = in_plane_unit_perp(fnorm, p.dir);
+  const V3 fparash = cross(fnorm, fpara);
+  const double sini = dot(fpara, p.dir);
+  if (!f.has_neighbor) f.rhoT = 0.0, f.vT[0] = f.vT[1] = 1e-12;
+  const int choice = ch.choice;
   const bool reflected = choice < T_P;
-  R3D_SCHED_FENCE();
   // GetChosenRayDirection, rtcoef.cpp:529-548
   double comp_para, comp_norm;
-  rt_ray(f, sini, intype, choice, comp_para, comp_norm);
+  rt_ray(f, sini, ch.intype, choice, comp_para, comp_norm);
   if (comp_para > 1.0) comp_para = 1.0;
   if (reflected) comp_norm = -comp_norm;
   V3 out = comp_para * fpara + comp_norm * fnorm;
@@ -594,6 +618,10 @@ R3D_HD bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
   }
   p.dir = nd;
   return !reflected;
+}
+R3D_HD bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
+  const RtChoice ch = rt_choose(p, f, rng, key);
+  return rt_apply(p, f, ch);
 }
 
 // Snell bending without mode conversion across a weak velocity step

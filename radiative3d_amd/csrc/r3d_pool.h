@@ -40,9 +40,15 @@
 namespace r3d {
 
 #ifndef R3D_POOL_BLOCK
-#define R3D_POOL_BLOCK 512
+#define R3D_POOL_BLOCK 768
 #endif
-constexpr int kPoolBlock = R3D_POOL_BLOCK;   // 8 waves = 2 per SIMD: 256 registers per lane, no spills
+// 12 waves = 3 per SIMD, i.e. a budget of 168 registers per lane.  The kernel is bound by how
+// fast one wave can issue (memory round trips, dependent fp64 chains), so a third wave per SIMD is
+// worth 10-14 % -- once every phase fits the budget: the R/T solve in two halves with nothing but
+// the choice carried across, event counters that live for one batch (10 spilled registers left, in
+// rarely taken paths).  Measured at 512 / 768 threads: NSCP 15.8 / 12.8 ms, LopNor 13.9 / 11.0,
+// SphereEarth 40.8 / 33.0 per 3e6 histories.
+constexpr int kPoolBlock = R3D_POOL_BLOCK;
 constexpr int kPoolWaves = kPoolBlock / 64;
 
 enum { Q_MOVE = 0, Q_COLLECT = 1, Q_RT = 2, Q_SCATTER = 3, Q_FREE = 4, Q_NUM = 5 };
@@ -341,13 +347,24 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   __syncthreads();
 
   constexpr int kEv = 3 + R3D_INV_NUM;
-  // Tallies: the per-lane event counters of r3d_step.h (LaneStats) and the fates run on in
-  // registers for the whole launch and are added up once at the end; wave-uniform counts are
-  // added to the block's LDS tallies by lane 0.
-  LaneStats st = {0, 0, 0, 0, 0, 0, 0};
-  uint32_t n_lost = 0, n_timeout = 0, n_invalid = 0;
+  // Tallies: the per-lane event counters of r3d_step.h (LaneStats) live for one batch and are
+  // then summed over the wave (one packed butterfly) into the block's LDS tallies; fates and
+  // wave-uniform counts go there by ballot / directly.  (Counters that ran on in registers for the
+  // whole launch were ten registers that every phase had to carry -- or spill -- around its peak.)
   auto tally_n = [&](int slot, unsigned long long n) {
     if (lane == 0 && n) atomicAdd(&s_tally[slot], n);
+  };
+  auto tally = [&](bool cond, int slot) { tally_n(slot, (unsigned long long)__popcll(__ballot(cond))); };
+  auto tally_stats = [&](const LaneStats& st) {   // iterations, transfers, reflections (each <= 32 per lane and batch)
+    unsigned long long v = (unsigned long long)st.iterations | ((unsigned long long)st.transfer << 16) |
+                           ((unsigned long long)st.reflect << 32);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) {
+      if (v & 0xFFFFull) atomicAdd(&s_tally[kEv + R3D_EV_ITERATIONS], v & 0xFFFFull);
+      if ((v >> 16) & 0xFFFFull) atomicAdd(&s_tally[kEv + R3D_EV_TRANSFER], (v >> 16) & 0xFFFFull);
+      if ((v >> 32) & 0xFFFFull) atomicAdd(&s_tally[kEv + R3D_EV_REFLECT], (v >> 32) & 0xFFFFull);
+    }
   };
   // Report stream (diagnostic kernel only; include/r3d.h r3d_event): the lanes for which `cond`
   // holds append one record each; the wave claims the slots with one atomic.
@@ -372,15 +389,15 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   };
   // A history ended (lanes with `died`): loss counters, report line, final record.
   auto finish = [&](bool died, int fate, int reason, const Phonon& p, uint64_t hid, uint32_t catches) {
-    n_lost += (died && fate == FATE_LOST) ? 1u : 0u;
-    n_timeout += (died && fate == FATE_TIMEOUT) ? 1u : 0u;
+    if (!__any(died)) return;
+    tally(died && fate == FATE_LOST, 0);
+    tally(died && fate == FATE_TIMEOUT, 1);
     if (__any(died && fate == FATE_INVALID)) {   // rare
-      n_invalid += (died && fate == FATE_INVALID) ? 1u : 0u;
+      tally(died && fate == FATE_INVALID, 2);
 #pragma unroll
-      for (int r = 0; r < R3D_INV_NUM; r++)
-        tally_n(3 + r, (unsigned long long)__popcll(__ballot(died && fate == FATE_INVALID && reason == r)));
+      for (int r = 0; r < R3D_INV_NUM; r++) tally(died && fate == FATE_INVALID && reason == r, 3 + r);
     }
-    if (TRACE && __any(died)) {
+    if (TRACE) {
       report(died && fate == FATE_LOST, 5, p, hid);
       report(died && fate == FATE_TIMEOUT, 6, p, hid);
       report(died && fate == FATE_INVALID, 7, p, hid);
@@ -475,6 +492,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
     const unsigned long long t_begin = __builtin_readcyclecounter();
 #endif
     int dest = Q_FREE;   // where each active lane's slot goes after this phase
+    LaneStats st = {0, 0, 0, 0, 0, 0, 0};
 
     if (q == Q_FREE) {
       // ---- fresh histories: ids from the global counter, source spray (events.cpp:111-124) ----
@@ -650,8 +668,26 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         hid = ((uint64_t)rng.id_hi << 32) | rng.id_lo;
         Pending ev;
         ev.vel = 0.0, ev.face = (int)((meta >> 1) & 7u) - 1, ev.flags = (meta >> 8) & 0xFFu;
-        if (q == Q_RT) step_event<KIND, EV_RT>(a, T, p, rng, st, ev, (int)fu[FU_NBR * S + id]);
-        else step_event<KIND, EV_SCATTER>(a, T, p, rng, st, ev);
+        if (q == Q_RT) {
+#ifdef R3D_ABLATE_RT
+          step_event<KIND, EV_RT>(a, T, p, rng, st, ev, (int)fu[FU_NBR * S + id]);
+#else
+          // the solve in two halves with nothing but the choice, the draw counter and the slot
+          // number carried across (everything else is read again from the slot and the tables):
+          // what is live while the weights are formed decides whether three waves fit a SIMD
+          const int nbr = (int)fu[FU_NBR * S + id];
+          const RtChoice ch = rt_event_choose<KIND>(a, T, p, rng, st, ev, nbr);
+          const uint32_t draws = rng.k;
+          asm volatile("" ::: "memory");   // (the second half must not reuse the first half's loads)
+          load_state(id, p, rng, meta);
+          rng.k = draws;
+          Pending ev2;
+          ev2.vel = 0.0, ev2.face = (int)((meta >> 1) & 7u) - 1, ev2.flags = (meta >> 8) & 0xFFu;
+          rt_event_apply<KIND>(a, T, p, st, ev2, (int)fu[FU_NBR * S + id], ch);
+#endif
+        } else {
+          step_event<KIND, EV_SCATTER>(a, T, p, rng, st, ev);
+        }
         double* d = fd + id;
         d[FD_DX * S] = p.dir.x, d[FD_DY * S] = p.dir.y, d[FD_DZ * S] = p.dir.z;
         d[FD_PC * S] = p.pc, d[FD_PS * S] = p.ps;
@@ -665,6 +701,9 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         report(st.transfer != tr0, 4, p, hid);      // CEL
       }
     }
+    if (q == Q_SCATTER) tally_n(kEv + R3D_EV_SCATTER, k);
+    else if (q != Q_FREE) tally_stats(st);
+    if (q == Q_RT) tally_n(kEv + R3D_EV_RTSOLVE, k);
 #ifdef R3D_PHASE_TIMING
     const unsigned long long t_push = __builtin_readcyclecounter();
 #endif
@@ -687,17 +726,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(fd);
     for (size_t i = tid; i < image_words; i += kPoolBlock) img[i] = src[i];
   }
-  // ---- the lanes' running tallies, then the block's bin accumulators and tallies to HBM ----
-  {
-    auto add = [&](int slot, uint32_t v) {
-      if (v) atomicAdd(&s_tally[slot], (unsigned long long)v);
-    };
-    add(0, n_lost), add(1, n_timeout), add(2, n_invalid);
-    add(kEv + R3D_EV_ITERATIONS, st.iterations), add(kEv + R3D_EV_SCATTER, st.scatter);
-    add(kEv + R3D_EV_REFLECT, st.reflect), add(kEv + R3D_EV_TRANSFER, st.transfer);
-    add(kEv + R3D_EV_RTSOLVE, st.rtsolve);
-  }
-  __syncthreads();
+  // ---- the block's bin accumulators and tallies to HBM ----
   if (bc.on) {
     for (uint32_t i = tid; i <= bc.mask; i += kPoolBlock) {
       const uint32_t bin = bc.key[i];

@@ -364,6 +364,46 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
   return FATE_ALIVE;
 }
 
+// The reflection / transmission event in two calls (see rt_choose / rt_apply in r3d_physics.h):
+// a caller short of registers -- the pool kernel at three waves per SIMD -- draws the outcome, lets
+// go of everything but the two words of the choice, reloads the phonon and applies it.  Together
+// they are step_event<KIND, EV_RT>.
+template <int KIND>
+R3D_HD Iface rt_interface(const KArgs& a, const Tables<KIND>& T, const Phonon& p, const Pending& ev, int nbr) {
+  using Cell = typename CellOf<KIND>::type;
+  const Cell& c = T.cells[p.cell];
+  const bool adjoin = (ev.flags & F_ADJOIN) != 0;
+  Iface f;
+  f.normal = cell_face_normal(c, ev.face, p.loc);
+  f.vR[0] = cell_velocity(c, p.loc, 0), f.vR[1] = cell_velocity(c, p.loc, 1);
+  f.rhoR = cell_density(a, c, p.cell, p.loc);
+  f.has_neighbor = adjoin;
+  f.vT[0] = f.vT[1] = f.rhoT = 0;
+  if (adjoin) {
+    const Cell& o = T.cells[nbr];
+    f.vT[0] = cell_velocity(o, p.loc, 0), f.vT[1] = cell_velocity(o, p.loc, 1);
+    f.rhoT = cell_density(a, o, nbr, p.loc);
+  }
+  return f;
+}
+template <int KIND>
+R3D_HD RtChoice rt_event_choose(const KArgs& a, const Tables<KIND>& T, const Phonon& p, Rng& rng, LaneStats& st,
+                                const Pending& ev, int nbr) {
+  st.rtsolve++;
+  return rt_choose(p, rt_interface<KIND>(a, T, p, ev, nbr), rng, rng_key(a.seed));
+}
+template <int KIND>
+R3D_HD void rt_event_apply(const KArgs& a, const Tables<KIND>& T, Phonon& p, LaneStats& st, const Pending& ev,
+                           int nbr, RtChoice ch) {
+  const bool crossed = rt_apply(p, rt_interface<KIND>(a, T, p, ev, nbr), ch);
+  if (crossed) {
+    p.cell = nbr, st.transfer++;
+  } else {
+    st.reflect++;
+    volume_count(a, p);   // REF
+  }
+}
+
 // The whole iteration for one work-item on its own (host emulation).
 template <int KIND>
 R3D_HD int step(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng, LaneStats& st,
