@@ -2,7 +2,7 @@
 // around the traversal kernel of r3d_pool.h.
 //
 // Kernel design in one paragraph (details: r3d_pool.h): persistent grid, one
-// 512-thread workgroup per CU; the histories in flight live in LDS (a pool of ~1000 slots per
+// 768-thread workgroup per CU; the histories in flight live in LDS (a pool of ~1000 slots per
 // workgroup) and sit in one of five queues -- MOVE, COLLECT, RT, SCATTER, FREE; a wave takes 64
 // slots of ONE queue and runs that phase for all of them at once, so every phase executes at
 // (nearly) full width instead of under the partial masks of a one-phonon-per-lane loop; small
@@ -517,8 +517,9 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
       }
     }
     if (const char* s = getenv("R3D_POOL_SLOTS")) {   // developer tuning (never more than fits)
-      const uint32_t want = (uint32_t)atoi(s) / 64 * 64;
-      if (want >= 64 && want < slots) {
+      uint32_t want = (uint32_t)atoi(s) / 64 * 64;   // at least a slot per lane of the workgroup
+      if (want < (uint32_t)kPoolBlock) want = (uint32_t)kPoolBlock;
+      if (want < slots) {
         slots = want, cap = 64;
         while (cap < slots) cap <<= 1;
       }

@@ -421,12 +421,12 @@ def test_report_stream_over_a_carry_chain(engines):
 
 
 def test_small_pool_many_short_launches(models, monkeypatch):
-    """The pool kernel's queues under stress: the smallest pool the engine accepts (512 slots for
-    512 lanes, so the waves compete for every slot and the rings wrap constantly), no bin
+    """The pool kernel's queues under stress: the smallest pool the engine accepts (a slot per lane of
+    the workgroup, so the waves compete for every slot and the rings wrap constantly), no bin
     accumulators, and a carry chain of many launches far smaller than the pool (most workgroups
     find the id counter exhausted at once and park an almost empty pool) -- against the oracle
     and against one self-contained run."""
-    monkeypatch.setenv("R3D_POOL_SLOTS", "512")
+    monkeypatch.setenv("R3D_POOL_SLOTS", "64")      # clamped up to the workgroup size
     monkeypatch.setenv("R3D_ACC_BITS", "0")
     for name, n in (("crustpinch", 20000), ("lopnor", 20000), ("sphere_deep", 2000)):
         e = Engine(models(name))
