@@ -68,12 +68,46 @@ R3D_HD double fsqrt(double x) {
 #endif
 }
 
+// 1 / x for finite, non-zero x of moderate size (no scaling, no special cases: 0 and inf give NaN):
+// v_rcp_f64 plus two Newton steps, 5 instructions against the ~13 of an IEEE division; result within
+// an ulp or two.  Only where the operand is known to be a plain number (a velocity, a radius, a
+// denominator near 1); quotients whose zero / infinite cases mean something keep the division.
+R3D_HD double frcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(x);
+  y = __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+  y = __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+  return y;
+#else
+  return 1.0 / x;
+#endif
+}
+// True if the condition holds in every active lane of the wave (on the host: in this one).  For
+// choosing a shorter series when ALL lanes qualify -- a per-lane branch would run both.
+R3D_HD bool all_lanes(bool c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __all(c) != 0;
+#else
+  return c;
+#endif
+}
+
 // arcsin for |x| <= 0.5: x + x t P(t) / Q(t), t = x^2 -- the classical rational
 // approximation (fdlibm e_asin.c, error below one ulp on this interval).  Used where a small
 // angle is known by its sine and the sign of its cosine (the arc length of a tetra leg):
 // a third of the instructions of the general atan2.
 R3D_HD double asin_small(double x) {
   const double t = x * x;
+  if (all_lanes(t <= 0.00390625)) {   // |x| <= 1/16 (a leg of a fraction of a degree, the usual case in a
+    // tetrahedral grid): the Maclaurin series through x^13 (next term 0.014 x^14: 4e-19 x)
+    double s = 231.0 / 13312.0;
+    s = __builtin_fma(s, t, 63.0 / 2816.0);
+    s = __builtin_fma(s, t, 35.0 / 1152.0);
+    s = __builtin_fma(s, t, 5.0 / 112.0);
+    s = __builtin_fma(s, t, 3.0 / 40.0);
+    s = __builtin_fma(s, t, 1.0 / 6.0);
+    return __builtin_fma(x * t, s, x);
+  }
   const double p = t * (1.66666666666666657415e-01 + t * (-3.25565818622400915405e-01 + t * (2.01212532134862925881e-01 +
                    t * (-4.00555345006794114027e-02 + t * (7.91534994289814532176e-04 + t * 3.47933107596021167570e-05)))));
   const double q = 1.0 + t * (-2.40339491173441421878e+00 + t * (2.02094576023350569471e+00 +
@@ -152,6 +186,15 @@ R3D_HD double log_lean(double x) {
 // y^25 / 25, below 1e-18 relative to y on this interval).
 R3D_HD double atanh_small(double y) {
   const double t = y * y;
+  if (all_lanes(t <= 0.00390625)) {   // |y| <= 1/16 in every lane: through y^13 (next term y^15 / 15: 1e-18 y)
+    double q = 1.0 / 13.0;
+    q = __builtin_fma(q, t, 1.0 / 11.0);
+    q = __builtin_fma(q, t, 1.0 / 9.0);
+    q = __builtin_fma(q, t, 1.0 / 7.0);
+    q = __builtin_fma(q, t, 1.0 / 5.0);
+    q = __builtin_fma(q, t, 1.0 / 3.0);
+    return __builtin_fma(y * t, q, y);
+  }
   double p = 1.0 / 23.0;
   p = __builtin_fma(p, t, 1.0 / 21.0);
   p = __builtin_fma(p, t, 1.0 / 19.0);
@@ -221,9 +264,9 @@ R3D_HD V3 unit(V3 a) {
   return s * a;
 }
 R3D_HD V3 unit_else(V3 a, V3 fallback) {  // reference geom_r3.hpp:127-132
-  double m = mag(a);
-  if (m == 0) return fallback;
-  return (1.0 / m) * a;
+  const double m2 = mag2(a);
+  if (m2 == 0) return fallback;
+  return frsqrt(m2) * a;
 }
 
 // The reference stores a direction as theta = acos(z), phi = atan2(y, x) and
@@ -242,8 +285,8 @@ R3D_HD V3 through_angles(V3 v) {
 // geom_r3.cpp:222-224).
 R3D_HD void sph_basis(V3 d, V3& th_hat, V3& ph_hat) {
   double h2 = d.x * d.x + d.y * d.y;
-  double st = fsqrt(h2);
   double ih = (h2 != 0) ? frsqrt(h2) : 0.0;
+  double st = h2 * ih;     // sqrt(h2)
   double cp = (h2 != 0) ? d.x * ih : 1.0, sp = d.y * ih;
   th_hat = v3(d.z * cp, d.z * sp, -st);
   ph_hat = v3(-sp, cp, 0.0);
@@ -258,7 +301,7 @@ R3D_HD V3 in_plane_unit_perp(V3 self, V3 other) {
     if (is_zero(mp)) mp = cross(self, v3(0, 1, 0));
   }
   mp = unit(mp);
-  return unit(cross(mp, self));
+  return cross(mp, self);   // (mp is unit and normal to the unit `self`: unit already)
 }
 
 // ---- complex numbers (the reference's Complex = std::complex<Real>,

@@ -135,16 +135,21 @@ R3D_HD TetArc tet_arc(const CellTet& c, const Phonon& p) {
   const int t = p.type;
   V3 g = v3(c.g[t]);
   double vel = dot(p.loc, g) + c.v0[t];
+  // w2 = g x dir, w1 = w2 x g (the part of dir normal to g, times |g|^2): |w1| = |w2| |g|, so with
+  // iw = 1 / |w2| everything follows from ONE reciprocal square root and no division:
+  //   v1 = w1 / (|w2| |g|),   t.v1 = |w2| / |g|,   R = v / (|g| t.v1) = v / |w2|   (media.hpp:568-569)
   V3 w2 = cross(g, p.dir), w1 = cross(w2, g);
-  A.v1 = unit(w1), A.v3 = c.inv_gmag[t] * g;
-  double txp = dot(p.dir, A.v1), tzp = dot(p.dir, A.v3);
-  A.R = (vel * c.inv_gmag[t]) / txp;     // = 1 / ((t.v1 / v) |g|), media.hpp:568-569
+  const double m2 = mag2(w2);
+  const double iw = frsqrt(m2);
+  A.v1 = (iw * c.inv_gmag[t]) * w1, A.v3 = c.inv_gmag[t] * g;
+  const double txp = (m2 * iw) * c.inv_gmag[t], tzp = dot(p.dir, A.v3);
+  A.R = vel * iw;
   // In the rotated frame the phonon sits at R (-tz', 0, tx') from the centre
-  // (media.hpp:574-580), i.e. centre = loc + R tz' v1 - R tx' v3.
-  const double px = -A.R * tzp, pz = A.R * txp;
-  A.center = p.loc + ((-px) * A.v1 + (-pz) * A.v3);
-  double h = frsqrt(px * px + pz * pz);
-  A.s0 = px * h, A.c0 = pz * h;
+  // (media.hpp:574-580), i.e. centre = loc + R tz' v1 - R tx' v3; the direction is a unit vector in
+  // the (v1, v3) plane, so (-tz', tx') ARE the sine and cosine of its angle on the circle (the
+  // velocity, hence R, is positive).
+  A.center = p.loc + ((A.R * tzp) * A.v1 + (-A.R * txp) * A.v3);
+  A.s0 = -tzp, A.c0 = txp;
   return A;
 }
 // One plane against the arc circle, in sine space (reference
@@ -209,7 +214,7 @@ struct TetExit {
   int face;
 };
 R3D_HD TetExit tet_exit(const CellTet& c, const TetArc& A) {
-  const double inv_R = 1.0 / A.R;
+  const double inv_R = frcp(A.R);
   Gcad rv[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) rv[i] = tet_face_arc(c.n[i], c.d[i], A, inv_R);
@@ -244,7 +249,7 @@ R3D_HD void tet_advance(const CellTet& c, const TetArc& A, Phonon& p, double len
   // time = (ln|tan(a1/2+pi/4)| - ln|tan(a0/2+pi/4)|) / |g|,  ln|tan(a/2+pi/4)| = atanh(sin a), and
   // atanh(s1) - atanh(s0) = atanh(y), y = (s1 - s0) / (1 - s0 s1): a leg spans a few degrees, so y
   // is small and the series does (one division, no logarithm)
-  const double y = (s1 - A.s0) / (1.0 - A.s0 * s1);
+  const double y = (s1 - A.s0) * frcp(1.0 - A.s0 * s1);
   double time = c.inv_gmag[t] * ((fabs(y) <= 0.2) ? atanh_small(y) : 0.5 * log_lean((1.0 + y) / (1.0 - y)));
   p.path += len, p.t += time, p.recent += time;
   p.loc = nl;
@@ -282,7 +287,7 @@ R3D_HD double sph_linear_exit(double radius, V3 loc, V3 dir) {
 struct SphArc {
   double radius, rad2;
   V3 center, u1, u3;
-  double S2, TwoSQ, CotZetaBy2, timeCoef;
+  double S2, inv_TwoSQ, CotZetaBy2, timeCoef;   // (1 / TwoSQ of raypath.hpp: it only ever divides)
   double s0, c0;   // sine / cosine of the current location's angle from the arc bottom
   bool straight;   // a == 0: straight rays
 };
@@ -294,7 +299,7 @@ R3D_HD SphArc sph_arc(const CellSph& c, const double ec[3], const Phonon& p) {
   const int t = p.type;
   A.straight = (c.a[t] == 0);
   if (A.straight) {
-    A.radius = pos_inf(), A.rad2 = pos_inf(), A.S2 = 0, A.TwoSQ = 0, A.CotZetaBy2 = 0;
+    A.radius = pos_inf(), A.rad2 = pos_inf(), A.S2 = 0, A.inv_TwoSQ = 0, A.CotZetaBy2 = 0;
     A.timeCoef = 0, A.s0 = 0, A.c0 = 1, A.center = v3(0, 0, 0), A.u1 = p.dir, A.u3 = v3(0, 0, 0);
     return A;
   }
@@ -305,10 +310,12 @@ R3D_HD SphArc sph_arc(const CellSph& c, const double ec[3], const Phonon& p) {
   if (sini > 1.0) sini = 1.0;
   double cosi = dot(w3, p.dir);
   double r2 = mag2(p.loc);
-  const double G = sini * fsqrt(r2) / (c.c[t] + c.a[t] * r2);
+  // (the quotients below whose operands are plain positive numbers use frcp; the one whose zero
+  //  divisor means "vertical ray, infinite radius" stays a division)
+  const double G = sini * fsqrt(r2) * frcp(c.c[t] + c.a[t] * r2);
   const double TwoGA = 2. * G * c.a[t];
   const double urad = 1. - (2. * TwoGA * G * c.c[t]);
-  double bottom = (urad > 1) ? (1. - fsqrt(urad)) / TwoGA : 0;
+  double bottom = (urad > 1) ? (1. - fsqrt(urad)) * frcp(TwoGA) : 0;
   A.radius = (c.zero_rad2[t] / bottom - bottom) / 2.0;
   A.rad2 = A.radius * A.radius;
   A.center = p.loc + ((A.radius * cosi) * w1 + (-A.radius * sini) * w3);
@@ -321,11 +328,11 @@ R3D_HD SphArc sph_arc(const CellSph& c, const double ec[3], const Phonon& p) {
   }
   A.S2 = mag2(A.center);
   double S = fsqrt(A.S2);
-  A.TwoSQ = 2 * S * A.radius;
-  double cz = (A.S2 + A.radius * A.radius - c.zero_rad2[t]) / A.TwoSQ;
-  double sz = fsqrt(1 - cz * cz);
-  A.CotZetaBy2 = (1 + cz) / sz;
-  A.timeCoef = -1 / (c.a[t] * S * sz);
+  A.inv_TwoSQ = frcp(2 * S * A.radius);
+  double cz = (A.S2 + A.radius * A.radius - c.zero_rad2[t]) * A.inv_TwoSQ;
+  double isz = frsqrt(1 - cz * cz);     // 1 / sin zeta
+  A.CotZetaBy2 = (1 + cz) * isz;
+  A.timeCoef = -isz * frcp(c.a[t] * S);
   V3 cl = p.loc - A.center;
   const double y = dot(A.u1, cl), x = dot(A.u3, cl);   // the reference's a0 = atan2(y, x)
   const double h2 = x * x + y * y;
@@ -371,8 +378,8 @@ R3D_HD SphExit sph_exit(const CellSph& c, const SphArc& A, const Phonon& p) {
     return e;
   }
   const double base = A.S2 + A.rad2;
-  const double cq_t = (base - c.radius[0] * c.radius[0]) / A.TwoSQ;
-  const double cq_b = (base - c.radius[1] * c.radius[1]) / A.TwoSQ;
+  const double cq_t = (base - c.radius[0] * c.radius[0]) * A.inv_TwoSQ;
+  const double cq_b = (base - c.radius[1] * c.radius[1]) * A.inv_TwoSQ;
   const bool bottom_reach = !(cq_b > 1.0) && (A.s0 < 0);
   if (cq_t > 1.0) {          // top at -inf: taken, squashed to a zero-length leg
     e.face = 0, e.len = 0;
@@ -415,11 +422,14 @@ R3D_HD void sph_advance(const CellSph& c, const SphArc& A, Phonon& p, double len
     V3 nd = c1 * A.u1 + (-s1) * A.u3;
     // time = timeCoef (atanh(x1) - atanh(x0)), x = CotZetaBy2 tan(a/2), tan(a/2) = sin a / (1 + cos a);
     // atanh(x1) - atanh(x0) = atanh((x1 - x0) / (1 - x0 x1))
-    const double x0 = A.CotZetaBy2 * (A.s0 / (1.0 + A.c0));
-    const double x1 = A.CotZetaBy2 * (s1 / (1.0 + c1));
-    const double y = (x1 - x0) / (1.0 - x0 * x1);
+    // with tan(a/2) = s / (1 + c) put over the common denominator:
+    //   y = K (s1 (1 + c0) - s0 (1 + c1)) / ((1 + c0)(1 + c1) - K^2 s0 s1),  K = CotZetaBy2 -- one quotient
+    const double h0 = 1.0 + A.c0, h1 = 1.0 + c1;
+    const double y = (A.CotZetaBy2 * (s1 * h0 - A.s0 * h1)) * frcp(h0 * h1 - (A.CotZetaBy2 * A.CotZetaBy2) * (A.s0 * s1));
     time = att_time = A.timeCoef * ((fabs(y) <= 0.2) ? atanh_small(y) : 0.5 * log_lean((1.0 + y) / (1.0 - y)));
-    p.dir = through_angles(unit(nd));
+    // (nd = c1 u1 - s1 u3 with u1, u3 orthonormal is unit to rounding; the reference's
+    //  renormalisation + (theta, phi) round trip changes it by ~1e-16 and is skipped, as in tet_advance)
+    p.dir = nd;
   }
   p.path += len, p.t += time, p.recent += time;
   p.amp *= exp_lean(c.att[t] * att_time);
@@ -608,7 +618,10 @@ R3D_HD bool rt_apply(Phonon& p, Iface f, RtChoice ch) {
   if (reflected) comp_norm = -comp_norm;
   V3 out = comp_para * fpara + comp_norm * fnorm;
   p.type = (choice == R_P || choice == T_P) ? RAY_P : RAY_S;
-  V3 nd = through_angles(unit(out));  // mDir.Set(outdir.Theta(), outdir.Phi())
+  // (the reference sets mDir from outdir.Theta(), outdir.Phi(): `out` is a unit vector to rounding --
+  //  orthonormal fpara, fnorm with sine and cosine as coefficients -- and the round trip through the
+  //  angles, a change of ~1e-16, is skipped as in the advance functions)
+  const V3 nd = out;
   if (p.type == RAY_S) {  // GetChosenParticleDOM, rtcoef.cpp:559-588
     V3 dopm;
     if (choice == T_SH || choice == R_SH) dopm = fparash;
@@ -640,7 +653,7 @@ R3D_HD bool bend(Phonon& p, V3 fnorm, double veli, double velo) {
     transfer = true, coso = fsqrt(1.0 - sino * sino);
   }
   V3 out = sino * fpara + coso * fnorm;
-  const V3 nd = through_angles(unit(out));   // outdir.ThetaHat()/PhiHat() go through Theta()/Phi()
+  const V3 nd = out;   // (unit to rounding; see rt_apply)
   if (p.type != RAY_P) {
     V3 pdomi = direction_of_motion(p);
     V3 svi = cross(fparash, p.dir), svo = cross(fparash, out);
@@ -729,7 +742,7 @@ R3D_HD void scatter_transform(Phonon& p, V3 rel, double rc, double rs, int new_t
   const V3 bs1 = rc * b1 + rs * b2;              // S1 axis of the deflection frame
   V3 nd = rel.x * s1 + rel.y * s2 + rel.z * e3;  // AA.Express(BB.E3)
   V3 ns1 = bs1.x * s1 + bs1.y * s2 + bs1.z * e3;
-  nd = through_angles(nd);                       // theta = acos(z), phi = atan2(y, x)
+  // (nd is unit to rounding -- unit rel in an orthonormal frame; no round trip through theta, phi)
   set_pol(p, ns1, nd);
   p.dir = nd;
   p.type = new_type;

@@ -237,7 +237,7 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
     double s1 = texit.s, c1 = texit.c;   // a boundary leg ends at the exit point itself
     if (scatters || !(e.len > -pos_inf())) {
       double sd, cd;                      // scatter leg: rotate the start angle by len / R
-      rotation(len / tarc.R, &sd, &cd);
+      rotation(len * frcp(tarc.R), &sd, &cd);
       s1 = tarc.s0 * cd + tarc.c0 * sd, c1 = tarc.c0 * cd - tarc.s0 * sd;
     }
     tet_advance(c, tarc, p, len, s1, c1);
