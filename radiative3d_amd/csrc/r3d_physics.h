@@ -30,7 +30,10 @@ enum { CELL_CYL = 0, CELL_TET = 1, CELL_SPH = 2 };
 enum { FATE_ALIVE = 0, FATE_LOST = 1, FATE_TIMEOUT = 2, FATE_INVALID = 3 };
 
 struct Phonon {            // reference phonons.hpp:69-126
-  double t, path, recent, amp;
+  double t, path, recent;
+  double lamp;             // ln(amplitude): the attenuation exponents -pi f t / Q of the legs, summed -- the
+                           // reference multiplies the amplitude by exp() of each (phonons.cpp:62-70); the
+                           // exponential is taken where the amplitude is used (a catch, a report line)
   V3 loc, dir;
   double pc, ps;           // cos, sin of the polarisation angle mPol (the angle itself is never needed)
   int32_t type, cell;
@@ -41,6 +44,9 @@ struct Exit {              // where the current ray leaves the current cell
   double len;
   int face;
 };
+
+R3D_HD double amplitude(const Phonon& p) { return exp_lean(p.lamp); }
+R3D_HD double amplitude2(const Phonon& p) { return exp_lean(2.0 * p.lamp); }   // its square: the energy weight
 
 R3D_HD uint32_t face_flags(uint32_t packed, int f) { return (packed >> (8 * f)) & 0xFFu; }
 
@@ -73,7 +79,7 @@ R3D_HD double plane_exit(const double n[3], double d, V3 loc, V3 dir) {
   double d_fact = n[0] * dir.x + n[1] * dir.y + n[2] * dir.z;
   if (d_fact < 0) return pos_inf();
   if (d_fact == 0) return d_sh < 0 ? -pos_inf() : pos_inf();
-  return d_sh / d_fact;
+  return d_sh * frcp(d_fact);   // (0 < d_fact <= 1)
 }
 R3D_HD double cylwall_exit(double rad2, V3 loc, V3 dir) {
   // reference CylinderFace::LinearRayDistToExit, media_cellface.cpp:531-562
@@ -83,7 +89,7 @@ R3D_HD double cylwall_exit(double rad2, V3 loc, V3 dir) {
   double B = 2 * (loc.x * dir.x + loc.y * dir.y);
   double urad = B * B - 4 * A * C;
   if (urad < 0) return -pos_inf();
-  return (fsqrt(urad) - B) / (2 * A);
+  return (fsqrt(urad) - B) * frcp(2 * A);   // (A > 0)
 }
 // reference RCUCylinder::GetPathToBoundary, media.cpp:236-330.  Face ids:
 // 0 top, 1 bottom, 2 lateral wall (phonon is lost there).
@@ -102,10 +108,10 @@ R3D_HD Exit cyl_exit(const CellCyl& c, double wall_rad2, const Phonon& p) {
 // reference RCUCylinder::AdvanceLength + Phonon::Move, media.cpp:208-222,
 // phonons.cpp:62-70
 R3D_HD void cyl_advance(const CellCyl& c, Phonon& p, double len) {
-  double time = len / c.v[p.type];
+  double time = len * frcp(c.v[p.type]);
   p.path += len, p.t += time, p.recent += time;
   p.loc = p.loc + len * p.dir;
-  p.amp *= exp_lean(c.att[p.type] * time);
+  p.lamp += c.att[p.type] * time;
   p.moves += 1;
 }
 
@@ -257,7 +263,7 @@ R3D_HD void tet_advance(const CellTet& c, const TetArc& A, Phonon& p, double len
   //  renormalisation + (theta, phi) round trip changes it by ~1e-16 and is skipped --
   //  the next leg rebuilds v1 from scratch, so nothing accumulates)
   p.dir = nd;
-  p.amp *= exp_lean(c.att[t] * time);
+  p.lamp += c.att[t] * time;
   p.moves += 1;
 }
 
@@ -432,7 +438,7 @@ R3D_HD void sph_advance(const CellSph& c, const SphArc& A, Phonon& p, double len
     p.dir = nd;
   }
   p.path += len, p.t += time, p.recent += time;
-  p.amp *= exp_lean(c.att[t] * att_time);
+  p.lamp += c.att[t] * att_time;
   p.moves += 1;
 }
 

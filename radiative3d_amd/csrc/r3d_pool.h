@@ -64,7 +64,7 @@ typedef __attribute__((address_space(3))) uint16_t lds_u16;
 // reads and writes each field without bank conflicts (slot-major 128-byte records measured 77 % of
 // the LDS cycles as conflicts).  meta: bit 0 ray type | bits 1-3 pending face + 1 (0: none) |
 // bits 8-15 that face's flags | bits 16-18 the queue the slot is in (for carry-over).
-enum { FD_T, FD_PATH, FD_RECENT, FD_AMP, FD_LX, FD_LY, FD_LZ, FD_DX, FD_DY, FD_DZ, FD_PC, FD_PS, FD_NUM };
+enum { FD_T, FD_PATH, FD_RECENT, FD_LAMP, FD_LX, FD_LY, FD_LZ, FD_DX, FD_DY, FD_DZ, FD_PC, FD_PS, FD_NUM };
 enum { FU_CELL, FU_MOVES, FU_K, FU_META, FU_IDLO, FU_IDHI, FU_CATCH, FU_NBR, FU_NUM };   // NBR: the cell behind the pending face
 constexpr size_t kSlotBytes = FD_NUM * sizeof(double) + FU_NUM * sizeof(uint32_t);   // 128
 
@@ -173,7 +173,7 @@ __device__ __forceinline__ uint32_t pool_collect_pairs(const KArgs& a, const Tab
     sph_basis(p.dir, th, ph);
     dopm = p.pc * th + p.ps * ph;
   }
-  const double amp2 = p.amp * p.amp;
+  const double amp2 = amplitude2(p);
   const double inv_vel = 1.0 / vel_lane;
   uint32_t n_hits = 0;
   for (uint32_t base = 0; base < total; base += 64u) {
@@ -380,7 +380,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
     if (cond && at < a.evlog_cap) {
       r3d_event* r = reinterpret_cast<r3d_event*>(a.evlog) + at;
       r->id = hid;
-      r->time = q.t, r->path = q.path, r->amp = q.amp;
+      r->time = q.t, r->path = q.path, r->amp = amplitude(q);
       r->loc[0] = q.loc.x, r->loc[1] = q.loc.y, r->loc[2] = q.loc.z;
       r->dir[0] = q.dir.x, r->dir[1] = q.dir.y, r->dir[2] = q.dir.z;
       r->cell = (uint32_t)q.cell, r->moves = q.moves;
@@ -403,7 +403,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       report(died && fate == FATE_INVALID, 7, p, hid);
       if (died && a.finals) {   // (the diagnostic kernel also runs for the report stream alone)
         r3d_final* f = reinterpret_cast<r3d_final*>(a.finals) + (hid - a.first_id);
-        f->time = p.t, f->path = p.path, f->amp = p.amp;
+        f->time = p.t, f->path = p.path, f->amp = amplitude(p);
         f->loc[0] = p.loc.x, f->loc[1] = p.loc.y, f->loc[2] = p.loc.z;
         f->dir[0] = p.dir.x, f->dir[1] = p.dir.y, f->dir[2] = p.dir.z;
         f->moves = p.moves;
@@ -416,7 +416,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   auto load_state = [&](unsigned id, Phonon& p, Rng& rng, uint32_t& meta) {
     const double* d = fd + id;
     const uint32_t* u = fu + id;
-    p.t = d[FD_T * S], p.path = d[FD_PATH * S], p.recent = d[FD_RECENT * S], p.amp = d[FD_AMP * S];
+    p.t = d[FD_T * S], p.path = d[FD_PATH * S], p.recent = d[FD_RECENT * S], p.lamp = d[FD_LAMP * S];
     p.loc = v3(d[FD_LX * S], d[FD_LY * S], d[FD_LZ * S]);
     p.dir = v3(d[FD_DX * S], d[FD_DY * S], d[FD_DZ * S]);
     p.pc = d[FD_PC * S], p.ps = d[FD_PS * S];
@@ -429,7 +429,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   auto store_state = [&](unsigned id, const Phonon& p, const Rng& rng, uint32_t meta) {
     double* d = fd + id;
     uint32_t* u = fu + id;
-    d[FD_T * S] = p.t, d[FD_PATH * S] = p.path, d[FD_RECENT * S] = p.recent, d[FD_AMP * S] = p.amp;
+    d[FD_T * S] = p.t, d[FD_PATH * S] = p.path, d[FD_RECENT * S] = p.recent, d[FD_LAMP * S] = p.lamp;
     d[FD_LX * S] = p.loc.x, d[FD_LY * S] = p.loc.y, d[FD_LZ * S] = p.loc.z;
     d[FD_DX * S] = p.dir.x, d[FD_DY * S] = p.dir.y, d[FD_DZ * S] = p.dir.z;
     d[FD_PC * S] = p.pc, d[FD_PS * S] = p.ps;

@@ -85,7 +85,7 @@ R3D_HD void spray(const KArgs& a, Phonon& p, Rng& rng) {
   uint64_t k = sample_cdf_guided(cdf, guide, a.guide_bits, total, rng_draw(rng, rng_key(a.seed)));
 #endif
   p.t = p.path = p.recent = 0.0;
-  p.amp = 1.0;
+  p.lamp = 0.0;
   p.moves = 0;
   p.dir = v3(a.toa_xyz + 3 * k);
   // mPol = pi/2 for SH, else 0 (phonons.hpp:200); cos(pi/2) in fp64 is 6.1e-17, not 0
@@ -116,6 +116,7 @@ R3D_HD void collect(const KArgs& a, const Tables<KIND>& T, const Phonon& p, doub
   if (k0 == k1) return;
   const int t = p.type;
   V3 dopm = v3(0, 0, 0);
+  double amp2 = 0.0;
   bool have_dopm = false;
   for (uint32_t k = k0; k < k1; k++) {
     const uint32_t s = g.items[k];
@@ -130,10 +131,10 @@ R3D_HD void collect(const KArgs& a, const Tables<KIND>& T, const Phonon& p, doub
     double fl = floor(scaled);
     if (!(fl < a.n_bins_f)) continue;
     uint32_t bin = (uint32_t)fl;
-    if (!have_dopm) dopm = direction_of_motion(p), have_dopm = true;
+    if (!have_dopm) dopm = direction_of_motion(p), amp2 = amplitude2(p), have_dopm = true;
     const SeisHit& H = T.seis_hit[s];
     double xf = dot(dopm, v3(H.axes[0])), yf = dot(dopm, v3(H.axes[1])), zf = dot(dopm, v3(H.axes[2]));
-    double energy = (p.amp * p.amp) * H.inv_norm[t];
+    double energy = amp2 * H.inv_norm[t];
     size_t slot = (size_t)s * a.n_bins + bin;
     double* e = a.energy + slot * 5;
     R3D_ADD_F64(e + 0, energy * (xf * xf));

@@ -45,7 +45,7 @@ static void run_kind(const KArgs& a, uint64_t n, uint64_t first_id, uint64_t see
     if (finals) {
       r3d_final& f = finals[i];
       std::memset(&f, 0, sizeof f);
-      f.time = p.t, f.path = p.path, f.amp = p.amp;
+      f.time = p.t, f.path = p.path, f.amp = amplitude(p);
       f.loc[0] = p.loc.x, f.loc[1] = p.loc.y, f.loc[2] = p.loc.z;
       f.dir[0] = p.dir.x, f.dir[1] = p.dir.y, f.dir[2] = p.dir.z;
       f.moves = p.moves;
