@@ -112,7 +112,7 @@ R3D_HD double asin_small(double x) {
                    t * (-4.00555345006794114027e-02 + t * (7.91534994289814532176e-04 + t * 3.47933107596021167570e-05)))));
   const double q = 1.0 + t * (-2.40339491173441421878e+00 + t * (2.02094576023350569471e+00 +
                    t * (-6.88283971605453293030e-01 + t * 7.70381505559019352791e-02)));
-  return x + x * (p / q);
+  return x + x * (p * frcp(q));   // (q within [0.6, 1])
 }
 
 // ---- lean elementary functions for the hot path ------------------------------------------------
@@ -182,11 +182,15 @@ R3D_HD double log_lean(double x) {
   const double dk = (double)e;
   return dk * 6.93147180369123816490e-01 - ((hfsq - (s_ * (hfsq + r) + dk * 1.90821492927058770002e-10)) - f);
 }
-// atanh(y) for |y| <= 0.2 by its odd series y + y^3/3 + ... + y^23/23 (first term left out:
-// y^25 / 25, below 1e-18 relative to y on this interval).
-R3D_HD double atanh_small(double y) {
-  const double t = y * y;
-  if (all_lanes(t <= 0.00390625)) {   // |y| <= 1/16 in every lane: through y^13 (next term y^15 / 15: 1e-18 y)
+// atanh(y) for |y| < 1 -- the travel time along an arc is a difference of two, folded into one
+// (media.cpp:487-488, :877-957).  By the odd series y + y^3/3 + ..., as long as every lane of the wave
+// allows: through y^13 for |y| <= 1/16 (legs of a fraction of a degree: a tetrahedral grid), through
+// y^27 for |y| <= 0.268; lanes between 1/4 and 1/2 (long legs in thick shells) first halve the
+// argument, atanh y = 2 atanh(y / (1 + sqrt(1 - y^2))) -- with selects, so that a wave holding both
+// kinds runs ONE series; only beyond 1/2 (rare) the logarithm.  Errors below 1e-17 relative.
+R3D_HD double atanh_lean(double y) {
+  double t = y * y;
+  if (all_lanes(t <= 0.00390625)) {
     double q = 1.0 / 13.0;
     q = __builtin_fma(q, t, 1.0 / 11.0);
     q = __builtin_fma(q, t, 1.0 / 9.0);
@@ -195,7 +199,16 @@ R3D_HD double atanh_small(double y) {
     q = __builtin_fma(q, t, 1.0 / 3.0);
     return __builtin_fma(y * t, q, y);
   }
-  double p = 1.0 / 23.0;
+  double z = y, scale = 1.0;
+  if (!all_lanes(t <= 0.0625)) {
+    const bool big = t > 0.0625;
+    const double zz = y * frcp(1.0 + fsqrt(1.0 - t));
+    z = big ? zz : y, scale = big ? 2.0 : 1.0;
+    t = z * z;
+  }
+  double p = 1.0 / 27.0;
+  p = __builtin_fma(p, t, 1.0 / 25.0);
+  p = __builtin_fma(p, t, 1.0 / 23.0);
   p = __builtin_fma(p, t, 1.0 / 21.0);
   p = __builtin_fma(p, t, 1.0 / 19.0);
   p = __builtin_fma(p, t, 1.0 / 17.0);
@@ -206,7 +219,10 @@ R3D_HD double atanh_small(double y) {
   p = __builtin_fma(p, t, 1.0 / 7.0);
   p = __builtin_fma(p, t, 1.0 / 5.0);
   p = __builtin_fma(p, t, 1.0 / 3.0);
-  return __builtin_fma(y * t, p, y);
+  double r = scale * __builtin_fma(z * t, p, z);
+  if (!(fabs(y) <= 0.5))   // (log_lean works on the bits: a NaN, or an argument outside (-1, 1), is passed on as such)
+    r = (fabs(y) < 1.0) ? 0.5 * log_lean((1.0 + y) / (1.0 - y)) : y * pos_inf();
+  return r;
 }
 // sin and cos for |x| <= pi/4: the classical kernels (fdlibm k_sin.c / k_cos.c coefficients, error
 // below one ulp on this interval); no argument reduction.
@@ -228,19 +244,41 @@ R3D_HD void sincos_small(double x, double* s, double* c) {
   *c = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
 }
 
-// sin and cos of a rotation angle: the small-argument kernels where they apply (a scatter leg is a
-// fraction of a cell), else the library's.
+// sin and cos of a rotation angle up to pi either way (a scatter leg's angle on its arc): the small-
+// argument kernels on the angle itself, on its half or on its quarter, doubled back once or twice --
+// chosen per lane with selects, so that a wave holding short and long legs evaluates ONE pair of
+// polynomials.  Beyond pi (never seen): the library's.
 R3D_HD void rotation(double x, double* s, double* c) {
-  if (fabs(x) <= 0.78539816339744830962) {
+  const double ax = fabs(x);
+  if (all_lanes(ax <= 0.78539816339744830962)) {
     sincos_small(x, s, c);
-  } else if (fabs(x) <= 3.14159265358979323846) {   // a quarter of the angle, doubled twice
-    double s4, c4;
-    sincos_small(0.25 * x, &s4, &c4);
-    const double s2 = 2.0 * s4 * c4, c2 = 1.0 - 2.0 * s4 * s4;
-    *s = 2.0 * s2 * c2, *c = 1.0 - 2.0 * s2 * s2;
-  } else {
-    sincos(x, s, c);
+    return;
   }
+  const bool two = ax > 0.78539816339744830962, four = ax > 1.57079632679489661923;
+  double sh, ch;
+  sincos_small(x * (four ? 0.25 : two ? 0.5 : 1.0), &sh, &ch);
+  double s2 = 2.0 * sh * ch, c2 = 1.0 - 2.0 * sh * sh;
+  sh = two ? s2 : sh, ch = two ? c2 : ch;
+  s2 = 2.0 * sh * ch, c2 = 1.0 - 2.0 * sh * sh;
+  sh = four ? s2 : sh, ch = four ? c2 : ch;
+  *s = sh, *c = ch;
+  if (!(ax <= 3.14159265358979323846)) sincos(x, s, c);
+}
+
+// The angle in [-pi, pi] whose sine and cosine are s, c (unit to rounding): atan2(s, c) without its
+// ~190 instructions.  Where every lane of the wave is within 30 degrees of zero (a leg rarely spans
+// more) the small arcsine; else the direction is referred to the nearest of 0, +-60, +-120, 180
+// degrees -- residual within +-30 degrees, its sine by the subtraction formula -- and the same arcsine
+// serves all lanes at once.
+R3D_HD double angle_from_sincos(double s, double c) {
+  if (all_lanes(c > 0 && fabs(s) <= 0.5)) return asin_small(s);
+  const double k866 = 0.86602540378443864676;
+  const bool near0 = c >= k866, front = c >= 0.0, back = c >= -k866;
+  const double cf = near0 ? 1.0 : front ? 0.5 : back ? -0.5 : -1.0;
+  const double sf = copysign((near0 || !back) ? 0.0 : k866, s);
+  const double phi = copysign(near0 ? 0.0 : front ? 1.04719755119659774615 : back ? 2.09439510239319549231
+                                                                             : 3.14159265358979323846, s);
+  return phi + asin_small(s * cf - c * sf);
 }
 
 struct V3 {

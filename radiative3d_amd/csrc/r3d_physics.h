@@ -242,8 +242,7 @@ R3D_HD TetExit tet_exit(const CellTet& c, const TetArc& A) {
 R3D_HD double tet_exit_length(const TetArc& A, const TetExit& e) {
   if (!(e.s > -pos_inf() && e.s < pos_inf())) return e.s;   // +-inf (NaN propagates)
   const double sd = e.s * A.c0 - e.c * A.s0, cd = e.c * A.c0 + e.s * A.s0;   // sine, cosine of the arc angle
-  if (cd > 0 && fabs(sd) <= 0.5) return A.R * asin_small(sd);   // (the usual case: a leg spans a few degrees)
-  return A.R * atan2(sd, cd);
+  return A.R * angle_from_sincos(sd, cd);
 }
 // reference Tetra::AdvanceLength (media.cpp:442-499) + Phonon::Move.  (s1, c1)
 // are the sine / cosine of the end angle: the exit's own for a boundary leg,
@@ -256,7 +255,7 @@ R3D_HD void tet_advance(const CellTet& c, const TetArc& A, Phonon& p, double len
   // atanh(s1) - atanh(s0) = atanh(y), y = (s1 - s0) / (1 - s0 s1): a leg spans a few degrees, so y
   // is small and the series does (one division, no logarithm)
   const double y = (s1 - A.s0) * frcp(1.0 - A.s0 * s1);
-  double time = c.inv_gmag[t] * ((fabs(y) <= 0.2) ? atanh_small(y) : 0.5 * log_lean((1.0 + y) / (1.0 - y)));
+  double time = c.inv_gmag[t] * atanh_lean(y);
   p.path += len, p.t += time, p.recent += time;
   p.loc = nl;
   // (nd = c1 v1 - s1 v3 with v1, v3 orthonormal is unit to rounding; the reference's
@@ -347,16 +346,6 @@ R3D_HD SphArc sph_arc(const CellSph& c, const double ec[3], const Phonon& p) {
   A.c0 = (h2 == 0) ? 1.0 : x * ih;
   return A;
 }
-// An angle in (-pi, pi] from its sine and cosine (unit to rounding): the small-angle arcsin where
-// it applies (a leg rarely spans more than a few degrees), else the general function.
-R3D_HD double angle_from_sincos(double s, double c) {
-  if (c > 0 && fabs(s) <= 0.5) return asin_small(s);
-  // up to 60 degrees either way: the half angle, cos(d/2) = sqrt((1 + c) / 2), sin(d/2) = s / (2 cos(d/2))
-  const double ch = fsqrt(0.5 * (1.0 + c));
-  const double sh = 0.5 * s / ch;
-  if (c > -0.5 && fabs(sh) <= 0.5) return 2.0 * asin_small(sh);
-  return atan2(s, c);
-}
 // reference SphereShell::GetPathToBoundary, media.cpp:668-757 (search part), with
 // SphereFace::CircularArcDistToExit, media_cellface.cpp:717-748, for both faces.
 //
@@ -432,7 +421,7 @@ R3D_HD void sph_advance(const CellSph& c, const SphArc& A, Phonon& p, double len
     //   y = K (s1 (1 + c0) - s0 (1 + c1)) / ((1 + c0)(1 + c1) - K^2 s0 s1),  K = CotZetaBy2 -- one quotient
     const double h0 = 1.0 + A.c0, h1 = 1.0 + c1;
     const double y = (A.CotZetaBy2 * (s1 * h0 - A.s0 * h1)) * frcp(h0 * h1 - (A.CotZetaBy2 * A.CotZetaBy2) * (A.s0 * s1));
-    time = att_time = A.timeCoef * ((fabs(y) <= 0.2) ? atanh_small(y) : 0.5 * log_lean((1.0 + y) / (1.0 - y)));
+    time = att_time = A.timeCoef * atanh_lean(y);
     // (nd = c1 u1 - s1 u3 with u1, u3 orthonormal is unit to rounding; the reference's
     //  renormalisation + (theta, phi) round trip changes it by ~1e-16 and is skipped, as in tet_advance)
     p.dir = nd;

@@ -246,7 +246,7 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
     double s1 = sexit.sx, c1 = sexit.cx;  // a boundary leg ends at the exit point itself
     if (scatters || !sexit.on_arc) {
       double sd, cd;                      // scatter leg (or a squashed one): rotate by len / R
-      rotation(len / sarc.radius, &sd, &cd);
+      rotation(len * frcp(sarc.radius), &sd, &cd);
       s1 = sarc.s0 * cd + sarc.c0 * sd, c1 = sarc.c0 * cd - sarc.s0 * sd;
     }
     sph_advance(c, sarc, p, len, s1, c1);

@@ -95,3 +95,21 @@ extern "C" uint32_t r3d_emul_face_class(const r3d_model_desc* m, int ci, int f) 
 extern "C" uint32_t r3d_emul_class_from_corners(const double* steps, int n) {
   return classify_from_corner_steps(reinterpret_cast<const double (*)[2]>(steps), n);
 }
+
+// The lean elementary functions of r3d_math.h, one value at a time (host build: a "wave" is one
+// lane, so every tier of the wave-voted routines is reached by its own arguments).
+// which: 0 exp_lean(x)  1 log_lean(x)  2 atanh_lean(x)  3 asin_small(x)  4 angle_from_sincos(x, y)
+//        5 / 6 sine / cosine of rotation(x)
+extern "C" double r3d_emul_math(int which, double x, double y) {
+  double s = 0, c = 0;
+  switch (which) {
+    case 0: return exp_lean(x);
+    case 1: return log_lean(x);
+    case 2: return atanh_lean(x);
+    case 3: return asin_small(x);
+    case 4: return angle_from_sincos(x, y);
+    case 5: rotation(x, &s, &c); return s;
+    case 6: rotation(x, &s, &c); return c;
+  }
+  return 0.0 / 0.0;
+}

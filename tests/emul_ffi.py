@@ -29,6 +29,8 @@ def lib():
         L.r3d_emul_face_class.argtypes = [C.POINTER(_ffi.ModelDesc), C.c_int, C.c_int]
         L.r3d_emul_class_from_corners.restype = C.c_uint32
         L.r3d_emul_class_from_corners.argtypes = [C.POINTER(C.c_double), C.c_int]
+        L.r3d_emul_math.restype = C.c_double
+        L.r3d_emul_math.argtypes = [C.c_int, C.c_double, C.c_double]
         _lib = L
     return _lib
 
@@ -66,3 +68,8 @@ def class_from_corners(steps):
 
 def face_class(model, cell, face):
     return int(lib().r3d_emul_face_class(model.desc_p, cell, face))
+
+
+def math_fn(which, x, y=0.0):
+    """One of the kernel's lean elementary functions (tests/emul/emul.cpp r3d_emul_math)."""
+    return float(lib().r3d_emul_math(which, float(x), float(y)))
