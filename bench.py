@@ -365,9 +365,9 @@ def main():
         b_hist = algorithmic_bytes_per_history(ev, model.n_toa, model.n_seismometers, model.desc.cell_kind)
         roofline = {
             "bound": "valu",
-            "kernel": f"propagate_kernel<{kind_name}>", "kernel_ms_step_avg": avg_step_ms,
+            "kernel": f"pool_kernel<{kind_name}>", "kernel_ms_step_avg": avg_step_ms,
             "kernel_ms_flush": flush_ms, "kernel_ms_per_step_incl_flush": kernel_ms_per_step,
-            "note": "the traversal is fp64 vector code with divergent gathers; no MFMA, ~3-5 % of HBM peak. "
+            "note": "the traversal is fp64 vector code with divergent gathers; no MFMA, 4-16 % of HBM peak (the hbm object). "
                     "achieved = VALU-busy SIMD-cycles per second of a step launch (SQ_ACTIVE_INST_VALU x 4 "
                     "cycles, recorded per launch by rocprofv3 --pmc, / this run's measured launch time); "
                     "peak = 1024 SIMDs x 2.4 GHz",

@@ -4,8 +4,8 @@
 # Per config (default: all five of bench.py --config):
 #   1. kernel trace + stats of `python3 bench.py --config C --steps 5 --warmup 1 --timed-only`
 #   2. PMC passes (each in its own run, no tracing): HBM traffic, SQ issue / occupancy counters
-# --timed-only keeps the run to the warm-up and the timed chain, so every propagate_kernel dispatch
-# is a chained step launch of the workload and every drain_kernel dispatch a chain's flush.
+# --timed-only keeps the run to the warm-up and the timed chain, so every pool_kernel dispatch
+# is a chained step launch of the workload and every pool_drain_kernel dispatch a chain's flush.
 set -e
 tag=${1:-run}
 shift || true

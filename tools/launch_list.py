@@ -1,6 +1,6 @@
 """Per-launch durations of the traversal kernel from a rocprofv3 kernel trace, in launch order
 (tools/collect_profiles.sh): bench.py chains its steps (r3d_run_device_carry) -- step launches are
-propagate_kernel, the chain's flush launches (stragglers only) drain_kernel."""
+pool_kernel, the chain's flush launches (stragglers only) drain_kernel."""
 import csv
 import glob
 import json
@@ -8,7 +8,7 @@ import sys
 
 out, config = sys.argv[1], sys.argv[2]
 f = sorted(glob.glob(f"{out}/trace_{config}/**/*kernel_trace.csv", recursive=True))[0]
-rows = [r for r in csv.DictReader(open(f)) if "propagate_kernel" in r["Kernel_Name"] or "pool_kernel" in r["Kernel_Name"] or "drain_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(f)) if "pool_kernel" in r["Kernel_Name"] or "drain_kernel" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ms = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
 kinds = ["flush" if "drain_kernel" in r["Kernel_Name"] else "step" for r in rows]

@@ -1,7 +1,7 @@
 """Summarise the rocprofv3 --pmc passes of tools/collect_profiles.sh (DIR/pmc_<config>_*/) into
 DIR/pmc_<config>.json: per-dispatch counter values of the traversal kernel, and the derived
 figures bench.py's `roofline` object reads.  bench.py chains its steps (r3d_run_device_carry): the
-step launches are propagate_kernel dispatches, the chain's flush launches (stragglers only)
+step launches are pool_kernel dispatches, the chain's flush launches (stragglers only)
 drain_kernel dispatches; they are averaged separately."""
 import collections
 import csv
@@ -21,7 +21,7 @@ for f in sorted(glob.glob(f"{out}/pmc_{config}_*/**/*counter_collection.csv", re
     for row in csv.DictReader(open(f)):
         if "drain_kernel" in row["Kernel_Name"]:
             drain[row["Counter_Name"]][int(row["Dispatch_Id"])] += float(row["Counter_Value"])
-        if not ("propagate_kernel" in row["Kernel_Name"] or "pool_kernel" in row["Kernel_Name"]):
+        if not ("pool_kernel" in row["Kernel_Name"]):
             continue
         acc[row["Counter_Name"]][int(row["Dispatch_Id"])] += float(row["Counter_Value"])
         if kern is None:
