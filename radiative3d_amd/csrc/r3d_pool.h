@@ -441,7 +441,17 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   __syncthreads();
 #endif
 
+  // The launch arguments are re-read for every batch: `args` below is the kernel-argument segment
+  // behind a pointer the compiler cannot see through, so what a phase needs of the ~90 words is
+  // loaded (scalar loads, scalar cache) where the phase starts and dropped where it ends.  Left to
+  // itself the compiler fetches every argument once, ahead of the loop, and then holds -- or
+  // spills to vector-register lanes and scratch -- all of them across it: 84 scalar and 10
+  // vector registers spilled, against 15-43 and 0-4 this way.
+  typedef const __attribute__((address_space(4))) KArgs* KernArgs;
+  KernArgs args = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();   // (KArgs is the kernels' only parameter)
   for (;;) {
+    asm volatile("" : "+s"(args));
+    const KArgs& a = *(const KArgs*)args;   // (shadows the parameter: the same values, fetched afresh)
     int q;
     unsigned id, k;
     bool act;
@@ -721,8 +731,10 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   }
 
   __syncthreads();
-  if (a.carry_out) {   // park the pool for the engine's next launch
-    uint32_t* img = reinterpret_cast<uint32_t*>(a.carry_out) + (size_t)blockIdx.x * image_words;
+  asm volatile("" : "+s"(args));
+  const KArgs& a_end = *(const KArgs*)args;   // (for what follows the loop, fetched after it)
+  if (a_end.carry_out) {   // park the pool for the engine's next launch
+    uint32_t* img = reinterpret_cast<uint32_t*>(a_end.carry_out) + (size_t)blockIdx.x * image_words;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(fd);
     for (size_t i = tid; i < image_words; i += kPoolBlock) img[i] = src[i];
   }
@@ -731,7 +743,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
     for (uint32_t i = tid; i <= bc.mask; i += kPoolBlock) {
       const uint32_t bin = bc.key[i];
       if (bin == kEmpty) continue;
-      double* e = a.energy + (size_t)bin * 5;
+      double* e = a_end.energy + (size_t)bin * 5;
 #pragma unroll
       for (int cc = 0; cc < 5; cc++) {
         const double v = bc.e[i * 5u + cc];
@@ -740,14 +752,14 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #pragma unroll
       for (int t = 0; t < 2; t++) {
         const uint32_t n = bc.cnt[i * 2u + t];
-        if (n) atomicAdd(a.counts + (size_t)bin * 2 + t, (unsigned long long)n);
+        if (n) atomicAdd(a_end.counts + (size_t)bin * 2 + t, (unsigned long long)n);
       }
     }
   }
 #ifdef R3D_PHASE_TIMING
   if (tid < 40) atomicAdd(&g_pool_stats[tid / 8][tid % 8], s_stats[tid / 8][tid % 8]);
 #endif
-  if (tid < R3D_N_SCALARS && s_tally[tid] != 0ull) atomicAdd(a.scalars + tid, s_tally[tid]);
+  if (tid < R3D_N_SCALARS && s_tally[tid] != 0ull) atomicAdd(a_end.scalars + tid, s_tally[tid]);
 }
 
 // The traversal kernel, and the same body under a second name for the flush launch of a carry
