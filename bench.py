@@ -21,6 +21,7 @@ region (weak scaling: every rank runs the same count).  Rank 0 prints one JSON l
 """
 import argparse
 import hashlib
+import re
 import json
 import math
 import os
@@ -76,14 +77,18 @@ def algorithmic_bytes_per_history(ev, n_toa, n_seis, cell_kind):
             + 104)
 
 
-def kernel_source_hash():
-    """sha256 over the kernel's sources and build flags: what the recorded counters are keyed by."""
+def kernel_source_hash(csrc=None):
+    """sha256 over the kernel's code and build flags: what the recorded counters are keyed by.
+    Comments and white space do not count (a reworded comment leaves the machine code as it was)."""
     h = hashlib.sha256()
-    csrc = os.path.join(REPO, "radiative3d_amd", "csrc")
+    csrc = csrc or os.path.join(REPO, "radiative3d_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
         if name.endswith((".h", ".hip")):
             h.update(name.encode())
-            h.update(open(os.path.join(csrc, name), "rb").read())
+            text = open(os.path.join(csrc, name), encoding="utf-8").read()
+            text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)          # block comments
+            text = re.sub(r"//[^\n]*", " ", text)                       # line comments (no string in these sources holds //)
+            h.update(" ".join(text.split()).encode())
     for line in open(os.path.join(REPO, "Makefile")):
         if line.startswith("HIPFLAGS") or line.lstrip().startswith("-mllvm"):
             h.update(line.encode())

@@ -8,32 +8,36 @@
 // model, with the vector issue slots 82-92 % full).  Here the histories in flight live in LDS
 // instead -- a pool of S 128-byte slots per workgroup -- and lanes are only workers:
 //
-//   * every slot is, between phases, in exactly one of six queues (rings of slot numbers in
-//     LDS): MOVE, COLLECT, RT, BEND, SCATTER, FREE;
+//   * every slot is, between phases, in exactly one of five queues (rings of slot numbers in
+//     LDS): MOVE, COLLECT, RT, SCATTER, FREE;
 //   * a wave takes up to 64 slots OF ONE QUEUE, loads their state into registers, runs that
 //     phase's code for all of them at once, stores what changed and hands each slot to the queue
-//     of its next phase.  With S about twice the workgroup's lanes the queues are deep enough
-//     that nearly every batch is a full one, so each phase runs at (close to) 64 lanes;
+//     of its next phase (one merged hand-off for all destinations).  With S above the workgroup's
+//     lane count the queues are deep enough that nearly every batch is a full one, so each phase
+//     runs at (close to) 64 lanes;
 //   * phases:  FREE -> (claim ids from the global counter, source spray) -> MOVE
-//              MOVE -> (termination checks, boundary search, free-path draw, advance) ->
-//                      SCATTER | COLLECT | RT | BEND | MOVE (plain hand-over) | FREE (history ended)
+//              MOVE -> (termination checks, boundary search, free-path draw, advance; a plain
+//                      hand-over or a Snell bend is served inline, and lanes that can simply move
+//                      again do so in registers: up to kPoolMoves moves while >= kMoveAgainLanes
+//                      lanes go on) -> SCATTER | COLLECT | RT | MOVE | FREE (history ended)
 //              COLLECT -> (receiver hash, (arrival, receiver) pairs dealt over the lanes, bins) ->
-//                      RT | BEND | MOVE | FREE
-//              RT, BEND, SCATTER -> MOVE
+//                      RT | MOVE | FREE
+//              RT, SCATTER -> MOVE
 //   * histories are keyed by id and draw from per-history counters (r3d_rng.h), and every phase
-//     is the same per-history code as before (r3d_step.h), so which wave runs which phase of a
-//     history, and in what order histories are served, changes no result.
+//     is the same per-history code as the host emulation runs (r3d_step.h), so which wave runs
+//     which phase of a history, and in what order histories are served, changes no result.
 //
 // Queue protocol (multi-producer, multi-consumer among the waves of one workgroup, LDS only):
-// a ring of 16-bit slot numbers with free-running head / tail tickets and a count of published
-// entries.  A consumer takes min(count, 64) with a compare-and-swap on the count, then a range
-// of head tickets, and spins on each of its entries until it is no longer EMPTY (the entry may
-// belong to a producer that has its ticket but has not written yet), reads it and marks it
-// EMPTY.  A producer takes tail tickets, waits until its entries are EMPTY (a consumer that
-// holds the ticket of the previous lap may not have read yet), writes them, then adds to the
-// count.  A slot's state is written before its number is published and read after it is taken
-// (LDS operations of a wave complete in order; release / acquire fences at workgroup scope
-// keep the compiler from moving them).
+// a ring of 16-bit slot numbers; the head ticket and the count of published entries share one
+// control word, the tail ticket has its own.  A consumer takes min(count, 64) entries with ONE
+// compare-and-swap on the control word it has just read (head advanced, count reduced), then
+// spins on each of its entries until it is no longer EMPTY (the entry may belong to a producer
+// that has its ticket but has not written yet), reads it and marks it EMPTY.  A producer takes
+// tail tickets -- for all destination queues with one LDS atomic instruction, lane q serving
+// queue q -- waits until its entries are EMPTY (a consumer holding the ticket of the previous lap
+// may not have read yet), writes them, then adds to the count.  A slot's state is written before
+// its number is published and read after it is taken (LDS operations of a wave complete in
+// order; release / acquire fences at workgroup scope keep the compiler from moving them).
 #ifndef R3D_POOL_H_
 #define R3D_POOL_H_
 
@@ -42,12 +46,12 @@ namespace r3d {
 #ifndef R3D_POOL_BLOCK
 #define R3D_POOL_BLOCK 768
 #endif
-// 12 waves = 3 per SIMD, i.e. a budget of 168 registers per lane.  The kernel is bound by how
-// fast one wave can issue (memory round trips, dependent fp64 chains), so a third wave per SIMD is
-// worth 10-14 % -- once every phase fits the budget: the R/T solve in two halves with nothing but
-// the choice carried across, event counters that live for one batch (10 spilled registers left, in
-// rarely taken paths).  Measured at 512 / 768 threads: NSCP 15.8 / 12.8 ms, LopNor 13.9 / 11.0,
-// SphereEarth 40.8 / 33.0 per 3e6 histories.
+// 12 waves = 3 per SIMD, i.e. a budget of 168 registers per lane.  At two waves per SIMD a wave that
+// waits (memory round trips, dependent fp64 chains) is covered by one other only, so a third is
+// worth 15-25 % -- once every phase fits the budget: the R/T solve in two halves with nothing but
+// the choice carried across, event counters that live for one batch, the launch arguments fetched
+// per batch (0-4 vector registers spilled).  Measured at 512 / 768 threads, same code otherwise:
+// NSCP 15.8 / 12.8 ms, LopNor 13.9 / 11.0, SphereEarth 40.8 / 33.0 per 3e6 histories.
 constexpr int kPoolBlock = R3D_POOL_BLOCK;
 constexpr int kPoolWaves = kPoolBlock / 64;
 
