@@ -383,6 +383,17 @@ double   r3d_kernel_ms(r3d_engine* e, uint64_t launch);
 /* Number of scalar counters r3d_run_device expects.                         */
 #define R3D_N_SCALARS (3 + R3D_INV_NUM + R3D_EV_NUM)
 
+/* Self-test hook: evaluates one of the kernel's own elementary functions
+ * (radiative3d_amd/csrc/r3d_math.h -- the traversal uses these instead of the
+ * device library's exp / log / atanh / asin / atan2 / sincos) on the device,
+ * 64 consecutive elements per wave, so a test can feed waves whose lanes fall
+ * into different tiers of the wave-voted routines.
+ * which: 0 exp_lean(x)  1 log_lean(x)  2 atanh_lean(x)  3 asin_small(x)
+ *        4 angle_from_sincos(x, y)  5 / 6 sine / cosine of rotation(x)
+ *        7 frcp(x)  8 frsqrt(x)  9 fsqrt(x)
+ * x, y (may be NULL where unused), out: host arrays of n doubles.  0 on success. */
+int r3d_selftest_math(int device, int which, const double* x, const double* y, double* out, uint64_t n);
+
 /* Message for the last failing call on this thread.                        */
 const char* r3d_last_error(void);
 

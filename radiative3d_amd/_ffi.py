@@ -208,6 +208,9 @@ def hip_lib():
         L.r3d_last_kernel_ms.argtypes = [C.c_void_p]
         L.r3d_launch_count.restype = C.c_uint64
         L.r3d_launch_count.argtypes = [C.c_void_p]
+        L.r3d_selftest_math.restype = C.c_int
+        L.r3d_selftest_math.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_double), C.c_uint64]
         L.r3d_kernel_ms.restype = C.c_double
         L.r3d_kernel_ms.argtypes = [C.c_void_p, C.c_uint64]
         L.r3d_engine_close.restype = C.c_int

@@ -725,6 +725,43 @@ int r3d_run_traced(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, 
   return run_host(e, n, first_id, seed, out, finals);
 }
 
+// ---- self-test of the lean elementary functions (include/r3d.h r3d_selftest_math) ----
+__global__ void selftest_math_kernel(int which, const double* x, const double* y, double* out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;   // (n is padded to whole waves by the caller's choice of inputs or not: the votes see active lanes only)
+  const double a = x[i], b = y ? y[i] : 0.0;
+  double s = 0.0, c = 0.0, r = 0.0;
+  switch (which) {   // (wave-uniform)
+    case 0: r = exp_lean(a); break;
+    case 1: r = log_lean(a); break;
+    case 2: r = atanh_lean(a); break;
+    case 3: r = asin_small(a); break;
+    case 4: r = angle_from_sincos(a, b); break;
+    case 5: rotation(a, &s, &c), r = s; break;
+    case 6: rotation(a, &s, &c), r = c; break;
+    case 7: r = frcp(a); break;
+    case 8: r = frsqrt(a); break;
+    case 9: r = fsqrt(a); break;
+    default: r = a - a; break;
+  }
+  out[i] = r;
+}
+int r3d_selftest_math(int device, int which, const double* x, const double* y, double* out, uint64_t n) {
+  const int fail_value = 1;
+  if (!x || !out || which < 0 || which > 9) return g_error = "r3d_selftest_math: bad arguments", 1;
+  if (n == 0) return 0;
+  R3D_ON_DEVICE(device);
+  DevBuf dx, dy, dout;
+  R3D_HIP_OK(dx.upload(x, n * sizeof(double)));
+  if (y) R3D_HIP_OK(dy.upload(y, n * sizeof(double)));
+  R3D_HIP_OK(dout.upload(x, n * sizeof(double)));
+  selftest_math_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(which, (const double*)dx.p, y ? (const double*)dy.p : nullptr,
+                                                                      (double*)dout.p, n);
+  R3D_HIP_OK(hipGetLastError());
+  R3D_HIP_OK(hipMemcpy(out, dout.p, n * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+}
+
 #ifdef R3D_PHASE_TIMING
 // diagnostic builds only: per queue of the pool kernel, batches served / lanes filled / wave cycles
 // since the last call (slot 6 of the first row: idle polls)

@@ -66,3 +66,73 @@ def test_rotation_up_to_pi_and_beyond():
         tol = 5e-16 if abs(x) <= math.pi / 4 or abs(x) > math.pi else 2e-15
         assert abs(emul_ffi.math_fn(ROT_S, x) - math.sin(x)) < tol, x
         assert abs(emul_ffi.math_fn(ROT_C, x) - math.cos(x)) < tol, x
+
+
+# ---- the same functions on the device (wave-level tiers: 64 consecutive elements share a vote) ----
+def _device(which, x, y=None):
+    import ctypes as C
+    from radiative3d_amd import _ffi
+    L = _ffi.hip_lib()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    dp = C.POINTER(C.c_double)
+    yp = None
+    if y is not None:
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        yp = y.ctypes.data_as(dp)
+    rc = L.r3d_selftest_math(0, which, x.ctypes.data_as(dp), yp, out.ctypes.data_as(dp), x.size)
+    assert rc == 0, L.r3d_last_error().decode()
+    return out
+
+
+def _waves(small, large, n_waves=24):
+    """Waves of 64: all-small, all-large, and mixed (one large lane among small ones, half and half)."""
+    rows = []
+    for w in range(n_waves):
+        kind = w % 4
+        s, l = RNG.choice(small, 64), RNG.choice(large, 64)
+        if kind == 0:
+            rows.append(s)
+        elif kind == 1:
+            rows.append(l)
+        elif kind == 2:
+            r = s.copy(); r[RNG.integers(64)] = l[0]; rows.append(r)
+        else:
+            r = s.copy(); r[::2] = l[::2]; rows.append(r)
+    return np.concatenate(rows)
+
+
+@pytest.mark.gpu
+def test_device_atanh_asin_rotation_across_wave_tiers():
+    sgn = lambda n: RNG.choice([-1.0, 1.0], n)
+    # atanh: tiers at 1/16, 1/4 (halving), 1/2 (logarithm)
+    small, large = np.logspace(-12, np.log10(1 / 16), 500), np.concatenate([RNG.uniform(1 / 16, 0.5, 400), RNG.uniform(0.5, 0.97, 100)])
+    x = _waves(small, large); x *= sgn(x.size)
+    got = _device(ATANH, x)
+    assert np.max(np.abs(got - np.arctanh(x)) / np.abs(np.arctanh(x))) < 8e-16
+    # asin_small: |x| <= 1/16 short series by vote, else the rational form
+    x = _waves(np.logspace(-12, np.log10(1 / 16), 500), RNG.uniform(1 / 16, 0.5, 500)); x *= sgn(x.size)
+    assert np.max(np.abs(_device(ASIN, x) - np.arcsin(x)) / np.abs(np.arcsin(x))) < 6e-16
+    # rotation: pi/4, pi/2, pi tiers, and beyond
+    x = _waves(RNG.uniform(0, math.pi / 4, 500), np.concatenate([RNG.uniform(math.pi / 4, math.pi, 450), RNG.uniform(math.pi, 30, 50)]))
+    x *= sgn(x.size)
+    assert np.max(np.abs(_device(ROT_S, x) - np.sin(x))) < 2e-15
+    assert np.max(np.abs(_device(ROT_C, x) - np.cos(x))) < 2e-15
+
+
+@pytest.mark.gpu
+def test_device_angle_exp_log_and_the_newton_reciprocals():
+    a = _waves(RNG.uniform(-0.5, 0.5, 500), RNG.uniform(-math.pi, math.pi, 500))
+    got = _device(ANGLE, np.sin(a), np.cos(a))
+    want = np.arctan2(np.sin(a), np.cos(a))
+    assert np.max(np.abs(got - want)) < 1.2e-15
+    x = np.concatenate([RNG.uniform(-30, 5, 1000), -np.logspace(-12, 1, 280)])
+    assert np.max(np.abs(_device(EXP, x) / np.exp(x) - 1)) < 5e-16
+    x = np.concatenate([RNG.uniform(1e-9, 1, 1000), np.logspace(-300, 3, 280)])
+    assert np.max(np.abs(_device(LOG, x) - np.log(x)) / np.maximum(1.0, np.abs(np.log(x)))) < 5e-16
+    x = np.concatenate([RNG.uniform(1e-3, 1e4, 1000), np.logspace(-30, 30, 280)]) * RNG.choice([-1.0, 1.0], 1280)
+    assert np.max(np.abs(_device(7, x) * x - 1)) < 5e-16                 # frcp
+    x = np.abs(x)
+    assert np.max(np.abs(_device(8, x) * np.sqrt(x) - 1)) < 5e-16        # frsqrt
+    assert np.max(np.abs(_device(9, x) / np.sqrt(x) - 1)) < 5e-16        # fsqrt
+    assert _device(9, np.zeros(64))[0] == 0.0
