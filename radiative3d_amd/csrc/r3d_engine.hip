@@ -508,7 +508,7 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
     const size_t left = kLds - kStatic - off;
     // S slots need 124 S bytes + one ring of (power of two >= S) u16 per queue: try the largest first
     uint32_t slots = 0, cap = 0;
-    for (uint32_t s_try = 2048; s_try >= 128; s_try -= 64) {
+    for (uint32_t s_try = 1984; s_try >= 128; s_try -= 64) {   // (a ring entry has 11 bits for the slot number)
       uint32_t c = 64;
       while (c < s_try) c <<= 1;
       if ((size_t)s_try * kSlotBytes + (size_t)Q_NUM * c * sizeof(uint16_t) <= left) {

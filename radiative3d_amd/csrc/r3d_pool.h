@@ -32,7 +32,8 @@
 // control word, the tail ticket has its own.  A consumer takes min(count, 64) entries with ONE
 // compare-and-swap on the control word it has just read (head advanced, count reduced), then
 // spins on each of its entries until it is no longer EMPTY (the entry may belong to a producer
-// that has its ticket but has not written yet), reads it and marks it EMPTY.  A producer takes
+// that has its ticket but has not written yet) and carries its own ticket's lap (below), reads it
+// and marks it EMPTY.  A producer takes
 // tail tickets -- for all destination queues with one LDS atomic instruction, lane q serving
 // queue q -- waits until its entries are EMPTY (a consumer holding the ticket of the previous lap
 // may not have read yet), writes them, then adds to the count.  A slot's state is written before
@@ -88,10 +89,18 @@ __device__ __forceinline__ uint32_t meta_pack(int type, int face, uint32_t flags
   return (uint32_t)type | ((uint32_t)(face + 1) << 1) | ((flags & 0xFFu) << 8) | ((uint32_t)queue << 16);
 }
 
+// A ring entry: the slot number in its low 11 bits (S <= 1984), above it the low 5 bits of the LAP of
+// the ticket it was written for.  A consumer accepts an entry only with its own ticket's lap on it:
+// should a wave ever stall between taking its tickets and reading its entries for as long as the
+// other waves need to push a whole ring's worth (tens of thousands of cycles -- a pre-empted queue),
+// the consumer a lap later waits instead of reading the stalled wave's entry.
+constexpr uint32_t kSlotBits = 11;
+__device__ __forceinline__ uint32_t lap_of(uint32_t ticket, uint32_t log2cap) { return (ticket >> log2cap) & 31u; }
+
 // Take up to 64 slot numbers from queue q, whose control word was last seen as `seen`; returns how
 // many (wave-uniform); lane l < k gets its slot in `id`.
-__device__ __forceinline__ unsigned q_pop(PoolCtl& ctl, lds_u16* ring, uint32_t mask, int q, unsigned lane,
-                                          uint32_t seen, unsigned& id) {
+__device__ __forceinline__ unsigned q_pop(PoolCtl& ctl, lds_u16* ring, uint32_t mask, uint32_t log2cap, int q,
+                                          unsigned lane, uint32_t seen, unsigned& id) {
   unsigned k = 0, pos = 0;
   if (lane == 0) {
     uint32_t w = seen;
@@ -111,12 +120,13 @@ __device__ __forceinline__ unsigned q_pop(PoolCtl& ctl, lds_u16* ring, uint32_t 
   id = 0;
   if (lane < k) {
     volatile lds_u16* e = ring + ((pos + lane) & mask);
+    const uint32_t want = lap_of(pos + lane, log2cap);
     uint16_t v;
     do {
       v = *e;
-    } while (v == kRingEmpty);
+    } while (v == kRingEmpty || (uint32_t)(v >> kSlotBits) != want);
     *e = kRingEmpty;
-    id = v;
+    id = v & ((1u << kSlotBits) - 1u);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   return k;
@@ -125,8 +135,8 @@ __device__ __forceinline__ unsigned q_pop(PoolCtl& ctl, lds_u16* ring, uint32_t 
 // Hand every active lane's slot to the queue named in its `dest` (all queues in one go: lane q
 // takes the tail tickets of queue q and publishes its count, so the whole distribution costs one
 // round of LDS atomics each way).
-__device__ __forceinline__ void q_push_all(PoolCtl& ctl, lds_u16* rings, uint32_t rcap, unsigned lane, bool act,
-                                           int dest, unsigned id) {
+__device__ __forceinline__ void q_push_all(PoolCtl& ctl, lds_u16* rings, uint32_t rcap, uint32_t log2cap,
+                                           unsigned lane, bool act, int dest, unsigned id) {
   unsigned long long m[Q_NUM];
   uint32_t kq = 0, rank = 0;
 #pragma unroll
@@ -140,10 +150,11 @@ __device__ __forceinline__ void q_push_all(PoolCtl& ctl, lds_u16* rings, uint32_
   if (lane < Q_NUM && kq) pos = atomicAdd(&ctl.tail[lane], kq);
   const uint32_t mine = (uint32_t)__shfl((int)pos, act ? dest : 0);
   if (act) {
-    volatile lds_u16* e = rings + (uint32_t)dest * rcap + ((mine + rank) & (rcap - 1u));
+    const uint32_t t = mine + rank;
+    volatile lds_u16* e = rings + (uint32_t)dest * rcap + (t & (rcap - 1u));
     while (*e != kRingEmpty) {
     }
-    *e = (uint16_t)id;
+    *e = (uint16_t)((lap_of(t, log2cap) << kSlotBits) | id);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   if (lane < Q_NUM && kq) atomicAdd(&ctl.word[lane], kq);
@@ -317,6 +328,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 
   // ---- the pool, its queues, the block's tallies ----
   const uint32_t S = a.pool_slots, rcap = a.pool_ring_mask + 1u, rmask = a.pool_ring_mask;
+  const uint32_t rlog = 31u - (uint32_t)__builtin_clz(rcap);   // (a power of two)
   double* const fd = reinterpret_cast<double*>(smem + a.lds_pool_off);          // [FD_NUM][S]
   uint32_t* const fu = reinterpret_cast<uint32_t*>(fd + (size_t)FD_NUM * S);    // [FU_NUM][S]
   lds_u16* const rings = (lds_u16*)(smem + a.lds_ring_off);                      // [Q_NUM][rcap]
@@ -339,7 +351,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       const uint32_t s = base + tid;
       const bool have = s < S;
       const int tag = have ? (int)((fu[FU_META * S + s] >> 16) & 7u) : 0;
-      q_push_all(ctl, rings, rcap, lane, have, tag, s);
+      q_push_all(ctl, rings, rcap, rlog, lane, have, tag, s);
     }
   } else {
     for (uint32_t s = tid; s < S; s += kPoolBlock) {
@@ -497,7 +509,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       uint32_t wq = 0;
 #pragma unroll
       for (int j = 0; j < Q_NUM; j++) wq = (q == j) ? w[j] : wq;
-      k = q_pop(ctl, ring(q), rmask, q, lane, wq, id);
+      k = q_pop(ctl, ring(q), rmask, rlog, q, lane, wq, id);
       if (k == 0) continue;   // another wave was quicker
       act = lane < k;
     }
@@ -721,7 +733,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #ifdef R3D_PHASE_TIMING
     const unsigned long long t_push = __builtin_readcyclecounter();
 #endif
-    q_push_all(ctl, rings, rcap, lane, act, dest, id);
+    q_push_all(ctl, rings, rcap, rlog, lane, act, dest, id);
 #ifdef R3D_PHASE_TIMING
     if (lane == 0) {
       const unsigned long long t_end = __builtin_readcyclecounter();
