@@ -8,8 +8,9 @@
 //
 // Both are templates over the cell kind (a model is homogeneous in kind, so
 // the choice is made once per launch, not per cell) and over where the small
-// tables live.  They are __host__ __device__: r3d_engine.hip wraps them in
-// the persistent refill kernel; tests/emul wraps them in a plain CPU loop.
+// tables live.  They are __host__ __device__: r3d_pool.h calls the halves of
+// the iteration from the phases of the pool kernel; tests/emul wraps them in
+// a plain CPU loop.
 #ifndef R3D_STEP_H_
 #define R3D_STEP_H_
 
