@@ -54,6 +54,15 @@ namespace r3d {
 // per batch (0-4 vector registers spilled).  Measured at 512 / 768 threads, same code otherwise:
 // NSCP 15.8 / 12.8 ms, LopNor 13.9 / 11.0, SphereEarth 40.8 / 33.0 per 3e6 histories.
 constexpr int kPoolBlock = R3D_POOL_BLOCK;
+// Wave priority: raised while a wave is between batches (hand-off, scheduling, take) -- serial LDS
+// round trips during which it holds slots other waves may be polling for -- and lowered for the
+// phase's arithmetic: from the hand-off until the next batch's state is in registers
+// (R3D_PRIO_NARROW: around the hand-off and the take only).
+#ifndef R3D_POOL_PRIO
+#define R3D_POOL_PRIO 2
+#endif
+#define R3D_PRIO_HIGH() __builtin_amdgcn_s_setprio(R3D_POOL_PRIO)
+#define R3D_PRIO_LOW() __builtin_amdgcn_s_setprio(0)
 constexpr int kPoolWaves = kPoolBlock / 64;
 
 enum { Q_MOVE = 0, Q_COLLECT = 1, Q_RT = 2, Q_SCATTER = 3, Q_FREE = 4, Q_NUM = 5 };
@@ -503,14 +512,22 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #ifdef R3D_PHASE_TIMING
         if (lane == 0) atomicAdd(&s_stats[0][6], 1ull);
 #endif
+        R3D_PRIO_LOW();   // (an idle wave must not outrank the ones that work)
         __builtin_amdgcn_s_sleep(8);
         continue;
       }
       uint32_t wq = 0;
 #pragma unroll
       for (int j = 0; j < Q_NUM; j++) wq = (q == j) ? w[j] : wq;
+      R3D_PRIO_HIGH();
       k = q_pop(ctl, ring(q), rmask, rlog, q, lane, wq, id);
-      if (k == 0) continue;   // another wave was quicker
+#ifdef R3D_PRIO_NARROW
+      R3D_PRIO_LOW();
+#endif
+      if (k == 0) {   // another wave was quicker
+        R3D_PRIO_LOW();
+        continue;
+      }
       act = lane < k;
     }
     const bool thin = k < 64u;
@@ -520,6 +537,9 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
     int dest = Q_FREE;   // where each active lane's slot goes after this phase
     LaneStats st = {0, 0, 0, 0, 0, 0, 0};
 
+#ifndef R3D_PRIO_NARROW
+    if (q == Q_FREE) R3D_PRIO_LOW();
+#endif
     if (q == Q_FREE) {
       // ---- fresh histories: ids from the global counter, source spray (events.cpp:111-124) ----
       unsigned long long base = 0;
@@ -554,6 +574,9 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       bool live = act;   // still moving in registers
       if (act) {
         load_state(id, p, rng, meta);
+#ifndef R3D_PRIO_NARROW
+        R3D_PRIO_LOW();
+#endif
         hid = ((uint64_t)rng.id_hi << 32) | rng.id_lo;
       }
 #pragma nounroll
@@ -627,6 +650,9 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       ev.vel = 0.0, ev.face = 0, ev.flags = 0u;
       if (act) {
         load_state(id, p, rng, meta);
+#ifndef R3D_PRIO_NARROW
+        R3D_PRIO_LOW();
+#endif
         hid = ((uint64_t)rng.id_hi << 32) | rng.id_lo;
         ev.face = (int)((meta >> 1) & 7u) - 1, ev.flags = (meta >> 8) & 0xFFu;
         vel = cell_velocity(T.cells[p.cell], p.loc, p.type);
@@ -691,6 +717,9 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       const uint32_t tr0 = st.transfer, rf0 = st.reflect;
       if (act) {
         load_state(id, p, rng, meta);
+#ifndef R3D_PRIO_NARROW
+        R3D_PRIO_LOW();
+#endif
         hid = ((uint64_t)rng.id_hi << 32) | rng.id_lo;
         Pending ev;
         ev.vel = 0.0, ev.face = (int)((meta >> 1) & 7u) - 1, ev.flags = (meta >> 8) & 0xFFu;
@@ -706,6 +735,9 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
           const uint32_t draws = rng.k;
           asm volatile("" ::: "memory");   // (the second half must not reuse the first half's loads)
           load_state(id, p, rng, meta);
+#ifndef R3D_PRIO_NARROW
+        R3D_PRIO_LOW();
+#endif
           rng.k = draws;
           Pending ev2;
           ev2.vel = 0.0, ev2.face = (int)((meta >> 1) & 7u) - 1, ev2.flags = (meta >> 8) & 0xFFu;
@@ -733,7 +765,11 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #ifdef R3D_PHASE_TIMING
     const unsigned long long t_push = __builtin_readcyclecounter();
 #endif
+    R3D_PRIO_HIGH();
     q_push_all(ctl, rings, rcap, rlog, lane, act, dest, id);
+#ifdef R3D_PRIO_NARROW
+    R3D_PRIO_LOW();
+#endif
 #ifdef R3D_PHASE_TIMING
     if (lane == 0) {
       const unsigned long long t_end = __builtin_readcyclecounter();
