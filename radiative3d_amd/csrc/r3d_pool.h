@@ -63,6 +63,7 @@ constexpr int kPoolBlock = R3D_POOL_BLOCK;
 #endif
 #define R3D_PRIO_HIGH() __builtin_amdgcn_s_setprio(R3D_POOL_PRIO)
 #define R3D_PRIO_LOW() __builtin_amdgcn_s_setprio(0)
+#define R3D_PRIO_MOVE() __builtin_amdgcn_s_setprio(1)
 constexpr int kPoolWaves = kPoolBlock / 64;
 
 enum { Q_MOVE = 0, Q_COLLECT = 1, Q_RT = 2, Q_SCATTER = 3, Q_FREE = 4, Q_NUM = 5 };
@@ -575,7 +576,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       if (act) {
         load_state(id, p, rng, meta);
 #ifndef R3D_PRIO_NARROW
-        R3D_PRIO_LOW();
+        R3D_PRIO_MOVE();   // (the phase every other one waits for: above them, below a wave between batches)
 #endif
         hid = ((uint64_t)rng.id_hi << 32) | rng.id_lo;
       }
