@@ -47,3 +47,23 @@ def test_a_failing_rank_stops_the_job():
 def test_under_launcher_detection():
     assert not launch.under_launcher({})
     assert launch.under_launcher({"RANK": "0", "WORLD_SIZE": "1", "MASTER_PORT": "1"})
+
+
+def test_counter_key_follows_the_code_not_the_comments(tmp_path):
+    """The recorded PMC counters are used only while bench.kernel_source_hash() matches: the key must
+    move with the kernel's code and build flags and stay put when a comment or the spacing changes."""
+    import shutil
+    sys.path.insert(0, REPO)
+    import bench
+    src = os.path.join(REPO, "radiative3d_amd", "csrc")
+    base = bench.kernel_source_hash(src)
+    assert base == bench.kernel_source_hash()
+    work = tmp_path / "csrc"
+    shutil.copytree(src, work)
+    pool = work / "r3d_pool.h"
+    text = pool.read_text()
+    pool.write_text("// a new remark\n" + text.replace("\n", "\n   \n", 3) + "\n/* and a block\n   comment */\n")
+    assert bench.kernel_source_hash(str(work)) == base
+    pool.write_text(text.replace("constexpr int kPoolMovesThin = 32;", "constexpr int kPoolMovesThin = 33;"))
+    assert "kPoolMovesThin = 33" in pool.read_text()
+    assert bench.kernel_source_hash(str(work)) != base
