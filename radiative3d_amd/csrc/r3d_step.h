@@ -294,9 +294,9 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
       if (conv == 3) {
 #if defined(__HIP_DEVICE_COMPILE__)
         typedef __attribute__((address_space(1))) const double gdouble;   // (HBM: a global, not a FLAT, load)
-        sincos(((gdouble*)sp->spol)[k], &rs, &rc);
+        rotation(((gdouble*)sp->spol)[k], &rs, &rc);   // (an angle in (-pi, pi]: the small-argument kernels serve it)
 #else
-        sincos(sp->spol[k], &rs, &rc);
+        rotation(sp->spol[k], &rs, &rc);
 #endif
       }
       scatter_transform(p, v3(a.toa_xyz + 3 * k), rc, rs, (conv & 1) ? RAY_S : RAY_P);
