@@ -114,7 +114,10 @@ __device__ __forceinline__ unsigned q_pop(PoolCtl& ctl, lds_u16* ring, uint32_t 
   unsigned k = 0, pos = 0;
   if (lane == 0) {
     uint32_t w = seen;
-    while (w & 0xFFFFu) {
+    // (never fewer than the scheduler counted on: when another wave was quicker and left a
+    //  remainder, taking that handful would make a batch of a few lanes -- look again instead)
+    const uint32_t need = (seen & 0xFFFFu) < 64u ? (seen & 0xFFFFu) : 64u;
+    while ((w & 0xFFFFu) >= need && (w & 0xFFFFu)) {
       const uint32_t c = w & 0xFFFFu, t = c < 64u ? c : 64u;
       const uint32_t next = ((w + (t << 16)) & 0xFFFF0000u) | (c - t);
       const uint32_t was = atomicCAS(&ctl.word[q], w, next);
@@ -281,6 +284,11 @@ __device__ unsigned long long g_pool_stats[5][8];   // rows 3 / 4: cycles in the
 constexpr int kPoolMoves = R3D_POOL_MOVES;
 constexpr int kPoolMovesThin = 32;   // (bounded, so that a drained launch with carry-over still parks promptly)
 constexpr unsigned kMoveAgainLanes = R3D_POOL_MOVE_AGAIN;
+// Entries a minor phase's queue must hold before a wave goes for it.
+#ifndef R3D_POOL_MINOR_FULL
+#define R3D_POOL_MINOR_FULL 64
+#endif
+constexpr uint32_t kMinorFull = R3D_POOL_MINOR_FULL;
 
 // LDS_CELLS / LDS_SCAT: the cell records / the scatterer heads are staged in LDS (models with a few
 // dozen cells; all but models with thousands of scatterers).  The receiver tables are read through
@@ -498,9 +506,9 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         c[Q_FREE] = 0u;              // (free slots are of no use any more)
       }
       q = -1;
-      if (c[Q_RT] >= 64u) q = Q_RT;
-      else if (c[Q_COLLECT] >= 64u) q = Q_COLLECT;
-      else if (c[Q_SCATTER] >= 64u) q = Q_SCATTER;
+      if (c[Q_RT] >= kMinorFull) q = Q_RT;
+      else if (c[Q_COLLECT] >= kMinorFull) q = Q_COLLECT;
+      else if (c[Q_SCATTER] >= kMinorFull) q = Q_SCATTER;
       else if (c[Q_FREE] >= 64u) q = Q_FREE;
       else if (c[Q_MOVE] >= 64u) q = Q_MOVE;
       else {
