@@ -636,28 +636,36 @@ R3D_HD bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
 // (reference Phonon::Refraction_Bend, phonons.cpp:311-405).  Returns true if
 // transmitted.
 R3D_HD bool bend(Phonon& p, V3 fnorm, double veli, double velo) {
-  V3 fpara = in_plane_unit_perp(fnorm, p.dir);
-  V3 fparash = cross(fnorm, fpara);
-  double sini = dot(fpara, p.dir);
-  double sino = (velo / veli) * sini;
-  bool transfer;
-  double coso;
-  if (sino >= 1.0) {
-    transfer = false, sino = sini, coso = -1.0 * dot(fnorm, p.dir);
-  } else {
-    transfer = true, coso = fsqrt(1.0 - sino * sino);
-  }
-  V3 out = sino * fpara + coso * fnorm;
-  const V3 nd = out;   // (unit to rounding; see rt_apply)
+  // The reference builds unit axes fpara (in the plane of incidence, along the face), fparash (normal
+  // to that plane) and the SV axes of the incoming and outgoing ray, and expresses the particle
+  // motion in them.  None of them needs normalising:
+  //   * sin(i) fpara is the part of the direction tangential to the face, dt = d - (n.d) n, and
+  //     Snell's outgoing direction is (velo / veli) dt + cos(o) n -- no division by sin(i);
+  //   * w = n x d = sin(i) fparash, and with w in place of fparash the outgoing particle motion
+  //     comes out scaled by sin^2(i) > 0, which the projection onto (theta^, phi^) divides away.
+  // Normal incidence (w = 0) takes the reference's substitute axis (geom_r3.cpp:146-171).
+  const double cn = dot(fnorm, p.dir);
+  const V3 dt = p.dir - cn * fnorm;
+  const double ratio = velo / veli;
+  const double so2 = (ratio * ratio) * mag2(dt);   // sin^2 of the outgoing angle
+  const bool transfer = !(so2 >= 1.0);
+  // (total reflection: the same tangential part, the normal part reversed)
+  const double kt = transfer ? ratio : 1.0;
+  const double kn = transfer ? fsqrt(1.0 - so2) : -cn;
+  const V3 out = kt * dt + kn * fnorm;
   if (p.type != RAY_P) {
-    V3 pdomi = direction_of_motion(p);
-    V3 svi = cross(fparash, p.dir), svo = cross(fparash, out);
-    V3 pdomo = dot(pdomi, fparash) * fparash + dot(pdomi, svi) * svo;
-    set_pol(p, pdomo, nd);
+    V3 w = cross(fnorm, p.dir);
+    if (is_zero(w)) {
+      w = cross(fnorm, v3(1, 0, 0));
+      if (is_zero(w)) w = cross(fnorm, v3(0, 1, 0));
+    }
+    const V3 pdomi = direction_of_motion(p);
+    const V3 pdomo = dot(pdomi, w) * w + dot(pdomi, cross(w, p.dir)) * cross(w, out);
+    set_pol(p, pdomo, out);
   } else {
     p.pc = 1.0, p.ps = 0.0;                  // polout = 0
   }
-  p.dir = nd;
+  p.dir = out;
   return transfer;
 }
 
