@@ -217,6 +217,16 @@ const double* upload_doubles(r3d_engine* e, const double* src, size_t n, hipErro
   return reinterpret_cast<const double*>(e->keep(std::move(b))->p);
 }
 
+// The search guide of a cumulative table that is already in HBM (r3d_tables.h GuideCell), made there.
+const GuideCell* make_guide(r3d_engine* e, const double* d_cdf, uint64_t n, uint32_t bits, hipError_t* err) {
+  auto g = std::make_unique<DevBuf>();
+  if (hipError_t r = g->alloc_zero((size_t(1) << bits) * sizeof(GuideCell)); r != hipSuccess) *err = r;
+  GuideCell* d_guide = reinterpret_cast<GuideCell*>(e->keep(std::move(g))->p);
+  if (*err == hipSuccess)
+    if (hipError_t r = build_guide_on_device(d_cdf, n, bits, d_guide, nullptr); r != hipSuccess) *err = r;
+  return d_guide;
+}
+
 // Call f(kind, res) with the engine's cell kind and table residency as compile-time constants.
 template <class F>
 hipError_t with_kernel(const r3d_engine* e, F&& f) {
@@ -376,7 +386,7 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
     if (S.cdf[0]) {   // host-built tables: copy them in
       for (int k = 0; k < 4; k++) {
         pm.scat_ptrs[s].cdf[k] = upload_doubles(e.get(), S.cdf[k], m->n_toa, &err);
-        pm.scat_ptrs[s].guide[k] = upload_vec(e.get(), pm.scat_guide[s * 4 + k], &err);
+        pm.scat_ptrs[s].guide[k] = make_guide(e.get(), pm.scat_ptrs[s].cdf[k], m->n_toa, a.guide_bits, &err);
         st.total[k] = S.cdf[k][m->n_toa - 1];
       }
       pm.scat_ptrs[s].spol = upload_doubles(e.get(), S.spol, m->n_toa, &err);
@@ -402,13 +412,8 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
       break;
     }
     for (int k = 0; k < 4; k++) {
-      auto g = std::make_unique<DevBuf>();
-      if (hipError_t r = g->alloc_zero(((size_t(1) << a.guide_bits) + 1) * sizeof(uint32_t)); r != hipSuccess) err = r;
-      uint32_t* d_guide = reinterpret_cast<uint32_t*>(e->keep(std::move(g))->p);
-      if (err == hipSuccess)
-        if (hipError_t r = build_guide_on_device(d_cdf[k], m->n_toa, a.guide_bits, d_guide, nullptr); r != hipSuccess)
-          err = r;
-      pm.scat_ptrs[s].cdf[k] = d_cdf[k], pm.scat_ptrs[s].guide[k] = d_guide;
+      pm.scat_ptrs[s].cdf[k] = d_cdf[k];
+      pm.scat_ptrs[s].guide[k] = make_guide(e.get(), d_cdf[k], m->n_toa, a.guide_bits, &err);
       pm.scat_head[s].total[k] = st.total[k];
     }
     pm.scat_ptrs[s].spol = d_spol;
@@ -461,13 +466,8 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
       for (int k = 0; k < 3; k++) a.src_total[k] = tot[k], a.src_whole[k] = (acc += tot[k]);
     }
     for (int k = 0; k < 3; k++) e->src_whole[k] = a.src_whole[k];
-    for (int k = 0; k < 3 && err == hipSuccess; k++) {
-      auto g = std::make_unique<DevBuf>();
-      if (hipError_t r = g->alloc_zero(((size_t(1) << a.guide_bits) + 1) * sizeof(uint32_t)); r != hipSuccess) err = r;
-      uint32_t* d_guide = reinterpret_cast<uint32_t*>(e->keep(std::move(g))->p);
-      if (err == hipSuccess) err = build_guide_on_device(d_src[k], m->n_toa, a.guide_bits, d_guide, nullptr);
-      a.src_guide[k] = d_guide;
-    }
+    for (int k = 0; k < 3 && err == hipSuccess; k++)
+      a.src_guide[k] = make_guide(e.get(), d_src[k], m->n_toa, a.guide_bits, &err);
     if (err == hipSuccess) err = hipDeviceSynchronize();
   }
   a.seis_scan = upload_vec(e.get(), pm.seis_scan, &err);

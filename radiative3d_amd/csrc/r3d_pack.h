@@ -27,8 +27,8 @@ struct PackedModel {
   std::vector<SeisScan> seis_scan;
   std::vector<SeisHit> seis_hit;
   std::vector<uint32_t> grid_start, grid_items;
-  std::vector<std::vector<uint32_t>> src_guide;    // [3]
-  std::vector<std::vector<uint32_t>> scat_guide;   // [n_scat * 4]
+  std::vector<std::vector<GuideCell>> src_guide;    // [3]   (host emulation only: the engine builds its own in HBM)
+  std::vector<std::vector<GuideCell>> scat_guide;   // [n_scat * 4]
   KArgs args;                        // pointers refer to the vectors above / the model
   size_t cell_bytes() const {
     return cyl.size() * sizeof(CellCyl) + tet.size() * sizeof(CellTet) + sph.size() * sizeof(CellSph);
@@ -132,6 +132,20 @@ inline void build_guide(const double* cdf, uint64_t n, uint32_t bits, std::vecto
     const double r = total * ((double)j / (double)G);
     while (k < n - 1 && !(r <= cdf[k])) k++;
     g[j] = (uint32_t)k;
+  }
+}
+// ... and its cells (r3d_tables.h GuideCell): the bracket's ends and its first entries.
+inline void build_guide_cells(const double* cdf, uint64_t n, uint32_t bits, std::vector<GuideCell>& cells) {
+  std::vector<uint32_t> g;
+  build_guide(cdf, n, bits, g);
+  const uint64_t G = 1ull << bits;
+  cells.resize(G);
+  for (uint64_t j = 0; j < G; j++) {
+    GuideCell& c = cells[j];
+    c.k1 = g[j], c.k2 = g[j + 1];
+    const bool direct = c.k2 - c.k1 <= (uint32_t)kGuideVals;
+    for (int i = 0; i < kGuideVals; i++)
+      c.c[i] = direct ? cdf[(uint64_t)c.k1 + i < c.k2 ? (uint64_t)c.k1 + i : c.k2] : cdf[guide_pivot(c.k1, c.k2, i)];
   }
 }
 inline uint32_t guide_bits_for(uint64_t n_toa) {
@@ -332,8 +346,11 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm, bool for_engine
     for (int k = 0; k < 4; k++) {
       pm.scat_ptrs[s].cdf[k] = S.cdf[k];
       pm.scat_head[s].total[k] = S.cdf[k][m.n_toa - 1];
-      build_guide(S.cdf[k], m.n_toa, a.guide_bits, pm.scat_guide[s * 4 + k]);
-      pm.scat_ptrs[s].guide[k] = pm.scat_guide[s * 4 + k].data();
+      pm.scat_ptrs[s].guide[k] = nullptr;
+      if (!for_engine) {   // (the engine makes the guides in HBM, from the tables it has copied in)
+        build_guide_cells(S.cdf[k], m.n_toa, a.guide_bits, pm.scat_guide[s * 4 + k]);
+        pm.scat_ptrs[s].guide[k] = pm.scat_guide[s * 4 + k].data();
+      }
     }
     pm.scat_ptrs[s].spol = S.spol;
   }
@@ -363,7 +380,7 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm, bool for_engine
     a.src_cdf[k] = m.source.cdf[k];
     a.src_total[k] = m.source.cdf[0] ? m.source.cdf[k][m.n_toa - 1] : 0.0;
     if (!for_engine) {
-      build_guide(m.source.cdf[k], m.n_toa, a.guide_bits, pm.src_guide[k]);
+      build_guide_cells(m.source.cdf[k], m.n_toa, a.guide_bits, pm.src_guide[k]);
       a.src_guide[k] = pm.src_guide[k].data();
     }
     a.src_whole[k] = m.source.whole_cdf[k];

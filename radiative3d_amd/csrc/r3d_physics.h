@@ -682,48 +682,58 @@ R3D_HD uint64_t sample_cdf(const double* __restrict__ cdf, uint64_t n, double u)
   }
   return k2;
 }
-// The same draw with a search guide (r3d_pack.h build_guide): identical result.  The guide narrows
-// the search to a bracket [k1, k2] of a few entries (about four on average); the bracket's first
-// eight entries are then fetched AT ONCE and the answer is k1 + (how many of them lie below r) --
-// the table is non-decreasing, so that is the smallest k with r <= cdf[k], what the bisection
-// finds -- instead of two or three probes that each wait for the one before: the draw costs two
-// dependent memory round trips (guide, bracket) where the bisection cost three to four.  Only
-// a bracket longer than eight entries falls back to bisecting its remainder.
-R3D_HD uint64_t sample_cdf_guided(const double* __restrict__ cdf_, const uint32_t* __restrict__ guide_,
+// The same draw with a search guide (r3d_tables.h GuideCell, r3d_pack.h build_guide_cells):
+// identical result.  The guide cell of the draw holds the ends [k1, k2] of a bracket of a few
+// entries (about five on average) AND, for a bracket of up to seven, its entries: the answer --
+// k1 + (how many of them lie below r): the table is non-decreasing, so that is the smallest k with
+// r <= cdf[k], what the bisection finds -- follows from ONE 64-byte fetch.  A longer bracket's cell
+// holds seven pivots instead; they leave an eighth of the bracket, whose first eight entries are
+// fetched at once: two dependent round trips for brackets of up to 64 entries, where a bisection
+// of the whole table takes twenty and one of the bracket three to six.
+R3D_HD uint64_t sample_cdf_guided(const double* __restrict__ cdf_, const GuideCell* __restrict__ guide_,
                                   uint32_t bits, double total, double u) {
 #if defined(__HIP_DEVICE_COMPILE__)
   // the tables live in HBM: say so, or pointers that were themselves loaded from memory become
   // FLAT loads (which also count against the LDS counter and wait with it)
   typedef __attribute__((address_space(1))) const double gdouble;
-  typedef __attribute__((address_space(1))) const uint32_t gu32;
+  typedef __attribute__((address_space(1))) const GuideCell gcell;
   gdouble* cdf = (gdouble*)cdf_;
-  gu32* guide = (gu32*)guide_;
+  gcell* guide = (gcell*)guide_;
 #else
   const double* cdf = cdf_;
-  const uint32_t* guide = guide_;
+  const GuideCell* guide = guide_;
 #endif
   const double r = total * u;
   uint32_t j = (uint32_t)(u * (double)(1u << bits));
   if (j > (1u << bits) - 1u) j = (1u << bits) - 1u;
-  uint64_t k1 = guide[j];
-  const uint64_t k2 = guide[j + 1];
+  const GuideCell g = guide[j];
+  uint64_t k1 = g.k1;
+  const uint64_t k2 = g.k2;
+  const bool direct = k2 - k1 <= (uint64_t)kGuideVals;
+  uint32_t below = 0;   // how many of the cell's values lie below r (entries, or pivots)
+#pragma unroll
+  for (int i = 0; i < kGuideVals; i++) below += ((direct ? k1 + i < k2 : true) && !(r <= g.c[i])) ? 1u : 0u;
+  if (direct) return k1 + below;
+  // a long bracket: the pivots leave an eighth of it, [lo, hi]; its first eight entries at once
+  uint64_t lo = below ? guide_pivot(k1, k2, (int)below - 1) + 1 : k1;
+  const uint64_t hi = below < (uint32_t)kGuideVals ? guide_pivot(k1, k2, (int)below) : k2;
   constexpr int kAtOnce = 8;
   double c[kAtOnce];
 #pragma unroll
-  for (int i = 0; i < kAtOnce; i++) c[i] = cdf[(k1 + i < k2) ? k1 + i : k2];
-  uint32_t below = 0;
+  for (int i = 0; i < kAtOnce; i++) c[i] = cdf[(lo + i < hi) ? lo + i : hi];
+  uint32_t more = 0;
 #pragma unroll
-  for (int i = 0; i < kAtOnce; i++) below += (k1 + i < k2 && !(r <= c[i])) ? 1u : 0u;
-  k1 += below;
-  if (below == kAtOnce) {   // all eight below r and the bracket goes on: bisect what is left
-    uint64_t hi = k2;
-    while (k1 != hi) {
-      const uint64_t k = (k1 + hi) >> 1;
-      if (r <= cdf[k]) hi = k;
-      else k1 = k + 1;
+  for (int i = 0; i < kAtOnce; i++) more += (lo + i < hi && !(r <= c[i])) ? 1u : 0u;
+  lo += more;
+  if (more == kAtOnce) {   // (brackets beyond 64 entries: bisect what is left)
+    uint64_t top = hi;
+    while (lo != top) {
+      const uint64_t k = (lo + top) >> 1;
+      if (r <= cdf[k]) top = k;
+      else lo = k + 1;
     }
   }
-  return k1;
+  return lo;
 }
 R3D_HD int sample_small(const double* cdf, int n, double u) {
   const double r = cdf[n - 1] * u;

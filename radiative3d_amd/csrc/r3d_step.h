@@ -81,7 +81,7 @@ R3D_HD void spray(const KArgs& a, Phonon& p, Rng& rng) {
   // (selects, not a[rt3]: a dynamic index into the by-value argument block would
   //  make the compiler copy the arrays to scratch memory)
   const double* cdf = rt3 == 0 ? a.src_cdf[0] : rt3 == 1 ? a.src_cdf[1] : a.src_cdf[2];
-  const uint32_t* guide = rt3 == 0 ? a.src_guide[0] : rt3 == 1 ? a.src_guide[1] : a.src_guide[2];
+  const GuideCell* guide = rt3 == 0 ? a.src_guide[0] : rt3 == 1 ? a.src_guide[1] : a.src_guide[2];
   const double total = rt3 == 0 ? a.src_total[0] : rt3 == 1 ? a.src_total[1] : a.src_total[2];
   uint64_t k = sample_cdf_guided(cdf, guide, a.guide_bits, total, rng_draw(rng, rng_key(a.seed)));
 #endif

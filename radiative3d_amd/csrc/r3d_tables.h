@@ -71,6 +71,24 @@ struct RhoLin {       // density side table for tetra cells
   double g[3], c;
 };
 
+// One cell of a cumulative table's search guide: a draw u in [j / G, (j + 1) / G), G = 2^guide_bits,
+// has its answer inside [k1, k2] (k1 = smallest k with total j / G <= cdf[k], k2 the same for
+// j + 1).  c[] holds, for a bracket of up to seven entries -- 97 % of the draws --, the table's
+// entries k1 .. k2 - 1: the draw is decided by this ONE 64-byte fetch.  For a longer bracket it
+// holds seven pivots, the entries at guide_pivot(k1, k2, i): they cut the bracket into eighths, and
+// one further fetch of eight neighbouring entries finishes all but the longest (a lane in a long
+// bracket is what the whole wave waits for: bisecting it took three to six dependent round trips).
+struct alignas(64) GuideCell {
+  uint32_t k1, k2;
+  double c[7];
+};
+static_assert(sizeof(GuideCell) == 64, "a guide cell is one 64-byte sector");
+constexpr int kGuideVals = 7;
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint64_t guide_pivot(uint64_t k1, uint64_t k2, int i) { return k1 + (((uint64_t)(i + 1) * (k2 - k1)) >> 3); }
+
 // ---- scatterers ------------------------------------------------------------
 struct ScatHead {     // small per-scatterer record, staged in LDS
   double mfp[2];
@@ -80,7 +98,7 @@ struct ScatHead {     // small per-scatterer record, staged in LDS
 struct ScatPtrs {     // HBM-resident tables of one scatterer
   const double* cdf[4];
   const double* spol;
-  const uint32_t* guide[4];  // search guides of the four CDFs (see sample_cdf_guided)
+  const GuideCell* guide[4]; // search guides of the four CDFs (see sample_cdf_guided)
 };
 
 // ---- seismometers ----------------------------------------------------------
@@ -119,9 +137,9 @@ struct KArgs {
   uint64_t n_toa;
   const double* toa_xyz;     // n_toa x 3, theta already nudged
   const double* src_cdf[3];
-  const uint32_t* src_guide[3];
+  const GuideCell* src_guide[3];
   double src_total[3];       // src_cdf[k][n_toa-1]
-  uint32_t guide_bits;       // guides have 2^guide_bits + 1 entries
+  uint32_t guide_bits;       // guides have 2^guide_bits cells
   uint32_t pad0_;
   double src_whole[3];
   double src_loc[3];

@@ -7,6 +7,8 @@
 
 #include <cstdint>
 
+#include "r3d_tables.h"
+
 namespace r3d {
 
 // Fill d_cdf[0..3] (GPP, GPS, GSP, GSS; cumulative, n entries each) and d_spol (n) for the
@@ -28,8 +30,8 @@ hipError_t build_toa_xyz_on_device(const double* d_toa, uint64_t n, double min_t
 hipError_t build_source_tables(const double moment[6], const double* d_toa, uint64_t n, double* d_cdf[3],
                                double totals[3], hipStream_t stream);
 
-// guide[j] = smallest k with total * j / 2^bits <= cdf[k], j = 0 .. 2^bits (asynchronous).
-hipError_t build_guide_on_device(const double* d_cdf, uint64_t n, uint32_t bits, uint32_t* d_guide,
+// The 2^bits guide cells of a cumulative table (r3d_tables.h GuideCell; asynchronous).
+hipError_t build_guide_on_device(const double* d_cdf, uint64_t n, uint32_t bits, GuideCell* d_guide,
                                  hipStream_t stream);
 
 }  // namespace r3d

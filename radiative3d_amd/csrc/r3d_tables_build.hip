@@ -160,12 +160,9 @@ __global__ __launch_bounds__(kThreads) void add_offsets(double* const* __restric
   }
 }
 
-// guide[j] = smallest k with total * (j / G) <= cdf[k], j = 0..G (r3d_pack.h build_guide).
-__global__ __launch_bounds__(kThreads) void guide_kernel(const double* __restrict__ cdf, uint64_t n, uint32_t bits,
-                                                         uint32_t* __restrict__ guide) {
-  const uint64_t G = 1ull << bits;
-  const uint64_t j = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (j > G) return;
+// Guide cell j (r3d_tables.h GuideCell; r3d_pack.h build_guide_cells): k1 / k2 = smallest k with
+// total * (j / G) resp. total * ((j + 1) / G) <= cdf[k], and the table's entries from k1 on.
+__device__ uint64_t guide_bound(const double* __restrict__ cdf, uint64_t n, uint64_t j, uint64_t G) {
   const double r = cdf[n - 1] * ((double)j / (double)G);
   uint64_t lo = 0, hi = n - 1;   // first k in [0, n-1] with r <= cdf[k], else n-1
   while (lo < hi) {
@@ -173,7 +170,20 @@ __global__ __launch_bounds__(kThreads) void guide_kernel(const double* __restric
     if (r <= cdf[mid]) hi = mid;
     else lo = mid + 1;
   }
-  guide[j] = (uint32_t)lo;
+  return lo;
+}
+__global__ __launch_bounds__(kThreads) void guide_kernel(const double* __restrict__ cdf, uint64_t n, uint32_t bits,
+                                                         GuideCell* __restrict__ guide) {
+  const uint64_t G = 1ull << bits;
+  const uint64_t j = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (j >= G) return;
+  GuideCell c;
+  const uint64_t k1 = guide_bound(cdf, n, j, G), k2 = guide_bound(cdf, n, j + 1, G);
+  c.k1 = (uint32_t)k1, c.k2 = (uint32_t)k2;
+#pragma unroll
+  for (int i = 0; i < kGuideVals; i++)
+    c.c[i] = (k2 - k1 <= (uint64_t)kGuideVals) ? cdf[k1 + i < k2 ? k1 + i : k2] : cdf[guide_pivot(k1, k2, i)];
+  guide[j] = c;
 }
 
 // ---- take-off set -------------------------------------------------------------------------
@@ -337,10 +347,10 @@ hipError_t build_scatterer_tables(const double het[6], double psdf_numer, const 
   return err;
 }
 
-hipError_t build_guide_on_device(const double* d_cdf, uint64_t n, uint32_t bits, uint32_t* d_guide,
+hipError_t build_guide_on_device(const double* d_cdf, uint64_t n, uint32_t bits, GuideCell* d_guide,
                                  hipStream_t stream) {
   const uint64_t G = 1ull << bits;
-  guide_kernel<<<(uint32_t)((G + 1 + kThreads - 1) / kThreads), kThreads, 0, stream>>>(d_cdf, n, bits, d_guide);
+  guide_kernel<<<(uint32_t)((G + kThreads - 1) / kThreads), kThreads, 0, stream>>>(d_cdf, n, bits, d_guide);
   return hipGetLastError();
 }
 

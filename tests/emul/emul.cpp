@@ -113,3 +113,20 @@ extern "C" double r3d_emul_math(int which, double x, double y) {
   }
   return 0.0 / 0.0;
 }
+
+// Inverse-CDF draws two ways (r3d_physics.h): out_guided[i] from the search guide's cells
+// (sample_cdf_guided), out_plain[i] by bisecting the whole table (sample_cdf) -- the reference's
+// ProbDist::GetRandomIndex.  bits = 0: the width the engine would choose for a table of n entries.
+extern "C" void r3d_emul_sample_cdf(const double* cdf, uint64_t n, uint32_t bits, const double* u, uint64_t m,
+                                    uint64_t* out_guided, uint64_t* out_plain, uint64_t* longest_bracket) {
+  if (!bits) bits = guide_bits_for(n);
+  std::vector<GuideCell> cells;
+  build_guide_cells(cdf, n, bits, cells);
+  uint64_t longest = 0;
+  for (const GuideCell& c : cells) longest = std::max<uint64_t>(longest, c.k2 - c.k1);
+  if (longest_bracket) *longest_bracket = longest;
+  for (uint64_t i = 0; i < m; i++) {
+    out_guided[i] = sample_cdf_guided(cdf, cells.data(), bits, cdf[n - 1], u[i]);
+    out_plain[i] = sample_cdf(cdf, n, u[i]);
+  }
+}

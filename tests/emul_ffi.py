@@ -29,6 +29,9 @@ def lib():
         L.r3d_emul_face_class.argtypes = [C.POINTER(_ffi.ModelDesc), C.c_int, C.c_int]
         L.r3d_emul_class_from_corners.restype = C.c_uint32
         L.r3d_emul_class_from_corners.argtypes = [C.POINTER(C.c_double), C.c_int]
+        L.r3d_emul_sample_cdf.restype = None
+        L.r3d_emul_sample_cdf.argtypes = [C.POINTER(C.c_double), C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.c_uint64,
+                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.r3d_emul_math.restype = C.c_double
         L.r3d_emul_math.argtypes = [C.c_int, C.c_double, C.c_double]
         _lib = L
@@ -73,3 +76,18 @@ def face_class(model, cell, face):
 def math_fn(which, x, y=0.0):
     """One of the kernel's lean elementary functions (tests/emul/emul.cpp r3d_emul_math)."""
     return float(lib().r3d_emul_math(which, float(x), float(y)))
+
+
+def sample_cdf_both_ways(cdf, u, bits=0):
+    """Indices drawn from the cumulative table `cdf` for the uniforms `u`: through the search guide's
+    cells and by bisecting the whole table; and the longest bracket of the guide."""
+    import numpy as np
+    cdf = np.ascontiguousarray(cdf, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    a = np.empty(u.size, dtype=np.uint64)
+    b = np.empty(u.size, dtype=np.uint64)
+    longest = C.c_uint64(0)
+    dp, up = C.POINTER(C.c_double), C.POINTER(C.c_uint64)
+    lib().r3d_emul_sample_cdf(cdf.ctypes.data_as(dp), cdf.size, bits, u.ctypes.data_as(dp), u.size,
+                              a.ctypes.data_as(up), b.ctypes.data_as(up), C.byref(longest))
+    return a, b, int(longest.value)
