@@ -29,12 +29,15 @@ HOST_HDR := $(wildcard $(HOSTDIR)/*.hpp) include/r3d.h include/r3d_host.h
 ENGINE_SRC := $(CSRC)/r3d_engine.hip $(CSRC)/r3d_tables_build.hip
 ENGINE_HDR := $(wildcard $(CSRC)/*.h) include/r3d.h
 
-.PHONY: default all host engine oracle cli clean
+.PHONY: default all host engine repro oracle cli clean
 default: all
-all: host engine oracle cli
+all: host engine repro oracle cli
 
 host: $(LIBDIR)/libr3d_host.so
 engine: $(LIBDIR)/libr3d_hip.so
+# the same engine with every wave-voted series choice taken out (r3d_math.h all_lanes): a history's
+# result is then bit-defined by (model, seed, id); loaded under R3D_REPRODUCIBLE=1
+repro: $(LIBDIR)/libr3d_hip_repro.so
 oracle: oracle/libr3d_oracle.so
 cli: main
 
@@ -50,6 +53,10 @@ $(LIBDIR)/libr3d_host.so: $(HOST_SRC) $(HOST_HDR)
 $(LIBDIR)/libr3d_hip.so: $(ENGINE_SRC) $(ENGINE_HDR)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -pthread -o $@ $(ENGINE_SRC)
+
+$(LIBDIR)/libr3d_hip_repro.so: $(ENGINE_SRC) $(ENGINE_HDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -DR3D_REPRODUCIBLE -shared -pthread -o $@ $(ENGINE_SRC)
 
 oracle/libr3d_oracle.so: oracle/r3d_oracle.cpp oracle/philox.h include/r3d.h
 	$(CXX) $(CXXFLAGS) -shared -o $@ oracle/r3d_oracle.cpp

@@ -16,8 +16,8 @@ equal --gpus, and `n_gpus` in the output is the process group's size.
 
 A step = one pass of the hot path (GenerateEventPhonon + Propagate) over a fresh batch of
 history ids per GPU; tables are resident in HBM before the timed region; the per-receiver bins
-stay in HBM and are summed over ranks with one RCCL all-reduce per buffer inside the timed
-region (weak scaling: every rank runs the same count).  Rank 0 prints one JSON line.
+stay in HBM and are summed over ranks with one RCCL all-reduce per buffer at the end of the job,
+inside the timed region (weak scaling: every rank runs the same count).  Rank 0 prints one JSON line.
 """
 import argparse
 import hashlib
@@ -36,7 +36,7 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0
 N_SIMD = 256 * 4
 MAX_CLOCK_GHZ = 2.4
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def workloads():
@@ -205,6 +205,9 @@ def parse_args(argv=None):
     ap.add_argument("--self-contained", action="store_true",
                     help="every step a self-contained launch that drains its own stragglers "
                          "(default: steps chained, one flush launch at the end of the timed region)")
+    ap.add_argument("--reduce-per-step", action="store_true",
+                    help="all-reduce every step's bins (default: every launch adds into the rank's own block "
+                         "and the blocks are summed over ranks once, after the flush)")
     ap.add_argument("--timed-only", action="store_true",
                     help="stop after the timed region: no single-launch, device-table, CPU-baseline or envelope "
                          "legs (profiling passes: every dispatch is then a step or flush launch of the chain)")
@@ -250,7 +253,7 @@ def main():
     import torch
     import torch.distributed as dist
     from radiative3d_amd import Engine, Model
-    from radiative3d_amd.parallel import DeviceResult, DeviceVolume
+    from radiative3d_amd.parallel import DeviceResult, DeviceVolume, shard_range
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
@@ -270,10 +273,11 @@ def main():
     seed = 0x5EED
 
     # ---- build the model (host) and put it in HBM: not timed --------------
-    # One GPU: host-built tables, the ones the CPU baseline / envelope check also runs on.
-    # Several ranks: every rank lets its engine evaluate the tables in HBM (--device-tables)
-    # instead of N processes each spending the host's cores on the same GBs of tables.
-    model_args = wl["args"](args.toa_degree) + (["--device-tables"] if world > 1 else [])
+    # Every rank lets its engine evaluate the tables in HBM (--device-tables), at every N: the
+    # points of a scaling curve then run on tables of one provenance, and N processes do not
+    # each spend the host's cores on the same GBs of tables.  (The CPU baseline builds its own
+    # host tables further down; the two builders agree to 1e-12, tests/test_device_tables.py.)
+    model_args = wl["args"](args.toa_degree) + ["--device-tables"]
     t0 = time.perf_counter()
     model = Model(model_args)
     t_build = time.perf_counter() - t0
@@ -281,8 +285,8 @@ def main():
     engine = Engine(model, device=local_rank)
     t_upload = time.perf_counter() - t0
     note(f"{args.config}: model built in {t_build:.1f} s, tables in HBM after {t_upload:.1f} s")
-    result = DeviceResult(model, device)
-    step_res = DeviceResult(model, device)
+    result = DeviceResult(model, device)     # this rank's running total; the job's after the one all-reduce
+    step_res = DeviceResult(model, device)   # (--reduce-per-step only)
     volume = None
     if wl["volume"]:
         volume = DeviceVolume(engine, device=device, **wl["volume"])
@@ -295,26 +299,29 @@ def main():
     # flush launch after the last step runs the stragglers to their end.  Results do not
     # depend on it.  --self-contained times lone launches instead; the default run reports
     # them too, as `single_launch`.
-    def step(i, launches=None):
-        # every step and every rank gets its own disjoint id range; a step ends with the
-        # whole-job bins of that launch (summed over ranks) added to the running total
-        first = (i * world + rank) * n
-        step_res.zero_()
-        engine.run_device(n, first, seed, *step_res.pointers(), stream=stream.cuda_stream,
-                          carry=None if args.self_contained else "carry")
+    #
+    # Reduction: every launch ADDS into this rank's result block in HBM, and the blocks are summed
+    # over ranks ONCE, after the flush, inside the timed region -- the reference's replicas +
+    # combine (scripts/do-parallel.sh:23-29, vis/seisplot/combine.m:26-33).  --reduce-per-step
+    # all-reduces every step's block instead (a rank-synchronising point every step).
+    def launch(count, first, carry, launches):
+        target = step_res if args.reduce_per_step else result
+        if args.reduce_per_step:
+            step_res.zero_()
+        engine.run_device(count, first, seed, *target.pointers(), stream=stream.cuda_stream, carry=carry)
         if launches is not None:
             launches.append(engine.launch_count())
-        step_res.allreduce_()     # no-op at world == 1
-        result.add_(step_res)
+        if args.reduce_per_step:
+            step_res.allreduce_()     # no-op without a process group
+            result.add_(step_res)
+
+    def step(i, launches=None):
+        # every step and every rank gets its own disjoint id range
+        launch(n, (i * world + rank) * n, None if args.self_contained else "carry", launches)
 
     def flush(launches=None):
         if not args.self_contained:
-            step_res.zero_()
-            engine.run_device(0, 0, seed, *step_res.pointers(), stream=stream.cuda_stream, carry="final")
-            if launches is not None:
-                launches.append(engine.launch_count())
-            step_res.allreduce_()
-            result.add_(step_res)
+            launch(0, 0, "final", launches)
 
     def sync():
         if launched:
@@ -324,6 +331,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     flush()
+    if not args.reduce_per_step:
+        result.allreduce_()
     sync()
     result.zero_()
     if volume is not None:
@@ -336,6 +345,8 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i, step_launches)
     flush(flush_launches)
+    if not args.reduce_per_step:
+        result.allreduce_()               # the one reduction of the job's bins (RCCL over xGMI)
     t_vol0 = time.perf_counter()
     if volume is not None:   # the job's event grid: summed over ranks once, at the end
         torch.cuda.synchronize()          # (so that the reduction is timed on its own)
@@ -347,12 +358,22 @@ def main():
     volume_reduce_s = (t1 - t_vol0) if volume is not None else None
     step_ms = [ms for ms in (engine.kernel_ms(k) for k in step_launches) if ms >= 0]   # (the 64 most recent)
     flush_ms = [ms for ms in (engine.kernel_ms(k) for k in flush_launches) if ms >= 0]
+    per_rank = None
     if launched:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's own kernel times, so that an imbalance between the GPUs is visible
+        mine = torch.tensor([min(step_ms, default=-1.0), max(step_ms, default=-1.0),
+                             sum(step_ms) / max(1, len(step_ms)), sum(flush_ms)],
+                            dtype=torch.float64, device=device)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        per_rank = [dict(zip(("step_ms_min", "step_ms_max", "step_ms_mean", "flush_ms"),
+                             (round(float(v), 4) for v in row))) for row in everyone]
     note(f"timed {args.steps} steps in {elapsed:.3f} s")
 
+    line = None
     if rank == 0:
         res = result.to_result()
         total = res.events["generated"]            # histories summed over ranks and passes
@@ -404,6 +425,8 @@ def main():
                     "surface arrival, cell records from memory) / measured launch time; not HBM traffic -- the "
                     "receiver hash and the LDS-resident tables never move most of these bytes, hence > peak"}
 
+        reduction = ("one all-reduce of every step's bins" if args.reduce_per_step else
+                     "one all-reduce of the bins at the end of the job (inside the timed region)")
         line = {
             "metric": "phonon-histories/sec", "value": value, "unit": "histories/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -414,18 +437,22 @@ def main():
                        "name": args.config,
                        "histories_per_gpu_per_step": n, "toa_degree": args.toa_degree,
                        "cells": model.n_cells, "scatterers": model.n_scatterers,
-                       "parallelism": f"history-id shards x{world}, one all-reduce of the bins per step; "
+                       "parallelism": f"history-id shards x{world}, {reduction}; "
                                       + ("every step a self-contained launch" if args.self_contained else
                                          "steps chained (unfinished histories carried into the next "
                                          "step's launch, one flush launch at the end, inside the timed region)")},
             "roofline": roofline, "contract_bytes": contract,
-            "host": {"model_build_s": round(t_build, 2), "table_upload_s": round(t_upload, 2),
-                     "tables": "device-built" if world > 1 else "host-built"},
+            "collective": {"backend": dist.get_backend() if launched else None,
+                           "process_group": bool(launched), "per_rank_kernel_ms": per_rank},
+            "host": {"model_build_s": round(t_build, 2), "engine_create_s": round(t_upload, 2),
+                     "tables": "device-built"},
         }
         if volume is not None:
             line["volume"] = {"shape": list(volume.shape), "bytes": volume.counters.numel() * 4,
                               "events_binned": volume.total(),
-                              "reduce_over_ranks_s": volume_reduce_s, "saturated_cells": volume.saturated}
+                              "reduce_over_ranks_s": volume_reduce_s, "saturated_cells": volume.saturated,
+                              "reduced_as": None if volume.widened is None else
+                                            ("int64, saturating" if volume.widened else "int32 in place")}
 
         if args.timed_only:
             line["cpu_baseline"] = None
@@ -444,53 +471,61 @@ def main():
                                      "note": "median of 3 self-contained launches (each drains its own "
                                              "stragglers), this rank only"}
 
-        # the same model with every table evaluated in HBM (--device-tables): what a production
-        # run pays before its first history
-        if not args.timed_only:
+    # ---- CPU baseline and envelope agreement (any world size) --------------------------------
+    # Rank 0 times the oracle on its host cores, on host-built tables of the same model; the GPU
+    # side of the envelope check is then run by ALL ranks together -- each batch's id range
+    # sharded over the ranks, the bins all-reduced -- so the figure also covers the sharded path.
+    do_cpu = not args.timed_only and not args.no_cpu_baseline
+    if do_cpu:
+        plan = torch.zeros(2, dtype=torch.int64, device=device)   # batches, histories per batch
+        cpu_parts = None
+        if rank == 0:
+            note("building host tables and timing the CPU baseline (oracle) ...")
             t0 = time.perf_counter()
-            dev_model = Model(wl["args"](args.toa_degree) + ["--device-tables"])
-            t_dev_host = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            dev_engine = Engine(dev_model, device=local_rank)
-            t_dev_engine = time.perf_counter() - t0
-            dev_engine.close()
-            line["host"]["device_tables"] = {"model_build_s": round(t_dev_host, 2),
-                                             "engine_create_s": round(t_dev_engine, 2)}
+            host_model = Model(wl["args"](args.toa_degree))
+            line["host"]["host_tables_model_build_s"] = round(time.perf_counter() - t0, 2)
+            line["cpu_baseline"], cpu_parts, per_thread = cpu_baseline(host_model)
+            plan[0], plan[1] = len(cpu_parts), per_thread
+        if launched:
+            dist.broadcast(plan, src=0)
+        n_batches, per_batch = int(plan[0].item()), int(plan[1].item())
 
-        if args.timed_only:
-            pass
-        elif not args.no_cpu_baseline and world == 1:
-            note("timing the CPU baseline (oracle) ...")
-            line["cpu_baseline"], cpu_parts, per_thread = cpu_baseline(model)
-            note("envelope check: GPU batches ...")
-            # the GPU sample mirrors the CPU sample's batch structure (same count, same size), on
-            # ids beyond every range used above: two independent samples of 1e7 histories each
-            # when the CPU got that far
-
-            def gpu_batches(base):
-                g_e, g_c = [], []
-                for b in range(len(cpu_parts)):   # untimed
-                    step_res.zero_()
-                    engine.run_device(per_thread, base + b * per_thread, seed, *step_res.pointers(),
-                                      stream=stream.cuda_stream)
-                    torch.cuda.synchronize()
+        def gpu_batches(base):
+            g_e, g_c = [], []
+            for b in range(n_batches):   # untimed
+                lo, hi = shard_range(per_batch, rank, world)
+                step_res.zero_()
+                engine.run_device(hi - lo, base + b * per_batch + lo, seed, *step_res.pointers(),
+                                  stream=stream.cuda_stream)
+                step_res.allreduce_()
+                torch.cuda.synchronize()
+                if rank == 0:
                     r = step_res.to_result()
-                    g_e.append(r.energy / per_thread), g_c.append(r.counts)
-                return batch_moments(g_e, g_c)
+                    g_e.append(r.energy / per_batch), g_c.append(r.counts)
+            return batch_moments(g_e, g_c) if rank == 0 else None
 
-            n_side = per_thread * len(cpu_parts)
-            gpu_mom = gpu_batches(1 << 44)
-            cpu_mom = batch_moments([p.energy / per_thread for p in cpu_parts], [p.counts for p in cpu_parts])
+        note("envelope check: GPU batches ...")
+        # the GPU sample mirrors the CPU sample's batch structure (same count, same size), on ids
+        # beyond every range used above: two independent samples of 1e7 histories each when the
+        # CPU got that far
+        gpu_mom = gpu_batches(1 << 44)
+        # calibration of the statistic: the same comparison with the CPU sample replaced by a
+        # second independent GPU sample (both sides the same code); with few batches and
+        # heavy-tailed bins it need not sit at exactly 1
+        gpu_mom2 = gpu_batches(1 << 52)
+        if rank == 0:
+            n_side = per_batch * n_batches
+            cpu_mom = batch_moments([p.energy / per_batch for p in cpu_parts], [p.counts for p in cpu_parts])
             line["envelope"] = envelope_agreement(gpu_mom, cpu_mom, n_side, n_side)
-            # calibration of the statistic: the same comparison with the CPU sample replaced by a
-            # second independent GPU sample (both sides the same code); with few batches and
-            # heavy-tailed bins it need not sit at exactly 1
-            twin = envelope_agreement(gpu_mom, gpu_batches(1 << 52), n_side, n_side)
+            line["envelope"]["gpu_side"] = (f"device-built tables, each batch sharded over {world} rank(s) and "
+                                            "all-reduced" if launched else "device-built tables, one engine")
+            line["envelope"]["cpu_side"] = "host-built tables, oracle/r3d_oracle.cpp"
+            twin = envelope_agreement(gpu_mom, gpu_mom2, n_side, n_side)
             line["envelope"]["rms_sigma_gpu_vs_gpu_same_batches"] = twin["rms_sigma"]
-        else:
-            line["cpu_baseline"] = None
-        if not args.timed_only:
-            print(json.dumps(line), flush=True)
+    elif rank == 0 and not args.timed_only:
+        line["cpu_baseline"] = None
+    if rank == 0 and not args.timed_only:
+        print(json.dumps(line), flush=True)
     engine.close()
     if launched:
         dist.barrier()

@@ -280,6 +280,13 @@ int r3d_run_device(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,
  * to summation order).  Returns 0 on success.                                 */
 int r3d_run_model(const r3d_model_desc* model, uint64_t n, uint64_t first_id, uint64_t seed,
                   int n_gpus, r3d_result* out);
+/* The same with the devices named: shard g of n_devices runs on devices[g] (a device may
+ * appear more than once -- the shards then share it).  r3d_run_model is this call with
+ * devices 0 .. n_gpus-1.  If any shard fails, nothing is added to *out and the message names
+ * the shard and its device.  (Reference seam: model.cpp:602-633; replicas summed as in
+ * vis/seisplot/combine.m:26-33.)                                               */
+int r3d_run_model_on(const r3d_model_desc* model, uint64_t n, uint64_t first_id, uint64_t seed,
+                     const int* devices, int n_devices, r3d_result* out);
 
 /* r3d_run_device for a CHAIN of batches (same engine, same seed, launches in stream
  * order).  A batch ends in a drain phase in which ever fewer lanes still carry a
@@ -379,6 +386,13 @@ uint64_t r3d_event_log_read(r3d_engine* e, r3d_event* out, uint64_t max, int res
 double   r3d_last_kernel_ms(r3d_engine* e);
 uint64_t r3d_launch_count(const r3d_engine* e);
 double   r3d_kernel_ms(r3d_engine* e, uint64_t launch);
+
+/* Which compiled kernel variant serves this engine: cell kind * 4 + table residency
+ * (0 cell records and scatterer heads staged in LDS, 1 the heads only, 2 neither), and the
+ * number of history slots of a workgroup's pool.  For tests that must name the code object
+ * they compare with the oracle.                                               */
+int      r3d_engine_variant(const r3d_engine* e);
+uint32_t r3d_engine_pool_slots(const r3d_engine* e);
 
 /* Number of scalar counters r3d_run_device expects.                         */
 #define R3D_N_SCALARS (3 + R3D_INV_NUM + R3D_EV_NUM)

@@ -111,7 +111,7 @@ def _load(path):
 
 
 _host = None
-_hip = None
+_hip = {}
 
 
 def host_lib():
@@ -155,12 +155,19 @@ def host_lib():
     return _host
 
 
-def hip_lib():
-    """libr3d_hip.so: the HIP engine.  Fails loudly when it was not built."""
-    global _hip
-    if _hip is None:
+def hip_lib(reproducible=None):
+    """libr3d_hip.so: the HIP engine.  Fails loudly when it was not built.
+
+    reproducible (default: the environment's R3D_REPRODUCIBLE=1): libr3d_hip_repro.so, the same
+    engine built with -DR3D_REPRODUCIBLE -- no wave-voted series choices (csrc/r3d_math.h
+    all_lanes), so a history's result is bit-defined by (model, seed, id)."""
+    if reproducible is None:
+        reproducible = os.environ.get("R3D_REPRODUCIBLE", "0") not in ("", "0")
+    key = bool(reproducible)
+    if key not in _hip:
         # R3D_HIP_LIB: developer override used by tools/ to time experimental builds
-        L = _load(os.environ.get("R3D_HIP_LIB") or os.path.join(LIBDIR, "libr3d_hip.so"))
+        L = _load(os.environ.get("R3D_HIP_LIB") or
+                  os.path.join(LIBDIR, "libr3d_hip_repro.so" if key else "libr3d_hip.so"))
         L.r3d_engine_create.restype = C.c_void_p
         L.r3d_engine_create.argtypes = [C.POINTER(ModelDesc), C.c_int]
         L.r3d_engine_destroy.argtypes = [C.c_void_p]
@@ -219,7 +226,14 @@ def hip_lib():
         L.r3d_engine_carry_pending.argtypes = [C.c_void_p]
         L.r3d_engine_set_volume_buffer.restype = C.c_int
         L.r3d_engine_set_volume_buffer.argtypes = [C.c_void_p, C.POINTER(VolumeDesc), C.c_void_p]
+        L.r3d_run_model_on.restype = C.c_int
+        L.r3d_run_model_on.argtypes = [C.POINTER(ModelDesc), C.c_uint64, C.c_uint64, C.c_uint64,
+                                       C.POINTER(C.c_int), C.c_int, C.POINTER(Result)]
+        L.r3d_engine_variant.restype = C.c_int
+        L.r3d_engine_variant.argtypes = [C.c_void_p]
+        L.r3d_engine_pool_slots.restype = C.c_uint32
+        L.r3d_engine_pool_slots.argtypes = [C.c_void_p]
         L.r3d_last_error.restype = C.c_char_p
         L.r3d_version.restype = C.c_char_p
-        _hip = L
-    return _hip
+        _hip[key] = L
+    return _hip[key]

@@ -166,7 +166,6 @@ struct r3d_engine {
   // launches on different streams may be in flight together (a caller overlapping one
   // batch's drain with the next batch): each takes its own work counter from a small ring
   static constexpr unsigned kCounters = 64;
-  unsigned launch_seq = 0;
   // ... and its own pair of timing events, so that r3d_kernel_ms(e, launch) reads the launch
   // it names and not whichever recorded last
   hipEvent_t ev0[kCounters] = {}, ev1[kCounters] = {};
@@ -243,7 +242,10 @@ hipError_t with_kernel(const r3d_engine* e, F&& f) {
 #else
   switch (e->kind) {
     case R3D_CELL_CYLINDER: return by_res(std::integral_constant<int, CELL_CYL>{});
-    case R3D_CELL_TETRA: return by_res(std::integral_constant<int, CELL_TET>{});
+    case R3D_CELL_TETRA:   // (tetra grids run to thousands of cells: their records are never staged in LDS,
+                           //  so that variant is not compiled)
+      if (e->res == RES_NONE) return f(std::integral_constant<int, CELL_TET>{}, std::integral_constant<int, RES_NONE>{});
+      return f(std::integral_constant<int, CELL_TET>{}, std::integral_constant<int, RES_TABLES>{});
     default: return by_res(std::integral_constant<int, CELL_SPH>{});
   }
 #endif
@@ -489,8 +491,14 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
     const size_t kLds = 160 * 1024, kStatic = 1024;   // static: queue control words, tallies
     const size_t head_bytes = (size_t)m->n_scatterers * sizeof(ScatHead);
     const size_t scat_bytes = head_bytes + (size_t)m->n_scatterers * sizeof(ScatPtrs);   // heads + table addresses
-    const bool scat_fit = scat_bytes <= 24 * 1024;
-    const bool cells_fit = scat_fit && cell_bytes + scat_bytes <= 24 * 1024;
+    // R3D_FORCE_RES=1 / 2 (developer and test switch): run the kernel variant that keeps the cell
+    // records (1) or also the scatterer heads (2) in HBM although they would fit in LDS, so that
+    // every compiled variant can be held against the oracle on any model
+    int force_res = 0;
+    if (const char* s = getenv("R3D_FORCE_RES")) force_res = atoi(s);
+    const bool scat_fit = scat_bytes <= 24 * 1024 && force_res < RES_NONE;
+    const bool cells_fit = scat_fit && cell_bytes + scat_bytes <= 24 * 1024 && force_res < RES_TABLES &&
+                           m->cell_kind != R3D_CELL_TETRA;
     e->res = cells_fit ? RES_ALL : scat_fit ? RES_TABLES : RES_NONE;
     size_t off = 0;
     a.lds_cells_off = a.lds_scat_off = a.lds_seis_off = a.lds_hit_off = a.lds_grid_off = 0xFFFFFFFFu;
@@ -595,7 +603,9 @@ static int enqueue(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, 
   R3D_ON_DEVICE(e->device);
   KArgs a = e->args;
   a.n = n, a.first_id = first_id, a.seed = seed;
-  const unsigned slot = e->launch_seq++ % r3d_engine::kCounters;
+  // the launch's work counter and event pair: slot (id - 1) % kCounters of the id it will get
+  // once it is enqueued -- what r3d_kernel_ms(e, id) reads; a rejected call takes nothing
+  const unsigned slot = (unsigned)(e->launches % r3d_engine::kCounters);
   a.next = reinterpret_cast<unsigned long long*>(e->d_next.p) + slot;
   a.energy = d_energy;
   a.counts = reinterpret_cast<unsigned long long*>(d_counts);
@@ -603,6 +613,7 @@ static int enqueue(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, 
   a.finals = d_finals;
   a.carry_in = a.carry_out = nullptr;
   bool must_launch = n > 0;
+  bool pending_after = e->carry_pending;
   if (carry) {
     if (d_finals) return g_error = "final records and carry-over cannot be combined", 1;
     if (e->carry_pending && seed != e->carry_seed)
@@ -614,14 +625,15 @@ static int enqueue(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, 
     }
     if (e->carry_pending) a.carry_in = e->d_carry->p, must_launch = true;
     if (carry == 1) a.carry_out = e->d_carry->p;
-    e->carry_pending = (carry == 1) && (n > 0 || e->carry_pending);
-    e->carry_seed = seed;
+    pending_after = (carry == 1) && (n > 0 || e->carry_pending);
   }
   R3D_HIP_OK(hipMemsetAsync(a.next, 0, sizeof(unsigned long long), s));
   R3D_HIP_OK(hipEventRecord(e->ev0[slot], s));
   if (must_launch)
     R3D_HIP_OK(launch_any(e, a, d_finals != nullptr || a.evlog != nullptr, s, /*drain_only*/ carry == 2 && n == 0));
   R3D_HIP_OK(hipEventRecord(e->ev1[slot], s));
+  // enqueued: only now does the engine's state move on
+  if (carry) e->carry_pending = pending_after, e->carry_seed = seed;
   e->launches++;
   return 0;
 }
@@ -676,10 +688,10 @@ int r3d_run(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, r3d_res
   return run_host(e, n, first_id, seed, out, nullptr);
 }
 
-int r3d_run_model(const r3d_model_desc* model, uint64_t n, uint64_t first_id, uint64_t seed, int n_gpus,
-                  r3d_result* out) {
+int r3d_run_model_on(const r3d_model_desc* model, uint64_t n, uint64_t first_id, uint64_t seed,
+                     const int* devices, int n_devices, r3d_result* out) {
   if (!model || !out || !out->energy || !out->counts) return g_error = "null argument", 1;
-  if (n_gpus < 1) return g_error = "n_gpus must be at least 1 (the engine has no CPU path)", 1;
+  if (n_devices < 1 || !devices) return g_error = "at least one device is needed (the engine has no CPU path)", 1;
   const size_t ne = (size_t)model->n_seismometers * model->params.n_bins * R3D_N_ENERGY;
   const size_t nc = (size_t)model->n_seismometers * model->params.n_bins * R3D_N_COUNT;
   struct Shard {
@@ -688,27 +700,28 @@ int r3d_run_model(const r3d_model_desc* model, uint64_t n, uint64_t first_id, ui
     r3d_result res{};
     std::string error;
   };
-  std::vector<Shard> shards(n_gpus);
+  std::vector<Shard> shards(n_devices);
   std::vector<std::thread> pool;
-  for (int g = 0; g < n_gpus; g++) {
+  for (int g = 0; g < n_devices; g++) {
     pool.emplace_back([&, g] {
       Shard& sh = shards[g];
       sh.energy.assign(std::max<size_t>(ne, 1), 0.0), sh.counts.assign(std::max<size_t>(nc, 1), 0);
       sh.res.energy = sh.energy.data(), sh.res.counts = sh.counts.data();
-      const uint64_t lo = n / n_gpus * g + std::min<uint64_t>(g, n % n_gpus);
-      const uint64_t cnt = n / n_gpus + ((uint64_t)g < n % n_gpus ? 1 : 0);
-      r3d_engine* e = r3d_engine_create(model, g);
+      const uint64_t lo = n / n_devices * g + std::min<uint64_t>(g, n % n_devices);
+      const uint64_t cnt = n / n_devices + ((uint64_t)g < n % n_devices ? 1 : 0);
+      r3d_engine* e = r3d_engine_create(model, devices[g]);
       if (!e) {
-        sh.error = g_error;   // (thread-local: this thread's message)
+        sh.error = "shard " + std::to_string(g) + " (device " + std::to_string(devices[g]) + "): " + g_error;   // (thread-local: this thread's message)
         return;
       }
-      if (r3d_run(e, cnt, first_id + lo, seed, &sh.res)) sh.error = g_error;
+      if (r3d_run(e, cnt, first_id + lo, seed, &sh.res))
+        sh.error = "shard " + std::to_string(g) + " (device " + std::to_string(devices[g]) + "): " + g_error;
       r3d_engine_destroy(e);
     });
   }
   for (auto& t : pool) t.join();
   for (const Shard& sh : shards)
-    if (!sh.error.empty()) return g_error = sh.error, 1;
+    if (!sh.error.empty()) return g_error = sh.error, 1;   // nothing is added to *out unless every shard ran
   for (const Shard& sh : shards) {
     for (size_t i = 0; i < ne; i++) out->energy[i] += sh.energy[i];
     for (size_t i = 0; i < nc; i++) out->counts[i] += sh.counts[i];
@@ -717,6 +730,14 @@ int r3d_run_model(const r3d_model_desc* model, uint64_t n, uint64_t first_id, ui
     for (int k = 0; k < R3D_EV_NUM; k++) out->events[k] += sh.res.events[k];
   }
   return 0;
+}
+
+int r3d_run_model(const r3d_model_desc* model, uint64_t n, uint64_t first_id, uint64_t seed, int n_gpus,
+                  r3d_result* out) {
+  if (n_gpus < 1) return g_error = "n_gpus must be at least 1 (the engine has no CPU path)", 1;
+  std::vector<int> devices(n_gpus);
+  for (int g = 0; g < n_gpus; g++) devices[g] = g;
+  return r3d_run_model_on(model, n, first_id, seed, devices.data(), n_gpus, out);
 }
 
 int r3d_run_traced(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, r3d_result* out,
@@ -909,6 +930,9 @@ int r3d_volume_read(r3d_engine* e, uint32_t* out, int reset) {
 }
 
 uint64_t r3d_launch_count(const r3d_engine* e) { return e ? e->launches : 0; }
+
+int r3d_engine_variant(const r3d_engine* e) { return e ? e->kind * 4 + e->res : -1; }
+uint32_t r3d_engine_pool_slots(const r3d_engine* e) { return e ? e->args.pool_slots : 0; }
 
 double r3d_kernel_ms(r3d_engine* e, uint64_t launch) {
   if (!e || launch == 0 || launch > e->launches || e->launches - launch >= r3d_engine::kCounters) return -1.0;

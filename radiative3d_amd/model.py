@@ -177,12 +177,18 @@ class Model:
         return Result(self.n_seismometers, self.n_bins)
 
 
-def run_model(model, n, first_id=0, seed=0x5EED, n_gpus=1):
-    """r3d_run_model: the whole seam in one call, sharded over `n_gpus` devices."""
+def run_model(model, n, first_id=0, seed=0x5EED, n_gpus=1, devices=None):
+    """r3d_run_model: the whole seam in one call, sharded over devices 0 .. n_gpus-1 -- or, with
+    `devices`, r3d_run_model_on: shard g on devices[g] (a device may be named more than once)."""
     lib = _ffi.hip_lib()
     res = model.new_result()
     c = res._as_c()
-    if lib.r3d_run_model(model.desc_p, n, first_id, seed, n_gpus, C.byref(c)):
+    if devices is not None:
+        devs = (C.c_int * len(devices))(*devices)
+        rc = lib.r3d_run_model_on(model.desc_p, n, first_id, seed, devs, len(devices), C.byref(c))
+    else:
+        rc = lib.r3d_run_model(model.desc_p, n, first_id, seed, n_gpus, C.byref(c))
+    if rc:
         raise RuntimeError("r3d_run_model failed: " + lib.r3d_last_error().decode())
     res._from_c(c)
     return res
@@ -199,9 +205,12 @@ def volume_desc(origin, cell_size, dims, n_frames, frame_dt):
 class Engine:
     """The model resident in HBM + the HIP traversal kernels (libr3d_hip.so)."""
 
-    def __init__(self, model, device=0):
-        self._lib = _ffi.hip_lib()
+    def __init__(self, model, device=0, reproducible=None):
+        """reproducible: None = as the environment says (R3D_REPRODUCIBLE=1), True / False = the
+        build without / with wave-voted series choices (see _ffi.hip_lib)."""
+        self._lib = _ffi.hip_lib(reproducible)
         self.model = model
+        self._volume_keepalive = None
         self._e = self._lib.r3d_engine_create(model.desc_p, device)
         if not self._e:
             raise RuntimeError("r3d_engine_create failed: " + self._lib.r3d_last_error().decode())
@@ -221,6 +230,7 @@ class Engine:
                     raise RuntimeError("r3d_engine_close failed: " + self._lib.r3d_last_error().decode())
                 self._lib.r3d_engine_destroy(self._e)
             self._e = None
+            self._volume_keepalive = None   # (only now may a caller-owned grid be freed)
 
     def __del__(self):
         try:
@@ -252,6 +262,8 @@ class Engine:
         addresses, e.g. tensor.data_ptr()).  carry: None (a self-contained launch),
         "carry" (one of a chain: unfinished histories stay in the engine for its next
         launch) or "final" (resume and finish everything carried); see r3d_run_device_carry."""
+        if carry not in (None, "carry", "final"):
+            raise ValueError(f"carry must be None, 'carry' or 'final', not {carry!r}")
         if carry is not None:
             rc = self._lib.r3d_run_device_carry(self._e, n, first_id, seed, d_energy, d_counts, d_scalars,
                                                 stream, 1 if carry == "final" else 0)
@@ -269,13 +281,34 @@ class Engine:
             raise RuntimeError("r3d_engine_set_volume failed: " + self._lib.r3d_last_error().decode())
         self._vol_shape = (2, int(n_frames), int(dims[2]), int(dims[1]), int(dims[0]))
 
-    def set_volume_buffer(self, origin, cell_size, dims, n_frames, frame_dt, d_counters):
-        """The same grid in caller-owned device memory (raw address of 2*n_frames*nz*ny*nx zeroed
-        uint32 counters, e.g. a torch tensor's data_ptr that is reduced over ranks afterwards)."""
+    def set_volume_buffer(self, origin, cell_size, dims, n_frames, frame_dt, counters):
+        """The same grid in caller-owned device memory: `counters` is a contiguous 32-bit integer
+        tensor of 2*n_frames*nz*ny*nx zeroed elements (e.g. a torch tensor that is reduced over
+        ranks afterwards).  The engine writes through its raw address, so this object keeps a
+        reference to the tensor until the grid is detached or the engine closed."""
+        shape = (2, int(n_frames), int(dims[2]), int(dims[1]), int(dims[0]))
+        want = 1
+        for d in shape:
+            want *= d
+        if not hasattr(counters, "data_ptr"):
+            raise TypeError("set_volume_buffer takes the tensor itself, not an address: the engine "
+                            "must keep it alive while it adds into it")
+        if counters.numel() != want or counters.element_size() != 4 or not counters.is_contiguous():
+            raise ValueError(f"volume buffer must be {want} contiguous 32-bit counters, got "
+                             f"{counters.numel()} x {counters.element_size()} bytes")
         v = volume_desc(origin, cell_size, dims, n_frames, frame_dt)
-        if self._lib.r3d_engine_set_volume_buffer(self._e, C.byref(v), d_counters):
+        if self._lib.r3d_engine_set_volume_buffer(self._e, C.byref(v), counters.data_ptr()):
             raise RuntimeError("r3d_engine_set_volume_buffer failed: " + self._lib.r3d_last_error().decode())
-        self._vol_shape = (2, int(n_frames), int(dims[2]), int(dims[1]), int(dims[0]))
+        assert self._lib.r3d_volume_len(self._e) == want
+        self._volume_keepalive = counters
+        self._vol_shape = shape
+
+    def detach_volume(self):
+        """Stop binning events (r3d_engine_set_volume_buffer(NULL)); releases the caller's tensor."""
+        if getattr(self, "_e", None):
+            if self._lib.r3d_engine_set_volume_buffer(self._e, None, None):
+                raise RuntimeError("detaching the volume failed: " + self._lib.r3d_last_error().decode())
+        self._volume_keepalive = None
 
     def read_volume(self, reset=False):
         out = np.zeros(self._vol_shape, dtype=np.uint32)
@@ -338,6 +371,18 @@ class Engine:
         if got == (1 << 64) - 1:
             raise RuntimeError("r3d_event_log_read failed: " + self._lib.r3d_last_error().decode())
         return out[:got]
+
+    @property
+    def variant(self):
+        """(cell kind, table residency) of the compiled kernel this engine launches:
+        kind 0 cylinder / 1 tetra / 2 sphere shell; residency 0 cells + scatterer heads in LDS,
+        1 heads only, 2 neither."""
+        v = int(self._lib.r3d_engine_variant(self._e))
+        return v // 4, v % 4
+
+    @property
+    def pool_slots(self):
+        return int(self._lib.r3d_engine_pool_slots(self._e))
 
     def last_kernel_ms(self):
         return float(self._lib.r3d_last_kernel_ms(self._e))

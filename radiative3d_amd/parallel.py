@@ -96,9 +96,11 @@ class DeviceVolume:
     (r3d_engine_set_volume_buffer) and `allreduce_` / `reduce_` add the grids once at the end
     of the job.  The counters are uint32 (a 10 GB grid at the 300 x 64 x 256 x 256 size of
     BASELINE config 5), and a sum over ranks of 1e8..1e9 histories could pass 2^32 in a hot
-    cell: the reduction therefore runs chunk by chunk in int64 and SATURATES at 2^32 - 1
-    instead of wrapping; `saturated` counts the cells that hit the ceiling.  (torch has no
-    arithmetic on uint32, so the storage is int32 holding the same bits.)"""
+    cell.  The reduction first asks (one scalar MAX over ranks) whether any cell CAN reach 2^31:
+    if not -- the usual case -- the int32 storage is all-reduced as it is, 4 bytes per cell on
+    the wire; else it runs chunk by chunk in int64 and SATURATES at 2^32 - 1 instead of
+    wrapping; `saturated` counts the cells that hit the ceiling, `widened` says which path ran.
+    (torch has no arithmetic on uint32, so the storage is int32 holding the same bits.)"""
 
     def __init__(self, engine, origin, cell_size, dims, n_frames, frame_dt, device):
         self.shape = (2, int(n_frames), int(dims[2]), int(dims[1]), int(dims[0]))
@@ -107,19 +109,43 @@ class DeviceVolume:
             n *= d
         self.counters = torch.zeros(n, dtype=torch.int32, device=device)
         self.saturated = 0
+        self.widened = None
         self.engine = engine
-        if engine is not None:
-            engine.set_volume_buffer(origin, cell_size, dims, n_frames, frame_dt, self.counters.data_ptr())
+        if engine is not None:   # (the engine keeps a reference to the tensor: model.Engine.set_volume_buffer)
+            engine.set_volume_buffer(origin, cell_size, dims, n_frames, frame_dt, self.counters)
+
+    def detach(self):
+        """Stop the engine from adding into this grid (before the tensor is dropped or re-used)."""
+        if self.engine is not None:
+            self.engine.detach_volume()
+            self.engine = None
 
     def zero_(self):
         self.counters.zero_()
         self.saturated = 0
 
+    def _headroom(self, world):
+        """True when no cell's sum over `world` ranks can reach 2^31: the counters can then be added
+        as they are stored (int32), with no widening.  One scalar all-reduce (MAX) decides it for
+        all ranks alike."""
+        lo, hi = int(self.counters.min().item()), int(self.counters.max().item())
+        worst = torch.tensor([(1 << 32) if lo < 0 else hi], dtype=torch.int64, device=self.counters.device)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        return int(worst.item()) * world < (1 << 31)
+
     def _reduce_chunks(self, collective, chunk_elems, keep):
-        """Widen, add over ranks, saturate, store back -- chunk by chunk so that the int64
-        scratch stays small next to a multi-GB grid."""
+        """Add the grids over ranks.  Usual case (every rank's largest counter x ranks < 2^31):
+        the collective runs on the int32 storage itself, in place, 4 bytes per cell on the wire.
+        Otherwise: widen, add, saturate, store back -- chunk by chunk so that the int64 scratch
+        stays small next to a multi-GB grid (8 bytes per cell on the wire)."""
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return self
+        if self._headroom(dist.get_world_size()):
+            self.widened = False
+            for lo in range(0, self.counters.numel(), chunk_elems):
+                collective(self.counters[lo:lo + chunk_elems])
+            return self
+        self.widened = True
         sat = 0
         for lo in range(0, self.counters.numel(), chunk_elems):
             part = self.counters[lo:lo + chunk_elems]
@@ -131,12 +157,13 @@ class DeviceVolume:
         self.saturated += sat
         return self
 
-    def allreduce_(self, chunk_elems=1 << 26):
-        """Every rank ends with the job's grid (one all-reduce(SUM) per chunk)."""
+    def allreduce_(self, chunk_elems=1 << 28):
+        """Every rank ends with the job's grid (one all-reduce(SUM) per chunk of 1 GiB)."""
         return self._reduce_chunks(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), chunk_elems, True)
 
-    def reduce_(self, dst=0, chunk_elems=1 << 26):
-        """Rank `dst` ends with the job's grid; the other ranks keep their own shard's."""
+    def reduce_(self, dst=0, chunk_elems=1 << 28):
+        """Rank `dst` ends with the job's grid; the other ranks' buffers are then undefined
+        (a reduce may use them as scratch)."""
         return self._reduce_chunks(lambda t: dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM), chunk_elems,
                                    dist.is_initialized() and dist.get_rank() == dst)
 

@@ -44,6 +44,91 @@ def check_against_oracle(engine, n, first_id=0, seed=0x5EED, allow_frac=0.0005):
     return rg, ro
 
 
+def assert_result_equals_oracle(got, want, what):
+    """Aggregate comparison for runs without per-history records: every integer output bit-exact
+    (counts per seismometer, bin and type; lost / timeout / invalid; the 8 event counters), the
+    invalid reasons as the per-history suite holds them (their sum: which of "negative time" /
+    "stuck" / "slow" a trapped phonon is filed under sits on the sign of rounding noise),
+    energies to 1e-9 relative (device libm vs glibc)."""
+    assert (got.n_lost, got.n_timeout, got.n_invalid) == (want.n_lost, want.n_timeout, want.n_invalid), what
+    assert got.events == want.events, what
+    assert int(got.invalid_reasons.sum()) == int(want.invalid_reasons.sum()) == got.n_invalid, what
+    assert (got.invalid_reasons[[0, 1, 2, 6]] == want.invalid_reasons[[0, 1, 2, 6]]).all(), what
+    assert (got.counts == want.counts).all(), what
+    assert np.allclose(got.energy, want.energy, rtol=1e-9, atol=1e-13), what
+
+
+def check_production_against_oracle(engine, n, first_id=0, seed=0x5EED, pieces=4):
+    """The code objects that ship and are timed -- pool_kernel<..., TRACE = false> (r3d_run,
+    r3d_run_device[_carry]) and pool_drain_kernel (a chain's flush) -- against the oracle, not
+    against the diagnostic kernel or themselves (reference phonons.cpp:540-682, dataout.cpp:103-216)."""
+    model = engine.model
+    want = O.run(model, n, first_id, seed)
+    got = engine.run(n, first_id, seed)                       # one self-contained production launch
+    assert_result_equals_oracle(got, want, "r3d_run")
+    # the same ids as a carry chain of `pieces` launches + a flush-only launch (n = 0: the drain kernel)
+    total = DeviceResult(model, "cuda:0")
+    per = n // pieces
+    for k in range(pieces):
+        count = per if k < pieces - 1 else n - per * (pieces - 1)
+        engine.run_device(count, first_id + k * per, seed, *total.pointers(), carry="carry")
+    torch.cuda.synchronize()
+    assert engine.carry_pending or n == 0
+    engine.run_device(0, 0, seed, *total.pointers(), carry="final")
+    torch.cuda.synchronize()
+    assert not engine.carry_pending
+    assert_result_equals_oracle(total.to_result(), want, "carry chain + drain")
+    return got, want
+
+
+# (cell kind, table residency) of every compiled traversal kernel and a model that runs it; residency 1 / 2
+# on models whose tables would fit in LDS is forced with R3D_FORCE_RES.  tests/test_kernel_coverage.py (CPU)
+# holds this list against the symbols in libr3d_hip.so.
+KERNEL_CASES = [(0, 0, "lopnor", 6000), (0, 1, "lopnor", 6000), (0, 2, "halfspace", 20000),
+                (1, 1, "crustpinch", 8000), (1, 2, "upthrust", 8000),
+                (2, 0, "sphere_deep", 1500), (2, 1, "sphere_deep", 1500), (2, 2, "toysphere_vids", 1500)]
+
+
+@pytest.mark.parametrize("kind,res,name,n", KERNEL_CASES)
+def test_every_compiled_kernel_matches_oracle(models, monkeypatch, kind, res, name, n):
+    """pool_kernel<kind, res, TRACE>, pool_kernel<kind, res, production> and pool_drain_kernel<kind, res>
+    each against the oracle; the engine says which variant it launches."""
+    monkeypatch.setenv("R3D_FORCE_RES", str(res))
+    e = Engine(models(name))
+    assert e.variant == (kind, res)
+    check_against_oracle(e, n, first_id=17)                   # the diagnostic kernel (final records)
+    check_production_against_oracle(e, n, first_id=17)        # the production kernel and the drain kernel
+    e.close()
+
+
+@pytest.mark.parametrize("name,n", [("halfspace", 50000), ("crustpinch", 20000), ("lopnor", 20000),
+                                    ("sphere_deep", 3000), ("upthrust", 20000), ("crustpinch_vids", 5000)])
+def test_production_kernel_matches_oracle(engines, name, n):
+    check_production_against_oracle(engines(name), n)
+
+
+def test_production_kernel_small_pool_and_many_receivers(models, monkeypatch):
+    """The production kernels under the queue stress of test_small_pool_many_short_launches (the
+    smallest pool, no bin accumulators) and with 4500 receivers (every catch through the hash)."""
+    monkeypatch.setenv("R3D_POOL_SLOTS", "64")
+    monkeypatch.setenv("R3D_ACC_BITS", "0")
+    for name, n in (("crustpinch", 20000), ("lopnor", 20000), ("sphere_deep", 2000)):
+        e = Engine(models(name))
+        assert e.pool_slots == 768
+        check_production_against_oracle(e, n, first_id=3, pieces=7)
+        e.close()
+    monkeypatch.delenv("R3D_POOL_SLOTS")
+    monkeypatch.delenv("R3D_ACC_BITS")
+    args = [a for a in halfspace(4) if not a.startswith("--seis-p2p")] + [
+        "--seis-p2p=0,0,0,183.85,183.85,0,2.737,0.105,10.0,1500",
+        "--seis-p2p=0,0,0,260,0,0,2.737,0.105,10.0,1500",
+        "--seis-p2p=0,0,0,240.21,-99.5,0,2.737,0.105,10.0,1500"]
+    e = Engine(Model(args))
+    got, _ = check_production_against_oracle(e, 20000)
+    assert got.events["catch"] > 100
+    e.close()
+
+
 @pytest.mark.parametrize("name,n", [("halfspace", 50000), ("crustpinch", 20000), ("lopnor", 20000),
                                     ("sphere", 3000), ("sphere_deep", 3000), ("toysphere_vids", 2000),
                                     ("lopnor_vids", 2000), ("upthrust", 20000), ("crustpinch_vids", 5000)])
@@ -159,8 +244,9 @@ def test_full_size_crustpinch_properties():
     z = (na[sel] - nb[sel]) / np.sqrt(na[sel] + nb[sel])
     assert abs(z.mean()) < 0.05 and 0.9 < z.std() < 1.5
     assert a.energy.sum() == pytest.approx(b.energy.sum(), rel=0.02)
-    # small-sample oracle comparison on the big tables too
+    # small-sample oracle comparison on the big tables too: diagnostic and production kernels
     check_against_oracle(e, 3000, first_id=123456789)
+    check_production_against_oracle(e, 3000, first_id=123456789)
 
 
 def independent_halves_agree(e, n, min_bins):
@@ -209,6 +295,7 @@ def test_full_size_lopnor_properties():
     assert a.n_invalid == 0 and a.energy.sum() == pytest.approx(b.energy.sum(), rel=0.03)
     reference_event_mix(e, "lopnor", a, n)
     check_against_oracle(e, 3000, first_id=987654321)
+    check_production_against_oracle(e, 3000, first_id=987654321)
     e.close()
 
 
@@ -225,6 +312,7 @@ def test_full_size_sphere_deep_source_properties():
     assert a.n_timeout == n and a.n_invalid == 0
     assert a.events["scatter"] / n > 50 and a.events["rtsolve"] / n > 20
     check_against_oracle(e, 1500, first_id=24680)
+    check_production_against_oracle(e, 1500, first_id=24680)
     e.close()
     from tests.configs import sphere
     e = Engine(Model(sphere(9)))
@@ -449,3 +537,128 @@ def test_small_pool_many_short_launches(models, monkeypatch):
         assert (got.counts == want.counts).all() and got.events == want.events
         assert np.allclose(got.energy, want.energy, rtol=1e-11, atol=1e-300)
         e.close()
+
+
+def test_run_model_on_three_engines_on_one_device(engines):
+    """r3d_run_model_on (SURVEY.md 8(b)'s n_gpus seam with the devices named): three engines, three
+    host threads, all on this box's one GPU, host sum == one engine's run of the union (counts
+    exact, energies to summation order) == the oracle; a failing shard fails the call, names
+    itself and leaves *out untouched.  Reference: model.cpp:602-633, combine.m:26-33."""
+    from radiative3d_amd import run_model
+    e = engines("lopnor")
+    n = 9001
+    want = e.run(n, first_id=11, seed=99)
+    got = run_model(e.model, n, first_id=11, seed=99, devices=[0, 0, 0])
+    assert (got.counts == want.counts).all() and got.events == want.events
+    assert (got.n_lost, got.n_timeout, got.n_invalid) == (want.n_lost, want.n_timeout, want.n_invalid)
+    assert np.allclose(got.energy, want.energy, rtol=1e-12, atol=1e-300)
+    assert_result_equals_oracle(got, O.run(e.model, n, 11, 99), "r3d_run_model_on")
+    with pytest.raises(RuntimeError, match=r"shard 1 \(device 99\): device index out of range"):
+        run_model(e.model, 100, devices=[0, 99, 0])
+    with pytest.raises(RuntimeError, match="at least one device"):
+        run_model(e.model, 100, devices=[])
+
+
+def test_run_device_rejects_unknown_carry_words_and_keeps_launch_ids_in_step(engines):
+    e = engines("halfspace")
+    buf = DeviceResult(e.model, "cuda:0")
+    for bad in ("Final", True, "flush", 1):
+        with pytest.raises(ValueError, match="carry must be"):
+            e.run_device(10, 0, 1, *buf.pointers(), carry=bad)
+    # a rejected launch takes no launch id and no timing slot: ids and times stay in step
+    before = e.launch_count()
+    e.run_device(50000, 0, 5, *buf.pointers(), carry="carry")
+    with pytest.raises(RuntimeError, match="another seed"):
+        e.run_device(1000, 50000, 6, *buf.pointers(), carry="carry")
+    assert e.launch_count() == before + 1 and e.carry_pending
+    e.run_device(3_000_000, 50000, 5, *buf.pointers(), carry="carry")
+    e.run_device(0, 0, 5, *buf.pointers(), carry="final")
+    torch.cuda.synchronize()
+    assert e.launch_count() == before + 3
+    small, big = e.kernel_ms(before + 1), e.kernel_ms(before + 2)
+    assert 0 < small < big, (small, big)       # launch before+2 is the 3e6-history one
+
+
+def test_reproducible_build_defines_every_history_to_the_bit(models, monkeypatch):
+    """libr3d_hip_repro.so (-DR3D_REPRODUCIBLE: no wave-voted series choice, csrc/r3d_math.h): a history's
+    final record is bit-identical whatever shares its wave -- another pool size, a chain of launches
+    against one launch -- on all three cell kinds; and it still matches the oracle."""
+    import ctypes
+
+    def finals_bytes(f):
+        return bytes(ctypes.string_at(ctypes.addressof(f), ctypes.sizeof(f)))
+
+    for name, n in (("crustpinch", 30000), ("lopnor", 20000), ("sphere_deep", 3000)):
+        m = models(name)
+        monkeypatch.delenv("R3D_POOL_SLOTS", raising=False)
+        big = Engine(m, reproducible=True)
+        monkeypatch.setenv("R3D_POOL_SLOTS", "768")
+        small = Engine(m, reproducible=True)
+        monkeypatch.delenv("R3D_POOL_SLOTS")
+        assert big.pool_slots > small.pool_slots == 768
+        ra, fa = big.run(n, first_id=5, seed=3, trace=True)
+        rb, fb = small.run(n, first_id=5, seed=3, trace=True)
+        assert finals_bytes(fa) == finals_bytes(fb), name
+        assert (ra.counts == rb.counts).all() and ra.events == rb.events
+        # chained against self-contained: the production kernels; energies are sums of identical terms in
+        # another order, the integer outputs must be identical
+        total = DeviceResult(m, "cuda:0")
+        for k in range(3):
+            small.run_device(n // 3, 5 + k * (n // 3), 3, *total.pointers(), carry="carry")
+        small.run_device(n - 3 * (n // 3), 5 + 3 * (n // 3), 3, *total.pointers(), carry="final")
+        torch.cuda.synchronize()
+        rc = total.to_result()
+        assert (rc.counts == ra.counts).all() and rc.events == ra.events
+        assert np.allclose(rc.energy, ra.energy, rtol=1e-12, atol=1e-300)
+        check_against_oracle(big, min(n, 5000), first_id=5, seed=3)
+        big.close(), small.close()
+
+
+def _bench_child(extra_args, launched, port=None):
+    """bench.py as a fresh child process; `launched` gives it the launcher's environment of a
+    one-rank job, i.e. the path the driver's N > 1 runs take: an nccl (= RCCL) process group, the
+    result block all-reduced, barrier, destroy."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "R3D_FORCE_RES",
+                        "R3D_POOL_SLOTS", "R3D_ACC_BITS")}
+    if launched:
+        env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1"] + extra_args, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("config", ["crustpinch", "crustpinch_volume"])
+def test_bench_under_a_launcher_runs_rccl_and_equals_the_direct_run(config):
+    """The launched path of bench.py at world size 1: RCCL initialised, DeviceResult.allreduce_ (and for
+    config 5 DeviceVolume under the group), barrier, destroy -- same totals as the direct run.
+    (Reference semantics: scripts/do-parallel.sh:23-29, vis/seisplot/combine.m:26-33.)"""
+    from radiative3d_amd.launch import free_port
+    args = ["--config", config, "--steps", "2", "--warmup", "1", "--histories", "200000", "--toa-degree", "5",
+            "--no-cpu-baseline"]
+    direct = _bench_child(args, launched=False)
+    rccl = _bench_child(args, launched=True, port=free_port())
+    assert direct["n_gpus"] == rccl["n_gpus"] == 1
+    assert rccl["collective"]["backend"] == "nccl" and rccl["collective"]["process_group"]
+    assert direct["collective"]["backend"] is None
+    assert rccl["roofline"]["events_per_history"] == direct["roofline"]["events_per_history"]
+    assert rccl["value"] > 0 and len(rccl["collective"]["per_rank_kernel_ms"]) == 1
+    if config == "crustpinch_volume":
+        assert rccl["volume"]["events_binned"] == direct["volume"]["events_binned"] > 0
+
+
+def test_bench_cpu_baseline_and_envelope_under_a_launcher():
+    """At any world size the line carries cpu_baseline and the envelope figure (rank 0 times the
+    oracle on host-built tables; the GPU batches run sharded and all-reduced over the group)."""
+    from radiative3d_amd.launch import free_port
+    line = _bench_child(["--config", "halfspace", "--steps", "2", "--warmup", "1", "--histories", "500000",
+                         "--toa-degree", "5"], launched=True, port=free_port())
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port"
+    assert line["envelope"]["gpu_side"].startswith("device-built tables, each batch sharded over 1 rank")

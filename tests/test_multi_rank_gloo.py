@@ -46,6 +46,40 @@ def _worker(rank, world, port, n, out_path):
     dist.destroy_process_group()
 
 
+def _reduce_once_worker(rank, world, port, n, steps, out_path):
+    """bench.py's two reduction schedules on the same shards: every launch adds into the rank's own
+    block and the blocks are all-reduced ONCE at the end (the default; the reference's replicas +
+    combine, vis/seisplot/combine.m:26-33) against one all-reduce per step."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = Model(lopnor(3))
+    once, per_step, step = DeviceResult(model, "cpu"), DeviceResult(model, "cpu"), DeviceResult(model, "cpu")
+    for i in range(steps):
+        res = E.run(model, n, first_id=(i * world + rank) * n)        # bench.py's id layout
+        step.energy.copy_(torch.from_numpy(res.energy.reshape(-1).copy()))
+        step.counts.copy_(torch.from_numpy(res.counts.astype(np.int64).reshape(-1)))
+        step.scalars.copy_(torch.from_numpy(res.scalars().astype(np.int64)))
+        once.add_(step)                       # what r3d_run_device does in place on the GPU
+        per_step.add_(step.allreduce_())
+    once.allreduce_()
+    assert torch.equal(once._ints, per_step._ints)
+    assert torch.allclose(once.energy, per_step.energy, rtol=1e-13, atol=0)
+    if rank == 0:
+        r = once.to_result()
+        np.savez(out_path, counts=r.counts, scalars=r.scalars(), energy=r.energy)
+    dist.destroy_process_group()
+
+
+def test_one_reduction_at_the_end_equals_one_per_step(tmp_path):
+    n, steps, world = 1500, 3, 2
+    out = str(tmp_path / "once.npz")
+    mp.spawn(_reduce_once_worker, args=(world, _free_port(), n, steps, out), nprocs=world, join=True)
+    got = np.load(out)
+    want = E.run(Model(lopnor(3)), n * steps * world)    # the ids of all steps and ranks are one contiguous range
+    assert (got["counts"] == want.counts).all() and (got["scalars"] == want.scalars()).all()
+    assert np.allclose(got["energy"], want.energy, rtol=1e-12, atol=1e-300)
+
+
 def test_shard_range_partitions():
     for n in (0, 1, 7, 64, 1000003):
         for w in (1, 2, 3, 8):
@@ -89,22 +123,37 @@ def _volume_worker(rank, world, port, n, out_path):
     mine = dv.total()
     # chunks smaller than the grid, not dividing it: the chunk loop is what is being tested
     dv.allreduce_(chunk_elems=100_003)
-    assert dv.saturated == 0 and dv.total() >= mine
-    # reduce_: only the destination holds the sum afterwards
+    # (no cell can reach 2^31 here: the int32 storage itself went over the wire, 4 bytes per cell)
+    assert dv.widened is False and dv.saturated == 0 and dv.total() >= mine
+    # reduce_: the destination holds the sum afterwards
     dr = DeviceVolume(None, device="cpu", **GRID)
     dr.counters.copy_(torch.from_numpy(vol.reshape(-1).view(np.int32)))
     dr.reduce_(dst=0, chunk_elems=250_000)
     if rank == 0:
         assert torch.equal(dr.counters, dv.counters)
         np.save(out_path, dv.to_numpy())
-    else:
-        assert dr.total() == mine
+    # the widened path on the same data (forced by one counter at 2^31 - 1 on one rank): same sums elsewhere
+    dw = DeviceVolume(None, device="cpu", **GRID)
+    dw.counters.copy_(torch.from_numpy(vol.reshape(-1).view(np.int32)))
+    keep = int(dw.counters[0].item())
+    if rank == 1:
+        dw.counters[0] = 0x7FFFFFFF
+    dw.allreduce_(chunk_elems=100_003)
+    assert dw.widened is True and dw.saturated == 0
+    assert torch.equal(dw.counters[1:], dv.counters[1:])
+    assert int(dw.to_numpy().reshape(-1)[0]) == (0x7FFFFFFF + keep if rank == 1 else 0x7FFFFFFF + int(dv.counters[0]) - keep)
+    # the headroom test is about the SUM: 2^30 on both ranks must take the widened path too
+    dh = DeviceVolume(None, device="cpu", origin=(0, 0, 0), cell_size=(1, 1, 1), dims=(2, 1, 1), n_frames=1,
+                      frame_dt=1.0)
+    dh.counters.copy_(torch.tensor([1 << 30, 1, 2, 3], dtype=torch.int32))
+    dh.allreduce_()
+    assert dh.widened is True and dh.to_numpy().reshape(-1).tolist() == [1 << 31, 2, 4, 6]
     # saturation instead of wrap-around: two ranks each holding 2^32 - 5 in one cell, 7 in another
     ds = DeviceVolume(None, device="cpu", origin=(0, 0, 0), cell_size=(1, 1, 1), dims=(2, 1, 1), n_frames=1,
                       frame_dt=1.0)
     ds.counters.copy_(torch.from_numpy(np.array([0xFFFFFFFB, 7, 0, 3], dtype=np.uint32).view(np.int32)))
     ds.allreduce_()
-    assert ds.to_numpy().reshape(-1).tolist() == [0xFFFFFFFF, 14, 0, 6] and ds.saturated == 1
+    assert ds.to_numpy().reshape(-1).tolist() == [0xFFFFFFFF, 14, 0, 6] and ds.saturated == 1 and ds.widened is True
     dist.destroy_process_group()
 
 
