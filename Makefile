@@ -38,7 +38,7 @@ engine: $(LIBDIR)/libr3d_hip.so
 # the same engine with every wave-voted series choice taken out (r3d_math.h all_lanes): a history's
 # result is then bit-defined by (model, seed, id); loaded under R3D_REPRODUCIBLE=1
 repro: $(LIBDIR)/libr3d_hip_repro.so
-oracle: oracle/libr3d_oracle.so
+oracle: oracle/libr3d_oracle.so oracle/libr3d_tables_oracle.so
 cli: main
 
 # The command-line program the reference's do-*.sh scripts call as ./main
@@ -60,6 +60,11 @@ $(LIBDIR)/libr3d_hip_repro.so: $(ENGINE_SRC) $(ENGINE_HDR)
 
 oracle/libr3d_oracle.so: oracle/r3d_oracle.cpp oracle/philox.h include/r3d.h
 	$(CXX) $(CXXFLAGS) -shared -o $@ oracle/r3d_oracle.cpp
+
+# the table builders restated (take-off set, scatterer tables, source patterns, seismometer axes):
+# plain g++, no fast-math, no FMA contraction -- the reference's operation order is the point
+oracle/libr3d_tables_oracle.so: oracle/r3d_tables_oracle.cpp
+	$(CXX) -std=c++17 -O2 -ffp-contract=off -fPIC -Wall -shared -o $@ oracle/r3d_tables_oracle.cpp
 
 clean:
 	rm -f $(LIBDIR)/*.so oracle/*.so main

@@ -71,6 +71,13 @@ uint32_t r3dh_model_report_mask(const r3dh_model* m);
  * return ""; path == NULL: return the text.  NULL on error.                 */
 const char* r3dh_write_reports(r3dh_model* m, const r3d_event* events, uint64_t n, const char* path);
 
+/* The coordinate system the model was built in (reference ecs.hpp:242-257): map_code 0 ENU_ORTHO,
+ * 1 RAE_ORTHO, 2 RAE_CURVED, 3 RAE_SPHERICAL; the Earth radius; whether --flatten applied.
+ * And the axes scheme of seismometer i (model.cpp:486-491): 0 ENZ, 1 RTZ, -1 out of range.
+ * For tests that restate the builders (oracle/r3d_tables_oracle.cpp).  Returns 0 ok.         */
+int r3dh_model_coordinates(const r3dh_model* m, int* map_code, double* earth_radius, int* flattened);
+int r3dh_seismometer_axes(const r3dh_model* m, int i);
+
 const char* r3dh_last_error(void);
 
 #ifdef __cplusplus

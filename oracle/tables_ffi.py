@@ -1,0 +1,96 @@
+"""ctypes access to the table-builder oracle (oracle/libr3d_tables_oracle.so).
+
+TEST INFRASTRUCTURE: import this only from tests/.  The product (radiative3d_amd/) never does.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+_dp = C.POINTER(C.c_double)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libr3d_tables_oracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"table oracle not built: {path} (run `make oracle`)")
+        L = C.CDLL(path)
+        L.r3d_oracle_toa.restype = C.c_uint64
+        L.r3d_oracle_toa.argtypes = [C.c_int, _dp]
+        L.r3d_oracle_gsato.argtypes = [_dp, C.c_double, C.c_double, _dp]
+        L.r3d_oracle_scatterer.argtypes = [_dp, _dp, C.c_uint64, C.c_int, _dp, C.c_int, C.POINTER(_dp), _dp,
+                                           _dp, _dp, _dp]
+        L.r3d_oracle_moment_tensor.argtypes = [C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp]
+        L.r3d_oracle_source.argtypes = [_dp, _dp, C.c_uint64, C.POINTER(_dp), _dp]
+        L.r3d_oracle_seismometer.argtypes = [C.c_int, C.c_double, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _vec(v):
+    return np.ascontiguousarray(v, dtype=np.float64)
+
+
+def toa(degree):
+    """(20 * 4^degree, 2) array of (theta, phi): S2::TesselSphere(TESS_ICO, degree), geom_s2.cpp:40-130."""
+    n = 20 * 4 ** degree
+    out = np.zeros((n, 2))
+    got = lib().r3d_oracle_toa(degree, _p(out))
+    assert got == n
+    return out
+
+
+def gsato(het, theta, phi):
+    out = np.zeros(5)
+    lib().r3d_oracle_gsato(_p(_vec(het)), theta, phi, _p(out))
+    return out
+
+
+def scatterer(het, toa_arr, mfp_override=None, no_deflect=False):
+    """Scatterer::Scatterer (scatterers.cpp:97-259) -> dict(cdf[4, n], spol[n], whole[2, 4], mfp[2], dipole[2])."""
+    t = _vec(toa_arr)
+    n = len(t)
+    cdf, spol = np.zeros((4, n)), np.zeros(n)
+    whole, mfp, dipole = np.zeros((2, 4)), np.zeros(2), np.zeros(2)
+    ptrs = (_dp * 4)(*[_p(cdf[k]) for k in range(4)])
+    given = _vec(mfp_override if mfp_override is not None else [0, 0])
+    lib().r3d_oracle_scatterer(_p(_vec(het)), _p(t), n, int(mfp_override is not None), _p(given), int(no_deflect),
+                               ptrs, _p(spol), _p(whole), _p(mfp), _p(dipole))
+    return dict(cdf=cdf, spol=spol, whole=whole, mfp=mfp, dipole=dipole)
+
+
+def moment_tensor(kind, params, map_code, earth_radius, event_loc):
+    """kind "SDR" (strike, dip, rake, iso fraction, moment) or "USGS" (rr, tt, pp, rt, rp, tp) -> the tensor
+    rotated to the local north-east-down frame at the event (model.cpp:431-433): xx, yy, zz, xy, xz, yz."""
+    p = np.zeros(6)
+    p[:len(params)] = params
+    out, asym = np.zeros(6), C.c_double()
+    lib().r3d_oracle_moment_tensor(0 if kind == "SDR" else 1, _p(p), map_code, earth_radius, _p(_vec(event_loc)),
+                                   _p(out), C.byref(asym))
+    return out, asym.value
+
+
+def source(mt, toa_arr):
+    """ShearDislocation::ShearDislocation (events.cpp:42-107) -> (cdf[3, n], whole[3])."""
+    t = _vec(toa_arr)
+    n = len(t)
+    cdf, whole = np.zeros((3, n)), np.zeros(3)
+    ptrs = (_dp * 3)(*[_p(cdf[k]) for k in range(3)])
+    lib().r3d_oracle_source(_p(_vec(mt)), _p(t), n, ptrs, _p(whole))
+    return cdf, whole
+
+
+def seismometer(map_code, earth_radius, event_loc, loc, rtz, r_in, r_out):
+    """Seismometer::Seismometer (dataout.cpp:42-71) -> (axes[3, 3], area[2])."""
+    axes, area = np.zeros((3, 3)), np.zeros(2)
+    lib().r3d_oracle_seismometer(map_code, earth_radius, _p(_vec(event_loc)), _p(_vec(loc)), int(rtz), _p(_vec(r_in)),
+                                 _p(_vec(r_out)), _p(axes), _p(area))
+    return axes, area

@@ -151,6 +151,10 @@ def host_lib():
         L.r3dh_write_reports.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p]
         L.r3dh_write_outputs.restype = C.c_char_p
         L.r3dh_write_outputs.argtypes = [C.c_void_p, C.POINTER(Result), C.c_char_p, C.c_char_p, C.c_char_p]
+        L.r3dh_model_coordinates.restype = C.c_int
+        L.r3dh_model_coordinates.argtypes = [C.c_void_p, C.POINTER(C.c_int), _dp, C.POINTER(C.c_int)]
+        L.r3dh_seismometer_axes.restype = C.c_int
+        L.r3dh_seismometer_axes.argtypes = [C.c_void_p, C.c_int]
         _host = L
     return _host
 

@@ -152,6 +152,19 @@ const char* r3dh_write_reports(r3dh_model* m, const r3d_event* events, uint64_t 
   return nullptr;
 }
 
+int r3dh_model_coordinates(const r3dh_model* m, int* map_code, double* earth_radius, int* flattened) {
+  if (!m) return 1;
+  if (map_code) *map_code = m->model->MapCode();
+  if (earth_radius) *earth_radius = m->model->EarthRadius();
+  if (flattened) *flattened = m->params.Flatten ? 1 : 0;
+  return 0;
+}
+
+int r3dh_seismometer_axes(const r3dh_model* m, int i) {
+  if (!m || i < 0 || i >= (int)m->model->SeisAxesDesc().size()) return -1;
+  return m->model->SeisAxesDesc()[i] == "RTZ" ? 1 : 0;
+}
+
 const char* r3dh_last_error(void) { return g_error.c_str(); }
 
 }  // extern "C"

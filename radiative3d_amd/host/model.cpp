@@ -316,6 +316,7 @@ Model::Model(const ModelParams& par, std::ostream* logp) {
   p.loop_concern = 1048576; // phonons.cpp:32
   R3::XYZ ec = ECS.CurvedCoords() ? ECS.GetEarthCenter() : R3::XYZ(0, 0, 0);
   put3(p.earth_center, ec);
+  mMapCode = (int)ECS.Mapping(), mRadE = ECS.GetEarthRadius();
 
   log << "@@ __MODEL_INITIALIZATION_COMPLETE__" << std::endl << std::flush;
 }

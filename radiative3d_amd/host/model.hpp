@@ -108,6 +108,10 @@ class Model {
   bool OverridesMFP() const { return mOverrideMFP; }
   bool NoDeflect() const { return mNoDeflect; }
   const std::vector<S2::ThetaPhi>& TOA() const { return mTOA; }
+  // The coordinate system the model was built in (the global ECS moves on with the next model):
+  // EarthCoords::earthcoords_e code and Earth radius.
+  int MapCode() const { return mMapCode; }
+  Real EarthRadius() const { return mRadE; }
 
   // Locators (reference model.cpp:521-551, :562-594) over the flat tables.
   int FindCellContainingPoint(const R3::XYZ& loc) const;
@@ -141,6 +145,8 @@ class Model {
   R3::XYZ mEventLoc;
   bool mOverrideMFP = false, mNoDeflect = false, mDeviceTables = false;
   Real mMFPOverride[2] = {0, 0};
+  int mMapCode = 0;
+  Real mRadE = 6371.0;
   r3d_model_desc mDesc{};
 };
 

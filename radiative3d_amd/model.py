@@ -154,6 +154,18 @@ class Model:
         return txt.decode()
 
     @property
+    def coordinates(self):
+        """(map code, Earth radius, flattened) of the coordinate system the model was built in
+        (reference ecs.hpp:242-257: 0 ENU_ORTHO, 1 RAE_ORTHO, 2 RAE_CURVED, 3 RAE_SPHERICAL)."""
+        code, flat, rad = C.c_int(), C.c_int(), C.c_double()
+        self._lib.r3dh_model_coordinates(self._h, C.byref(code), C.byref(rad), C.byref(flat))
+        return code.value, rad.value, bool(flat.value)
+
+    def seismometer_axes(self, i):
+        """0 ENZ, 1 RTZ (model.cpp:486-491)."""
+        return int(self._lib.r3dh_seismometer_axes(self._h, i))
+
+    @property
     def device_tables(self):
         """True if built with --device-tables: the scattering tables are made by the engine."""
         return bool(self._lib.r3dh_model_device_tables(self._h))

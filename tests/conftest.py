@@ -18,7 +18,9 @@ def pytest_configure(config):
     # without a GPU).  The prebuilt .so files travel to the GPU box.
     need = [os.path.join(REPO, "radiative3d_amd", "lib", "libr3d_host.so"),
             os.path.join(REPO, "radiative3d_amd", "lib", "libr3d_hip.so"),
-            os.path.join(REPO, "oracle", "libr3d_oracle.so")]
+            os.path.join(REPO, "radiative3d_amd", "lib", "libr3d_hip_repro.so"),
+            os.path.join(REPO, "oracle", "libr3d_oracle.so"),
+            os.path.join(REPO, "oracle", "libr3d_tables_oracle.so")]
     if not all(os.path.exists(p) for p in need):
         subprocess.check_call(["make", "-C", REPO, "all"])
 

@@ -1,6 +1,9 @@
-"""Scattering tables built in HBM (--device-tables; include/r3d.h r3d_scatterer build-on-device
-form, csrc/r3d_tables_build.hip) against the host builder's, and history parity of a run on
-them against the oracle fed the very same (downloaded) tables."""
+"""Tables built in HBM (--device-tables; include/r3d.h build-on-device forms, csrc/r3d_tables_build.hip)
+against oracle/r3d_tables_oracle.cpp -- the reference's table builders restated (take-off set
+geom_s2.cpp:60-292; GSATO -> cumulative tables, mean free paths, dipoles scatparams.cpp:75-194,
+scatterers.cpp:97-259; source patterns events.cpp:42-107) -- and history parity of a run on them
+against the path oracle fed the very same (downloaded) tables.  (The product's HOST builder meets
+the same oracle on the CPU: tests/test_tables_oracle.py.)"""
 import ctypes as C
 
 import numpy as np
@@ -75,42 +78,46 @@ class _Patched:
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,deg", [("crustpinch", 5), ("lopnor", 4), ("sphere", 4), ("halfspace", 6)])
-def test_device_tables_match_host_and_oracle(name, deg):
+@pytest.mark.parametrize("name,deg", [("crustpinch", 5), ("lopnor", 4), ("sphere", 4), ("halfspace", 6),
+                                      ("sphere_deep", 4), ("crustpinch_vids", 4)])
+def test_device_tables_match_the_tables_oracle_and_the_path_oracle(name, deg):
     from oracle import oracle_ffi
+    from oracle import tables_ffi as T
     from radiative3d_amd import Engine
-    host = Model(CONFIGS[name](deg))
-    dev = Model(CONFIGS[name](deg) + ["--device-tables"])
+    args = CONFIGS[name](deg)
+    host = Model(args)                      # (for the statistical comparison at the end only)
+    dev = Model(args + ["--device-tables"])
     e = Engine(dev)
-    n_toa = host.n_toa
-    for s in range(host.n_scatterers):
+    n_toa = dev.n_toa
+    override = [a for a in args if a.startswith("--overridemfp")]
+    given = [float(x) for x in override[0].split("=")[1].split(",")] if override else None
+    # the take-off set generated in HBM: the oracle's recursion, up to the last place of acos / atan2
+    want_toa = T.toa(deg)
+    toa = e.download_toa()
+    assert np.max(np.abs(toa[:, 0] - want_toa[:, 0])) < 1e-14
+    assert np.max(np.abs(np.angle(np.exp(1j * (toa[:, 1] - want_toa[:, 1]))))) < 1e-14
+    for s in range(dev.n_scatterers):
+        o = T.scatterer(list(dev.desc.scatterers[s].het), want_toa, mfp_override=given, no_deflect="--nodeflect" in args)
         st = e.scatterer_stats(s)
-        info = host.scatterer_info(s)
-        assert st[0] == pytest.approx(info["mfp_p"], rel=1e-11) and st[1] == pytest.approx(info["mfp_s"], rel=1e-11)
-        assert st[2] == pytest.approx(info["dipole_p"], abs=1e-10) and st[3] == pytest.approx(info["dipole_s"], abs=1e-10)
+        assert st[0] == pytest.approx(o["mfp"][0], rel=1e-11) and st[1] == pytest.approx(o["mfp"][1], rel=1e-11)
+        if "--nodeflect" not in args:       # (under --nodeflect the reference reports 1, 1 without computing)
+            assert st[2] == pytest.approx(o["dipole"][0], abs=1e-10) and st[3] == pytest.approx(o["dipole"][1], abs=1e-10)
         assert dev.scatterer_info(s)["mfp_p"] == st[0]            # the model now shows the engine's numbers
         cdf, spol = e.download_scatterer(s)
-        h = host.desc.scatterers[s]
         for k in range(4):
-            want = np.ctypeslib.as_array(h.cdf[k], shape=(n_toa,))
             assert np.all(np.diff(cdf[k]) >= 0)
-            assert np.max(np.abs(cdf[k] - want)) <= 1e-12 * want[-1]
-        want = np.ctypeslib.as_array(h.spol, shape=(n_toa,))
-        assert np.max(np.abs(np.angle(np.exp(1j * (spol - want))))) < 1e-9
-    # the take-off set generated in HBM: the host builder's, up to the last place of acos / atan2
-    toa = e.download_toa()
-    want = np.ctypeslib.as_array(host.desc.toa, shape=(n_toa, 2))
-    assert np.max(np.abs(toa[:, 0] - want[:, 0])) < 1e-14
-    assert np.max(np.abs(np.angle(np.exp(1j * (toa[:, 1] - want[:, 1]))))) < 1e-14
-    # the source's cumulative radiation patterns
+            assert np.max(np.abs(cdf[k] - o["cdf"][k])) <= 1e-12 * max(o["cdf"][k][-1], 1e-300)
+            assert st[4 + k] == pytest.approx(o["cdf"][k][-1], rel=1e-12)
+        assert np.max(np.abs(np.angle(np.exp(1j * (spol - o["spol"]))))) < 1e-9
+    # the source's cumulative radiation patterns, from the moment tensor the model carries
+    want_cdf, want_whole = T.source(list(dev.desc.source.moment), want_toa)
     cdf, whole = e.download_source()
     for k in range(3):
-        want = np.ctypeslib.as_array(host.desc.source.cdf[k], shape=(n_toa,))
         assert np.all(np.diff(cdf[k]) >= 0)
-        assert np.max(np.abs(cdf[k] - want)) <= 1e-12 * max(want[-1], host.desc.source.whole_cdf[2])
-        assert whole[k] == pytest.approx(host.desc.source.whole_cdf[k], rel=1e-12)
+        assert np.max(np.abs(cdf[k] - want_cdf[k])) <= 1e-12 * max(want_cdf[k][-1], want_whole[2])
+        assert whole[k] == pytest.approx(want_whole[k], rel=1e-12)
     # a run on the device-built tables == the oracle on those same tables, history for history
-    n = 20000 if name != "sphere" else 4000
+    n = 20000 if not name.startswith("sphere") else 4000
     res_g, fin_g = e.run(n, trace=True)
     res_o, fin_o = oracle_ffi.run(_Patched(dev, e), n, trace=True)
     bad = sum(finals_differ(a, b) for a, b in zip(fin_g, fin_o))
