@@ -304,6 +304,9 @@ bool check_model(const r3d_model_desc* m) {
   if ((uint64_t)std::max(0, m->n_seismometers) * m->params.n_bins >= (uint64_t(1) << 31))
     return g_error = "seismometers x time bins must stay below 2^31", false;
   if (m->source.cell < 0 || m->source.cell >= m->n_cells) return g_error = "source cell out of range", false;
+  // a tetra record packs neighbour + 1 into 22 bits and the scatterer index into 16 (r3d_tables.h CellTet)
+  if (m->cell_kind == R3D_CELL_TETRA && ((uint32_t)m->n_cells >= kTetNbrMask || m->n_scatterers > 65536))
+    return g_error = "tetra models are limited to 4 194 302 cells and 65 536 scatterers", false;
   const int want_faces = m->cell_kind == R3D_CELL_CYLINDER ? 3 : m->cell_kind == R3D_CELL_TETRA ? 4 : 2;
   for (int i = 0; i < m->n_cells; i++) {
     const r3d_cell& c = m->cells[i];

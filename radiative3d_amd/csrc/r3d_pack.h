@@ -280,25 +280,26 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm, bool for_engine
     a.cyl_radius2 = m.cells[0].faces[2].radius * m.cells[0].faces[2].radius;
     a.cells = pm.cyl.data();
   } else if (m.cell_kind == R3D_CELL_TETRA) {
-    pm.tet.resize(m.n_cells);
+    pm.tet.resize((size_t)2 * m.n_cells);   // one record per cell and ray type (r3d_tables.h CellTet)
     pm.rho.resize(m.n_cells);
     for (int i = 0; i < m.n_cells; i++) {
       const r3d_cell& c = m.cells[i];
-      CellTet& d = pm.tet[i];
-      std::memset(&d, 0, sizeof d);
+      const uint32_t flags = pack_flags_classified(m, i);
       for (int t = 0; t < 2; t++) {
-        for (int k = 0; k < 3; k++) d.g[t][k] = c.vel_grad[t][k];
-        d.v0[t] = c.vel_c[t];
-        d.inv_gmag[t] = 1.0 / std::sqrt(dot3(c.vel_grad[t], c.vel_grad[t]));
-        d.att[t] = kPiF / c.q[t];
+        CellTet& d = pm.tet[(size_t)2 * i + t];
+        std::memset(&d, 0, sizeof d);
+        for (int k = 0; k < 3; k++) d.g[k] = c.vel_grad[t][k];
+        d.v0 = c.vel_c[t];
+        d.inv_gmag = 1.0 / std::sqrt(dot3(c.vel_grad[t], c.vel_grad[t]));
+        d.att = kPiF / c.q[t];
+        for (int f = 0; f < 4; f++) {
+          for (int k = 0; k < 3; k++) d.n[f][k] = c.faces[f].normal[k];
+          d.d[f] = dot3(c.faces[f].normal, c.faces[f].point);
+          const uint32_t nbr = (c.faces[f].flags & R3D_FACE_ADJOIN) ? (uint32_t)(c.faces[f].neighbor + 1) : 0u;
+          d.link[f] = nbr | (((flags >> (8 * f)) & 0x3Fu) << kTetNbrBits) |
+                      ((((uint32_t)c.scatterer >> (4 * f)) & 0xFu) << 28);
+        }
       }
-      for (int f = 0; f < 4; f++) {
-        for (int k = 0; k < 3; k++) d.n[f][k] = c.faces[f].normal[k];
-        d.d[f] = dot3(c.faces[f].normal, c.faces[f].point);
-        d.nbr[f] = (c.faces[f].flags & R3D_FACE_ADJOIN) ? c.faces[f].neighbor : -1;
-      }
-      d.flags = pack_flags_classified(m, i);
-      d.scat = c.scatterer;
       for (int k = 0; k < 3; k++) pm.rho[i].g[k] = c.rho_grad[k];
       pm.rho[i].c = c.rho_c;
     }

@@ -138,17 +138,16 @@ struct TetArc {
 };
 R3D_HD TetArc tet_arc(const CellTet& c, const Phonon& p) {
   TetArc A;
-  const int t = p.type;
-  V3 g = v3(c.g[t]);
-  double vel = dot(p.loc, g) + c.v0[t];
+  V3 g = v3(c.g);          // (the record of this cell for the phonon's ray type)
+  double vel = dot(p.loc, g) + c.v0;
   // w2 = g x dir, w1 = w2 x g (the part of dir normal to g, times |g|^2): |w1| = |w2| |g|, so with
   // iw = 1 / |w2| everything follows from ONE reciprocal square root and no division:
   //   v1 = w1 / (|w2| |g|),   t.v1 = |w2| / |g|,   R = v / (|g| t.v1) = v / |w2|   (media.hpp:568-569)
   V3 w2 = cross(g, p.dir), w1 = cross(w2, g);
   const double m2 = mag2(w2);
   const double iw = frsqrt(m2);
-  A.v1 = (iw * c.inv_gmag[t]) * w1, A.v3 = c.inv_gmag[t] * g;
-  const double txp = (m2 * iw) * c.inv_gmag[t], tzp = dot(p.dir, A.v3);
+  A.v1 = (iw * c.inv_gmag) * w1, A.v3 = c.inv_gmag * g;
+  const double txp = (m2 * iw) * c.inv_gmag, tzp = dot(p.dir, A.v3);
   A.R = vel * iw;
   // In the rotated frame the phonon sits at R (-tz', 0, tx') from the centre
   // (media.hpp:574-580), i.e. centre = loc + R tz' v1 - R tx' v3; the direction is a unit vector in
@@ -248,21 +247,20 @@ R3D_HD double tet_exit_length(const TetArc& A, const TetExit& e) {
 // are the sine / cosine of the end angle: the exit's own for a boundary leg,
 // a0 + len/R for a scatter leg.
 R3D_HD void tet_advance(const CellTet& c, const TetArc& A, Phonon& p, double len, double s1, double c1) {
-  const int t = p.type;
   V3 nl = A.center + ((A.R * s1) * A.v1 + (A.R * c1) * A.v3);   // point of the circle at the end angle
   V3 nd = c1 * A.v1 + (-s1) * A.v3;                             // tangent (cos a, 0, -sin a)
   // time = (ln|tan(a1/2+pi/4)| - ln|tan(a0/2+pi/4)|) / |g|,  ln|tan(a/2+pi/4)| = atanh(sin a), and
   // atanh(s1) - atanh(s0) = atanh(y), y = (s1 - s0) / (1 - s0 s1): a leg spans a few degrees, so y
   // is small and the series does (one division, no logarithm)
   const double y = (s1 - A.s0) * frcp(1.0 - A.s0 * s1);
-  double time = c.inv_gmag[t] * atanh_lean(y);
+  double time = c.inv_gmag * atanh_lean(y);
   p.path += len, p.t += time, p.recent += time;
   p.loc = nl;
   // (nd = c1 v1 - s1 v3 with v1, v3 orthonormal is unit to rounding; the reference's
   //  renormalisation + (theta, phi) round trip changes it by ~1e-16 and is skipped --
   //  the next leg rebuilds v1 from scratch, so nothing accumulates)
   p.dir = nd;
-  p.lamp += c.att[t] * time;
+  p.lamp += c.att * time;
   p.moves += 1;
 }
 
@@ -562,7 +560,19 @@ struct RtChoice {
   int choice;    // R_P .. T_SH, after the no-transmit fold
   int intype;    // 0 P, 1 SH, 2 SV
 };
-R3D_HD RtChoice rt_choose(const Phonon& p, Iface f, Rng& rng, RngKey key) {
+// The event's uniforms (the S-polarisation draw only for S phonons, then the outcome draw: order and
+// count of draws are the reference's, rtcoef.cpp:414, :447), PINNED where this is called: they depend
+// on nothing that has to be fetched, so a caller draws them while the interface's records are on
+// their way -- left to itself the optimiser sinks each generator call down to its use.
+R3D_HD void rt_draws(const Phonon& p, Rng& rng, RngKey key, double& u_pol, double& u_out) {
+  u_pol = 1.0;
+  if (p.type == RAY_S) u_pol = rng_draw(rng, key);
+  u_out = rng_draw(rng, key);
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(u_pol), "+v"(u_out));
+#endif
+}
+R3D_HD RtChoice rt_choose(const Phonon& p, Iface f, double u_pol, double u_out) {
   const V3 fnorm = f.normal;
   const V3 fpara = in_plane_unit_perp(fnorm, p.dir);
   const double sini = dot(fpara, p.dir);
@@ -575,7 +585,7 @@ R3D_HD RtChoice rt_choose(const Phonon& p, Iface f, Rng& rng, RngKey key) {
   if (p.type == RAY_S) {  // ChooseSPolType, rtcoef.cpp:406-422
     const V3 fparash = cross(fnorm, fpara);
     double sh = dot(direction_of_motion(p), fparash);
-    intype = (rng_draw(rng, key) <= sh * sh) ? 1 : 2;
+    intype = (u_pol <= sh * sh) ? 1 : 2;
   }
   double w[RT_NUM], det2;
   R3D_SCHED_FENCE();
@@ -588,7 +598,7 @@ R3D_HD RtChoice rt_choose(const Phonon& p, Iface f, Rng& rng, RngKey key) {
 #pragma unroll
   for (int i = 1; i < RT_NUM; i++) cum[i] = cum[i - 1] + w[i];
   const double total = cum[RT_NUM - 1];
-  const double ran = rng_draw(rng, key) * total;
+  const double ran = u_out * total;
   int choice = RT_NUM - 1;
 #pragma unroll
   for (int i = RT_NUM - 2; i >= 0; i--)
@@ -628,7 +638,9 @@ R3D_HD bool rt_apply(Phonon& p, Iface f, RtChoice ch) {
   return !reflected;
 }
 R3D_HD bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
-  const RtChoice ch = rt_choose(p, f, rng, key);
+  double u_pol, u_out;
+  rt_draws(p, rng, key, u_pol, u_out);
+  const RtChoice ch = rt_choose(p, f, u_pol, u_out);
   return rt_apply(p, f, ch);
 }
 

@@ -591,7 +591,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #pragma nounroll
       for (int rep = 0;; rep++) {
         Pending ev;
-        ev.vel = 0.0, ev.face = -1, ev.flags = 0u;
+        ev.vel = 0.0, ev.face = -1, ev.flags = 0u, ev.nbr = -1;
         bool leaving = false;
         if (live) {
           fate = step_move<KIND>(a, T, p, rng, st, &reason, ev);
@@ -613,7 +613,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         const bool light = live && !leaving;
         if (light) {
           const uint32_t tr0 = st.transfer, rf0 = st.reflect;
-          step_event<KIND, EV_BEND>(a, T, p, rng, st, ev);
+          step_event<KIND, EV_BEND>(a, T, p, rng, st, ev, ev.nbr);
           if (TRACE) {
             report(st.reflect != rf0, 2, p, hid);    // REF
             report(st.transfer != tr0, 4, p, hid);   // CEL
@@ -638,7 +638,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
           if (keep) {
             store_state(id, p, rng, meta_pack(p.type, dest == Q_MOVE ? -1 : ev.face, dest == Q_MOVE ? 0u : ev.flags, dest));
             if (dest == Q_RT || dest == Q_COLLECT)   // (the cell's record is at hand here: the later phase need not wait for it)
-              fu[FU_NBR * S + id] = (uint32_t)cell_neighbor(T.cells[p.cell], ev.face);
+              fu[FU_NBR * S + id] = (uint32_t)ev.nbr;
           } else
             fu[FU_META * S + id] = meta_pack(0, -1, 0u, Q_FREE);
         }
@@ -656,7 +656,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       uint32_t k0 = 0, k1 = 0, catches = 0;
       double vel = 1.0;
       Pending ev;
-      ev.vel = 0.0, ev.face = 0, ev.flags = 0u;
+      ev.vel = 0.0, ev.face = 0, ev.flags = 0u, ev.nbr = -1;
       if (act) {
         load_state(id, p, rng, meta);
 #ifndef R3D_PRIO_NARROW
@@ -664,7 +664,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #endif
         hid = ((uint64_t)rng.id_hi << 32) | rng.id_lo;
         ev.face = (int)((meta >> 1) & 7u) - 1, ev.flags = (meta >> 8) & 0xFFu;
-        vel = cell_velocity(T.cells[p.cell], p.loc, p.type);
+        vel = velocity_in<KIND>(T, p.cell, p.loc, p.type);
         const SeisGrid& g = a.grid;
         const double fx = (p.loc.x - g.origin[0]) * g.inv_h;
         const double fy = (p.loc.y - g.origin[1]) * g.inv_h;
@@ -731,7 +731,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #endif
         hid = ((uint64_t)rng.id_hi << 32) | rng.id_lo;
         Pending ev;
-        ev.vel = 0.0, ev.face = (int)((meta >> 1) & 7u) - 1, ev.flags = (meta >> 8) & 0xFFu;
+        ev.vel = 0.0, ev.face = (int)((meta >> 1) & 7u) - 1, ev.flags = (meta >> 8) & 0xFFu, ev.nbr = -1;
         if (q == Q_RT) {
 #ifdef R3D_ABLATE_RT
           step_event<KIND, EV_RT>(a, T, p, rng, st, ev, (int)fu[FU_NBR * S + id]);
@@ -749,7 +749,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #endif
           rng.k = draws;
           Pending ev2;
-          ev2.vel = 0.0, ev2.face = (int)((meta >> 1) & 7u) - 1, ev2.flags = (meta >> 8) & 0xFFu;
+          ev2.vel = 0.0, ev2.face = (int)((meta >> 1) & 7u) - 1, ev2.flags = (meta >> 8) & 0xFFu, ev2.nbr = -1;
           rt_event_apply<KIND>(a, T, p, st, ev2, (int)fu[FU_NBR * S + id], ch);
 #endif
         } else {

@@ -14,6 +14,8 @@
 #ifndef R3D_STEP_H_
 #define R3D_STEP_H_
 
+#include <type_traits>
+
 #include "r3d_physics.h"
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -49,9 +51,21 @@ struct Tables {
 };
 
 // ---- per-kind property lookups --------------------------------------------
+// The record a phonon of ray type `type` in cell `cell` works from: layered and spherical cells have
+// one record, tetra cells one per ray type (r3d_tables.h CellTet).
+template <int KIND>
+R3D_HD const typename CellOf<KIND>::type& cell_rec(const Tables<KIND>& T, int cell, int type) {
+  if constexpr (KIND == CELL_TET) return T.cells[2 * cell + type];
+  else return T.cells[cell];
+}
+// velocity of ray type t at p, from a record that holds it (tetra: the record of type t)
 R3D_HD double cell_velocity(const CellCyl& c, V3, int t) { return c.v[t]; }
-R3D_HD double cell_velocity(const CellTet& c, V3 p, int t) { return dot(p, v3(c.g[t])) + c.v0[t]; }
+R3D_HD double cell_velocity(const CellTet& c, V3 p, int) { return dot(p, v3(c.g)) + c.v0; }
 R3D_HD double cell_velocity(const CellSph& c, V3 p, int t) { return c.c[t] + c.a[t] * mag2(p); }
+template <int KIND>
+R3D_HD double velocity_in(const Tables<KIND>& T, int cell, V3 p, int t) {
+  return cell_velocity(cell_rec<KIND>(T, cell, t), p, t);
+}
 
 R3D_HD double cell_density(const KArgs&, const CellCyl& c, int, V3) { return c.rho; }
 R3D_HD double cell_density(const KArgs& a, const CellTet&, int idx, V3 p) {
@@ -67,8 +81,14 @@ R3D_HD V3 cell_face_normal(const CellSph& c, int f, V3 loc) {  // media_cellface
   return c.radius[f] > 0 ? u : -u;
 }
 R3D_HD int cell_neighbor(const CellCyl& c, int f) { return f < 2 ? c.nbr[f] : -1; }
-R3D_HD int cell_neighbor(const CellTet& c, int f) { return c.nbr[f]; }
+R3D_HD int cell_neighbor(const CellTet& c, int f) { return tet_link_neighbor(c.link[f]); }
 R3D_HD int cell_neighbor(const CellSph& c, int f) { return c.nbr[f]; }
+R3D_HD uint32_t cell_face_flags(const CellCyl& c, int f) { return face_flags(c.flags, f); }
+R3D_HD uint32_t cell_face_flags(const CellTet& c, int f) { return tet_link_flags(c.link[f]); }
+R3D_HD uint32_t cell_face_flags(const CellSph& c, int f) { return face_flags(c.flags, f); }
+R3D_HD int cell_scat(const CellCyl& c) { return c.scat; }
+R3D_HD int cell_scat(const CellTet& c) { return tet_link_scat(c.link); }
+R3D_HD int cell_scat(const CellSph& c) { return c.scat; }
 
 // ---- source spray ----------------------------------------------------------
 R3D_HD void spray(const KArgs& a, Phonon& p, Rng& rng) {
@@ -171,6 +191,7 @@ struct Pending {
   double vel;        // phonon's velocity at the arrival point (for the seismometers)
   int32_t face;      // face reached, or -1 if the phonon scattered inside the cell
   uint32_t flags;    // that face's flags
+  int32_t nbr;       // the cell behind that face (-1: none), read while the cell's record is at hand
 };
 
 // First half (phonons.cpp:549-623): termination checks, boundary search,
@@ -195,11 +216,23 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
     p.recent = 0;
   }
   st.iterations++;
-  const Cell& c = T.cells[p.cell];
+  // Tetra records come from L2, a round trip of a microsecond under load.  The WHOLE record is read
+  // into registers here, ahead of the move's random number: the fence below keeps later code from
+  // moving up, so loads written at their uses -- inside the boundary search, and the links and the
+  // attenuation constant at the very end of the move -- would be issued after the draw and, the late
+  // ones, cost the wave a second and a third round trip.  (Layered and spherical records sit in LDS.)
+  using CellHere = typename std::conditional<KIND == CELL_TET, const Cell, const Cell&>::type;
+  CellHere c = cell_rec<KIND>(T, p.cell, p.type);
+  if constexpr (KIND == CELL_TET) R3D_SCHED_FENCE();   // (the loads above, THEN the draw: left to itself the scheduler puts the draw first)
   // The move's one uniform (for the free path, below) is drawn here: it depends on nothing, and
   // its hundred integer instructions fill the wait for the cell record, which everything else
   // in the move needs.
-  const double u_free = rng_draw(rng, rng_key(a.seed));
+  double u_free = rng_draw(rng, rng_key(a.seed));
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (pinned: without this the optimiser sinks the whole generator down to the free-path test, its
+  //  first use, and the wave sits out the record's round trip with nothing to do)
+  asm volatile("" : "+v"(u_free));
+#endif
   R3D_SCHED_FENCE();
 
   // --- where does the ray leave the cell? (phonons.cpp:590)
@@ -226,7 +259,7 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
   //     (scatterers.cpp:297-307, phonons.cpp:601)
   // scatlen = -ln(u) mfp.  Since -ln(u) >= 1 - u, (1-u) mfp >= len already rules a scatter
   // out, and the logarithm is only taken for the lanes that pass this screen.
-  const double mfp = T.scat_head[c.scat].mfp[p.type];
+  const double mfp = T.scat_head[cell_scat(c)].mfp[p.type];
   double scatlen = pos_inf();
   if (!((1.0 - u_free) * mfp >= e.len)) scatlen = -log_lean(u_free) * mfp;
   const bool scatters = scatlen < e.len;
@@ -254,9 +287,36 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
   }
 
   ev.face = scatters ? -1 : e.face;
-  ev.flags = scatters ? 0u : face_flags(c.flags, e.face);
+  if constexpr (KIND == CELL_TET) {   // (selects, not an index into the four words: that would be a table in scratch)
+    const uint32_t lk = e.face == 0 ? c.link[0] : e.face == 1 ? c.link[1] : e.face == 2 ? c.link[2] : c.link[3];
+    ev.flags = scatters ? 0u : tet_link_flags(lk);
+    ev.nbr = scatters ? -1 : tet_link_neighbor(lk);
+  } else {
+    ev.flags = scatters ? 0u : cell_face_flags(c, e.face);
+    ev.nbr = scatters ? -1 : cell_neighbor(c, e.face);
+  }
   ev.vel = cell_velocity(c, p.loc, p.type);
   return FATE_ALIVE;
+}
+
+// Elastic properties either side of the face the phonon sits on (CellFace::GetRTBasis,
+// media_cellface.cpp:122-149).
+template <int KIND>
+R3D_HD Iface rt_interface(const KArgs& a, const Tables<KIND>& T, const Phonon& p, const Pending& ev, int nbr) {
+  using Cell = typename CellOf<KIND>::type;
+  const Cell& c = cell_rec<KIND>(T, p.cell, p.type);
+  const bool adjoin = (ev.flags & F_ADJOIN) != 0;
+  Iface f;
+  f.normal = cell_face_normal(c, ev.face, p.loc);
+  f.vR[0] = velocity_in<KIND>(T, p.cell, p.loc, 0), f.vR[1] = velocity_in<KIND>(T, p.cell, p.loc, 1);
+  f.rhoR = cell_density(a, c, p.cell, p.loc);
+  f.has_neighbor = adjoin;
+  f.vT[0] = f.vT[1] = f.rhoT = 0;
+  if (adjoin) {
+    f.vT[0] = velocity_in<KIND>(T, nbr, p.loc, 0), f.vT[1] = velocity_in<KIND>(T, nbr, p.loc, 1);
+    f.rhoT = cell_density(a, cell_rec<KIND>(T, nbr, p.type), nbr, p.loc);
+  }
+  return f;
 }
 
 // Second half (phonons.cpp:611-618, :640-676): scatter, or act on the face
@@ -274,15 +334,16 @@ template <int KIND, int PART = EV_ALL>
 R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng, LaneStats& st,
                       const Pending& ev, int nbr_known = -2) {
   using Cell = typename CellOf<KIND>::type;
-  const Cell& c = T.cells[p.cell];
+  const Cell& c = cell_rec<KIND>(T, p.cell, p.type);
   if (PART == EV_SCATTER || (PART != EV_RT && PART != EV_BEND && ev.face < 0)) {
     // Scatterer::GetRandomScatteredRelativePhonon, scatterers.cpp:318-363
     st.scatter++;
     if (a.no_deflect) {
       scatter_transform(p, v3(a.nodeflect_dir), 1.0, 0.0, p.type);
     } else {
-      const ScatHead& sh = T.scat_head[c.scat];
-      const ScatPtrs* sp = T.scat_ptrs + c.scat;   // (indexed in place: a local copy would go to scratch)
+      const int scat = cell_scat(c);
+      const ScatHead& sh = T.scat_head[scat];
+      const ScatPtrs* sp = T.scat_ptrs + scat;   // (indexed in place: a local copy would go to scratch)
       int conv = sample_small(sh.whole[p.type], 4, rng_draw(rng, rng_key(a.seed)));  // GPP GPS GSP GSS
 #ifdef R3D_ABLATE_SCATTER   // timing-only developer build: no table search
       uint64_t k = (uint64_t)(rng_draw(rng, rng_key(a.seed)) * (double)(a.n_toa - 1));
@@ -311,19 +372,10 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
   //  fetched at once instead of the neighbour's waiting for this cell's)
   const int nbr = (nbr_known != -2) ? nbr_known : cell_neighbor(c, ev.face);
   const bool adjoin = (fl & F_ADJOIN) != 0;
+  (void)adjoin;   // (only the timing-only R3D_ABLATE_RT build reads it here)
   bool crossed;
   if (PART != EV_LIGHT && PART != EV_BEND && (PART == EV_RT || (fl & F_REFLECT) || (fl & F_DISCON))) {
-    Iface f;
-    f.normal = cell_face_normal(c, ev.face, p.loc);
-    f.vR[0] = cell_velocity(c, p.loc, 0), f.vR[1] = cell_velocity(c, p.loc, 1);
-    f.rhoR = cell_density(a, c, p.cell, p.loc);
-    f.has_neighbor = adjoin;
-    f.vT[0] = f.vT[1] = f.rhoT = 0;
-    if (adjoin) {
-      const Cell& o = T.cells[nbr];
-      f.vT[0] = cell_velocity(o, p.loc, 0), f.vT[1] = cell_velocity(o, p.loc, 1);
-      f.rhoT = cell_density(a, o, nbr, p.loc);
-    }
+    const Iface f = rt_interface<KIND>(a, T, p, ev, nbr);
     st.rtsolve++;
 #ifdef R3D_ABLATE_RT   // timing-only developer build: specular bounce / coin-flip transmission
     {
@@ -341,18 +393,20 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
   } else {
     // Phonon::Refract without a grid discontinuity (phonons.cpp:243-252):
     // bend on a fractional velocity step > 1e-5, else plain hand-over.
-    const Cell& o = T.cells[nbr];
-    double v1 = cell_velocity(c, p.loc, 0), v2 = cell_velocity(o, p.loc, 0);
-    double w1 = cell_velocity(c, p.loc, 1), w2 = cell_velocity(o, p.loc, 1);
+    // (tetra cells hold one record per ray type: the phonon's own type first -- the bend needs nothing else)
+    const int ty = p.type;
+    const double vi = cell_velocity(c, p.loc, ty), vo = velocity_in<KIND>(T, nbr, p.loc, ty);
     bool step = (fl & F_STEP) != 0;
-    if (!step) {      // straddling face: evaluate the reference's test here
+    if (!step) {      // straddling face: evaluate the reference's test here, on both ray types
+      const double ui = velocity_in<KIND>(T, p.cell, p.loc, 1 - ty), uo = velocity_in<KIND>(T, nbr, p.loc, 1 - ty);
+      const double v1 = ty == RAY_P ? vi : ui, v2 = ty == RAY_P ? vo : uo;
+      const double w1 = ty == RAY_P ? ui : vi, w2 = ty == RAY_P ? uo : vo;
       double dvp = fabs(2 * (v2 - v1) / (v2 + v1));
       double dvs = fabs(2 * (w2 - w1) / (w2 + w1));
       step = (dvp > dvs ? dvp : dvs) > 0.00001;
     }
     if (step) {
-      crossed = bend(p, cell_face_normal(c, ev.face, p.loc), p.type == RAY_P ? v1 : w1,
-                     p.type == RAY_P ? v2 : w2);
+      crossed = bend(p, cell_face_normal(c, ev.face, p.loc), vi, vo);
     } else {
       crossed = true;
     }
@@ -371,28 +425,14 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
 // go of everything but the two words of the choice, reloads the phonon and applies it.  Together
 // they are step_event<KIND, EV_RT>.
 template <int KIND>
-R3D_HD Iface rt_interface(const KArgs& a, const Tables<KIND>& T, const Phonon& p, const Pending& ev, int nbr) {
-  using Cell = typename CellOf<KIND>::type;
-  const Cell& c = T.cells[p.cell];
-  const bool adjoin = (ev.flags & F_ADJOIN) != 0;
-  Iface f;
-  f.normal = cell_face_normal(c, ev.face, p.loc);
-  f.vR[0] = cell_velocity(c, p.loc, 0), f.vR[1] = cell_velocity(c, p.loc, 1);
-  f.rhoR = cell_density(a, c, p.cell, p.loc);
-  f.has_neighbor = adjoin;
-  f.vT[0] = f.vT[1] = f.rhoT = 0;
-  if (adjoin) {
-    const Cell& o = T.cells[nbr];
-    f.vT[0] = cell_velocity(o, p.loc, 0), f.vT[1] = cell_velocity(o, p.loc, 1);
-    f.rhoT = cell_density(a, o, nbr, p.loc);
-  }
-  return f;
-}
-template <int KIND>
 R3D_HD RtChoice rt_event_choose(const KArgs& a, const Tables<KIND>& T, const Phonon& p, Rng& rng, LaneStats& st,
                                 const Pending& ev, int nbr) {
   st.rtsolve++;
-  return rt_choose(p, rt_interface<KIND>(a, T, p, ev, nbr), rng, rng_key(a.seed));
+  // (measured and kept out: the six tetra records' fields read by value ahead of the draws, as the
+  //  move does with its record -- +-0: the solve is long enough to cover its own fetches)
+  double u_pol, u_out;
+  rt_draws(p, rng, rng_key(a.seed), u_pol, u_out);
+  return rt_choose(p, rt_interface<KIND>(a, T, p, ev, nbr), u_pol, u_out);
 }
 template <int KIND>
 R3D_HD void rt_event_apply(const KArgs& a, const Tables<KIND>& T, Phonon& p, LaneStats& st, const Pending& ev,
@@ -414,7 +454,7 @@ R3D_HD int step(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng, Lane
   int fate = step_move<KIND>(a, T, p, rng, st, reason, ev);
   if (fate != FATE_ALIVE) return fate;
   if (ev.flags & F_COLLECT) collect<KIND>(a, T, p, ev.vel, st);
-  return step_event<KIND>(a, T, p, rng, st, ev);
+  return step_event<KIND>(a, T, p, rng, st, ev, ev.face < 0 ? -2 : ev.nbr);
 }
 
 }  // namespace r3d

@@ -42,20 +42,36 @@ struct alignas(16) CellCyl {
   int32_t scat;
 };
 
-// Tetrahedral cell with linear velocity (reference Tetra, media.hpp:400-408).
-struct alignas(16) CellTet {
-  double g[2][3];     // grad Vp, grad Vs
-  double v0[2];       // velocity at the origin
-  double inv_gmag[2]; // 1 / |grad v|
-  double att[2];
+// Tetrahedral cell with linear velocity (reference Tetra, media.hpp:400-408): ONE RECORD PER CELL
+// AND RAY TYPE (index 2 * cell + type), three 64-byte lines holding everything a move of that type
+// reads -- twelve 16-byte loads per lane.  A gather from thousands of records costs the L1 path
+// ~55-70 cycles per 64-lane load instruction whatever its width (tools/microbench/gather.hip: 445 ns
+// per wave for a 256-byte record fetched as 16 x 16 bytes, 275 ns for 192 bytes as 12 x 16, 730 ns for
+// 192 bytes as 24 x 8), and the tetra move's fetch kept the texture path busy two thirds of the
+// launch (profiles/r02: TA_BUSY 66 %): so no field of the other ray type, no 8- or 4-byte loads.
+// link[f]: the neighbour behind face f + 1 in bits 0-21 (0: none), the face's flag byte's low six bits
+// in bits 22-27, and in bits 28-31 nibble f of the cell's scatterer index.
+struct alignas(64) CellTet {
+  double g[3];        // grad v (this ray type)
+  double v0;          // velocity at the origin
+  double inv_gmag;    // 1 / |grad v|
+  double att;         // -pi f / Q
   double n[4][3];
   double d[4];
-  int32_t nbr[4];
-  uint32_t flags;
-  int32_t scat;
-  double pad_;
+  uint32_t link[4];
 };
-static_assert(sizeof(CellTet) == 256, "CellTet is one 256-byte record");
+static_assert(sizeof(CellTet) == 192, "a tetra record is three 64-byte lines");
+constexpr uint32_t kTetNbrBits = 22, kTetNbrMask = (1u << kTetNbrBits) - 1u;
+#if defined(__HIPCC__)
+#define R3D_TBL_HD __host__ __device__
+#else
+#define R3D_TBL_HD
+#endif
+R3D_TBL_HD inline int tet_link_neighbor(uint32_t link) { return (int)(link & kTetNbrMask) - 1; }
+R3D_TBL_HD inline uint32_t tet_link_flags(uint32_t link) { return (link >> kTetNbrBits) & 0x3Fu; }
+R3D_TBL_HD inline int tet_link_scat(const uint32_t link[4]) {
+  return (int)((link[0] >> 28) | ((link[1] >> 28) << 4) | ((link[2] >> 28) << 8) | ((link[3] >> 28) << 12));
+}
 
 // Spherical shell, v(r) = a r^2 + c (reference SphereShell, media.hpp:467-478).
 struct alignas(16) CellSph {
