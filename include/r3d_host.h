@@ -76,6 +76,20 @@ const char* r3dh_write_reports(r3dh_model* m, const r3d_event* events, uint64_t 
  * And the axes scheme of seismometer i (model.cpp:486-491): 0 ENZ, 1 RTZ, -1 out of range.
  * For tests that restate the builders (oracle/r3d_tables_oracle.cpp).  Returns 0 ok.         */
 int r3dh_model_coordinates(const r3dh_model* m, int* map_code, double* earth_radius, int* flattened);
+/* The grid as the cell builders see it (reference grid.hpp:341-403): dims = ni, nj, nk; nodes in the
+ * grid's own order (k slowest, then j, then i), each with its model-space location (GridNode::Loc),
+ * its radius from the Earth's centre (curved mappings; else 0), the number of attribute sets given
+ * (2 = a first-order discontinuity) and Data(GN_ABOVE) / Data(GN_BELOW) after the coordinate system's
+ * conversion: vp vs rho qp qs nu eps a kappa.  Valid while this model is the most recently built one. */
+typedef struct r3dh_grid_node {
+  double  loc[3];
+  double  radius;
+  double  side[2][9];
+  int32_t n_sets;
+  int32_t pad_;
+} r3dh_grid_node;
+int r3dh_grid_size(const r3dh_model* m, int dims[3]);
+int r3dh_grid_nodes(const r3dh_model* m, r3dh_grid_node* out, size_t capacity);
 int r3dh_seismometer_axes(const r3dh_model* m, int i);
 
 const char* r3dh_last_error(void);

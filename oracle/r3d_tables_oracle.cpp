@@ -1,7 +1,8 @@
 // r3d_tables_oracle.cpp -- CPU restatement of the reference's TABLE BUILDERS: everything the hot
 // path reads that is computed once, before the first phonon -- the take-off-angle set, the
 // scatterers' radiation-pattern tables / mean free paths / dipole moments, the event source's
-// moment tensor and P / SH / SV patterns, the seismometers' axes and gather areas.
+// moment tensor and P / SH / SV patterns, the seismometers' axes and gather areas, and the cell arrays
+// of the three model kinds (faces, links, flags, velocity / density fits, scatterer sharing).
 //
 // ***  TEST INFRASTRUCTURE ONLY.  ***  Nothing in the product may include, link or call this
 // file; only tests/ use it, as the checker for the two table builders the product has (the
@@ -22,6 +23,8 @@
 #include <cstdint>
 #include <cstring>
 #include <vector>
+
+#include "../include/r3d.h"   // (plain-C table layouts only: r3d_cell / r3d_face are what the builders fill)
 
 namespace {
 
@@ -398,6 +401,303 @@ void r3d_oracle_seismometer(int map, double radE, const double event_loc[3], con
   const V ax[3] = {x1, x2, x3};
   for (int k = 0; k < 3; k++) axes[k][0] = ax[k].x, axes[k][1] = ax[k].y, axes[k][2] = ax[k].z;
   for (int t = 0; t < 2; t++) area[t] = (r_out[t] * r_out[t] - r_in[t] * r_in[t]) * PI;
+}
+
+
+}  // extern "C"
+
+// ============================================================ cell builders ==
+// Model::BuildCellArray_Cylinder / _SphericalShells / _WCGTetra (model.cpp:647-934, :1017-1228) with
+// the cell and face constructors they call (media.cpp:130-156, :353-395, :578-626;
+// media_cellface.cpp:46-70, :176-214; geom_r4.cpp:15-66) and the scatterer sharing rule
+// (scatterers.cpp:45-91), from the grid's nodes as Model sees them: model-space location, both
+// attribute sets after the coordinate system's conversion, the discontinuity flag.
+namespace {
+
+struct NodeSide {   // GridData as the builders read it
+  double vp, vs, rho, qp, qs, nu, eps, a, kappa;
+};
+struct GridNodeIn {   // (the C layout of r3d_oracle_node, below)
+  double loc[3];
+  double radius;      // GetRawLoc().Radius(ECS), spherical grids
+  double side[2][9];  // [GN_ABOVE], [GN_BELOW]
+  int32_t n_sets;     // 2: the node is a first-order discontinuity
+  int32_t pad_;
+};
+inline V loc_of(const GridNodeIn& n) { return mk(n.loc[0], n.loc[1], n.loc[2]); }
+inline NodeSide side_of(const GridNodeIn& n, int s) {
+  const double* d = n.side[s];
+  return NodeSide{d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8]};
+}
+enum { ABOVE = 0, BELOW = 1 };
+
+struct Builder {
+  std::vector<r3d_cell> cells;
+  std::vector<Het> scat;     // in creation order
+  double omega;
+  bool one_dummy;            // --overridemfp and --nodeflect together (scatterers.cpp:48-52)
+
+  // Scatterer::GetScattererMatchingParams, scatterers.cpp:45-91; ScatterParams(V, HS), scatparams.hpp:124-134
+  int scatterer_for(const NodeSide& v, const NodeSide& hs) {
+    Het par{hs.nu, hs.eps, hs.a, hs.kappa, omega / v.vs, v.vp / v.vs};
+    if (one_dummy) par = Het{1.0, 0.0, 1.0, 1.0, 1.0, 1.0};   // HSneak(1.0, 0.0, 1.0, 1.0), el 1, gam0 1
+    for (size_t i = 0; i < scat.size(); i++) {
+      const Het& o = scat[i];   // CompareRoughly, scatparams.cpp:38-49: sum of squared differences <= 0
+      const double dnu = o.nu - par.nu, deps = o.eps - par.eps, da = o.a - par.a, dk = o.kappa - par.kappa;
+      const double del = o.el - par.el, dg = o.gam0 - par.gam0;
+      if (dnu * dnu + deps * deps + da * da + dk * dk + del * del + dg * dg <= 0) return (int)i;
+    }
+    scat.push_back(par);
+    return (int)scat.size() - 1;
+  }
+};
+
+r3d_face no_face() {
+  r3d_face f;
+  std::memset(&f, 0, sizeof f);
+  f.neighbor = -1;
+  return f;
+}
+r3d_cell no_cell(int n_faces) {
+  r3d_cell c;
+  std::memset(&c, 0, sizeof c);
+  c.scatterer = -1, c.n_faces = n_faces;
+  for (auto& f : c.faces) f = no_face();
+  return c;
+}
+// PlaneFace(N1, N2, N3), media_cellface.cpp:176-190: normal (N2 - N1) x (N3 - N1), normalised; point N1
+r3d_face plane3(V n1, V n2, V n3) {
+  r3d_face f = no_face();
+  V nrm = cross(n2 - n1, n3 - n1);
+  const double m = mag(nrm);
+  nrm = mk(nrm.x / m, nrm.y / m, nrm.z / m);   // XYZ::Normalize
+  f.normal[0] = nrm.x, f.normal[1] = nrm.y, f.normal[2] = nrm.z;
+  f.point[0] = n1.x, f.point[1] = n1.y, f.point[2] = n1.z;
+  return f;
+}
+// PlaneFace(N1, N2, N3, N4), :196-214: the same, turned away from the excluded node N4
+r3d_face plane4(V n1, V n2, V n3, V n4) {
+  r3d_face f = plane3(n1, n2, n3);
+  const V nrm = mk(f.normal[0], f.normal[1], f.normal[2]);
+  if (dot(nrm, n4 - n1) > 0) f.normal[0] = -nrm.x, f.normal[1] = -nrm.y, f.normal[2] = -nrm.z;
+  return f;
+}
+// CellFace::LinkTo(other, disc) / LinkTo(other), media_cellface.cpp:46-70
+void link(std::vector<r3d_cell>& cells, int ca, int fa, int cb, int fb, bool disc) {
+  r3d_face &A = cells[ca].faces[fa], &B = cells[cb].faces[fb];
+  A.neighbor = cb, B.neighbor = ca;
+  A.flags |= R3D_FACE_ADJOIN, B.flags |= R3D_FACE_ADJOIN;
+  A.flags = disc ? (A.flags | R3D_FACE_DISCON) : (A.flags & ~(uint32_t)R3D_FACE_DISCON);
+  B.flags = disc ? (B.flags | R3D_FACE_DISCON) : (B.flags & ~(uint32_t)R3D_FACE_DISCON);
+}
+void link_keep(std::vector<r3d_cell>& cells, int ca, int fa, int cb, int fb) {
+  const bool disc = ((cells[ca].faces[fa].flags | cells[cb].faces[fb].flags) & R3D_FACE_DISCON) != 0;
+  link(cells, ca, fa, cb, fb, disc);
+}
+
+// R4::Matrix::SolveAXB, geom_r4.cpp:15-66: Gauss-Jordan on the augmented rows, with the reference's own
+// pivot search (it compares every candidate with ROW i, not with the best so far, and so ends on the
+// LAST row that beats row i), rows scaled by 1 / pivot, elimination below, then back-substitution.
+void solve_axb(const double A[4][4], const double b[4], double x[4]) {
+  double row[4][5];
+  for (int r = 0; r < 4; r++) {
+    for (int c = 0; c < 4; c++) row[r][c] = A[r][c];
+    row[r][4] = b[r];
+  }
+  for (int i = 0; i < 4; i++) {
+    int largest = i;
+    for (int k = i; k < 4; k++)
+      if (std::abs(row[k][i]) > std::abs(row[i][i])) largest = k;
+    if (largest != i)
+      for (int c = 0; c < 5; c++) std::swap(row[largest][c], row[i][c]);
+    if (row[i][i] != 0) {
+      const double s = 1 / row[i][i];
+      for (int c = 0; c < 5; c++) row[i][c] *= s;
+      for (int j = 1; j < 4 - i; j++) {
+        const double f = row[i + j][i];
+        for (int c = 0; c < 5; c++) row[i + j][c] -= row[i][c] * f;
+      }
+    }
+  }
+  for (int j = 3; j >= 1; j--)
+    for (int i = 0; i <= j - 1; i++) {
+      const double f = row[i][j];
+      for (int c = 0; c < 5; c++) row[i][c] -= row[j][c] * f;
+    }
+  for (int r = 0; r < 4; r++) x[r] = row[r][4];
+}
+
+// Tetra::Tetra, media.cpp:353-395
+r3d_cell tetra(const V n[4], const NodeSide d[4]) {
+  r3d_cell c = no_cell(4);
+  c.faces[0] = plane4(n[1], n[2], n[3], n[0]);
+  c.faces[1] = plane4(n[2], n[3], n[0], n[1]);
+  c.faces[2] = plane4(n[3], n[0], n[1], n[2]);
+  c.faces[3] = plane4(n[0], n[1], n[2], n[3]);
+  double A[4][4], col[3][4], x[4];
+  for (int r = 0; r < 4; r++) {
+    A[r][0] = n[r].x, A[r][1] = n[r].y, A[r][2] = n[r].z, A[r][3] = 1;
+    col[0][r] = d[r].vp, col[1][r] = d[r].vs, col[2][r] = d[r].rho;
+  }
+  for (int t = 0; t < 2; t++) {
+    solve_axb(A, col[t], x);
+    for (int k = 0; k < 3; k++) c.vel_grad[t][k] = x[k];
+    c.vel_c[t] = x[3];
+  }
+  solve_axb(A, col[2], x);
+  for (int k = 0; k < 3; k++) c.rho_grad[k] = x[k];
+  c.rho_c = x[3];
+  c.q[0] = (d[0].qp + d[1].qp + d[2].qp + d[3].qp) / 4;
+  c.q[1] = (d[0].qs + d[1].qs + d[2].qs + d[3].qs) / 4;
+  return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+typedef struct r3d_oracle_node {
+  double  loc[3];       /* GridNode::Loc(): model space                                        */
+  double  radius;       /* GetRawLoc().Radius(ECS) (spherical grids; else unused)              */
+  double  side[2][9];   /* Data(GN_ABOVE), Data(GN_BELOW): vp vs rho qp qs nu eps a kappa      */
+  int32_t n_sets;       /* attribute sets given: 2 = discontinuous node                        */
+  int32_t pad_;
+} r3d_oracle_node;
+
+// kind: R3D_CELL_*; nodes in the grid's own order (k slowest, then j, then i: grid.hpp flat index);
+// cells_out has room for cells_cap cells, het_out for het_cap scatterers of six doubles (nu, eps, a,
+// kappa, el, gam0).  Returns the number of cells (negative on a size error); *n_scat the scatterers.
+int r3d_oracle_build_cells(int kind, int ni, int nj, int nk, const r3d_oracle_node* nodes_c, double frequency,
+                           double cylinder_range, int one_dummy_scatterer, r3d_cell* cells_out, int cells_cap,
+                           double* het_out, int het_cap, int* n_scat) {
+  const GridNodeIn* nodes = reinterpret_cast<const GridNodeIn*>(nodes_c);
+  static_assert(sizeof(GridNodeIn) == sizeof(r3d_oracle_node), "one layout");
+  auto node = [&](int i, int j, int k) -> const GridNodeIn& { return nodes[(size_t)k * nj * ni + (size_t)j * ni + i]; };
+  Builder B;
+  B.omega = 2.0 * frequency * PI;   // ScatterParams::SetFrequencyHertz, scatparams.hpp
+  B.one_dummy = one_dummy_scatterer != 0;
+  if (kind == R3D_CELL_CYLINDER) {   // model.cpp:647-724 + RCUCylinder, media.cpp:130-156
+    const int nc = nk - 1;
+    for (int k = 0; k < nc; k++) {
+      const NodeSide top = side_of(node(0, 0, k), BELOW);
+      r3d_cell c = no_cell(3);
+      c.faces[0] = plane3(loc_of(node(0, 0, k)), loc_of(node(1, 0, k)), loc_of(node(2, 0, k)));               // up
+      c.faces[1] = plane3(loc_of(node(0, 0, k + 1)), loc_of(node(2, 0, k + 1)), loc_of(node(1, 0, k + 1)));   // down
+      c.faces[2].radius = cylinder_range;   // cmLossFace: shared, never linked (media.cpp:124-125)
+      c.vel_c[0] = top.vp, c.vel_c[1] = top.vs;
+      c.rho_c = top.rho;
+      c.q[0] = top.qp, c.q[1] = top.qs;
+      c.scatterer = B.scatterer_for(top, top);
+      B.cells.push_back(c);
+    }
+    for (int k = 1; k < nc; k++) link(B.cells, k - 1, 1, k, 0, node(0, 0, k).n_sets == 2);
+    B.cells[0].faces[0].flags |= R3D_FACE_COLLECT | R3D_FACE_REFLECT;
+  } else if (kind == R3D_CELL_SPHERESHELL) {   // model.cpp:732-795 + SphereShell, media.cpp:578-626
+    const int nc = nk - 1;
+    for (int k = 0; k < nc; k++) {
+      const NodeSide top = side_of(node(0, 0, k), BELOW), bot = side_of(node(0, 0, k + 1), ABOVE);
+      const double RadTop = node(0, 0, k).radius, RadBot = node(0, 0, k + 1).radius;
+      r3d_cell c = no_cell(2);
+      c.faces[0].radius = RadTop;    // SphereFace(RadTop, F_TOP): outward
+      c.faces[1].radius = -RadBot;   // SphereFace(RadBot, F_BOTTOM): inward (signed radius, include/r3d.h)
+      const double denom = RadTop * RadTop - RadBot * RadBot;
+      c.vel_a[0] = (top.vp - bot.vp) / denom;
+      c.vel_a[1] = (top.vs - bot.vs) / denom;
+      c.rho_a = (top.rho - bot.rho) / denom;
+      c.vel_c[0] = top.vp - (c.vel_a[0] * RadTop * RadTop);
+      c.vel_c[1] = top.vs - (c.vel_a[1] * RadTop * RadTop);
+      c.rho_c = top.rho - (c.rho_a * RadTop * RadTop);
+      c.zero_rad2[0] = -c.vel_c[0] / c.vel_a[0];
+      c.zero_rad2[1] = -c.vel_c[1] / c.vel_a[1];
+      c.q[0] = top.qp, c.q[1] = top.qs;
+      c.scatterer = B.scatterer_for(top, top);
+      B.cells.push_back(c);
+    }
+    for (int k = 1; k < nc; k++) link(B.cells, k - 1, 1, k, 0, node(0, 0, k).n_sets == 2);
+    B.cells[0].faces[0].flags |= R3D_FACE_COLLECT | R3D_FACE_REFLECT;
+  } else {   // model.cpp:880-934, WCGBuildBasicPattern :1017-1148, WCGLinkBlocksForward :1181-1228
+    const int nI = ni - 1, nJ = nj - 1, nK = nk - 1;
+    auto base = [&](int i, int j, int k) { return (i * (nK * nJ) + j * nK + k) * 5; };
+    enum { FA = 0, FB = 1, FC = 2, FD = 3 };
+    auto link_blocks = [&](int block, int adjacent, int faceid, bool mirror) {
+      int c0, c1, c2, c3;
+      if (faceid == FB) c0 = block + 2, c1 = adjacent + 1, c2 = block + 3, c3 = adjacent + 4;
+      else if (faceid == FC) c0 = block + 4, c1 = adjacent + 1, c2 = block + 3, c3 = adjacent + 2;
+      else {
+        if (mirror) block += 1, adjacent += 1;
+        c0 = block + 1, c1 = adjacent + 1, c2 = block + 3, c3 = adjacent + 3;
+      }
+      link_keep(B.cells, c0, faceid, c1, faceid);
+      link_keep(B.cells, c2, faceid, c3, faceid);
+    };
+    for (int i = 0; i < nI; i++)
+      for (int j = 0; j < nJ; j++)
+        for (int k = 0; k < nK; k++) {
+          const GridNodeIn* N[8] = {&node(i, j, k),     &node(i, j, k + 1),     &node(i, j + 1, k),     &node(i, j + 1, k + 1),
+                                    &node(i + 1, j, k), &node(i + 1, j, k + 1), &node(i + 1, j + 1, k), &node(i + 1, j + 1, k + 1)};
+          const bool mirror = (((i + j + k) % 2) == 1), surface = (k == 0);
+          NodeSide D[8];
+          V L[8];
+          bool dis[8];
+          for (int q = 0; q < 8; q++) {
+            D[q] = side_of(*N[q], (q % 2 == 0) ? BELOW : ABOVE);   // even corners are block tops, odd ones bottoms
+            L[q] = loc_of(*N[q]);
+            dis[q] = N[q]->n_sets == 2;
+          }
+          auto T = [&](int a, int b, int c, int d) {
+            const V n[4] = {L[a], L[b], L[c], L[d]};
+            const NodeSide dd[4] = {D[a], D[b], D[c], D[d]};
+            return tetra(n, dd);
+          };
+          r3d_cell t[5];
+          int vel_from[5];
+          if (!mirror) {
+            t[0] = T(6, 5, 0, 3), t[1] = T(1, 3, 5, 0), t[2] = T(2, 0, 6, 3), t[3] = T(7, 5, 3, 6), t[4] = T(4, 6, 0, 5);
+            const int from[5] = {0, 0, 2, 6, 4};
+            std::memcpy(vel_from, from, sizeof from);
+          } else {
+            t[0] = T(7, 4, 1, 2), t[1] = T(0, 2, 4, 1), t[2] = T(3, 1, 7, 2), t[3] = T(6, 4, 2, 7), t[4] = T(5, 7, 1, 4);
+            const int from[5] = {4, 0, 2, 6, 4};
+            std::memcpy(vel_from, from, sizeof from);
+          }
+          for (int q = 0; q < 5; q++) t[q].scatterer = B.scatterer_for(D[vel_from[q]], D[0]);   // HetSpec always from node [0]
+          auto set_dis = [&](int cell, bool v) {
+            if (v) t[cell].faces[FD].flags |= R3D_FACE_DISCON;
+          };
+          if (!mirror) {
+            set_dis(4, dis[0] || dis[4] || dis[6]), set_dis(2, dis[0] || dis[2] || dis[6]);
+            set_dis(1, dis[1] || dis[5] || dis[3]), set_dis(3, dis[5] || dis[7] || dis[3]);
+          } else {
+            set_dis(1, dis[0] || dis[4] || dis[2]), set_dis(3, dis[4] || dis[2] || dis[6]);
+            set_dis(4, dis[1] || dis[5] || dis[7]), set_dis(2, dis[1] || dis[7] || dis[3]);
+          }
+          const int b0 = (int)B.cells.size();
+          for (int q = 0; q < 5; q++) B.cells.push_back(t[q]);
+          link(B.cells, b0 + 0, FA, b0 + 1, FA, false);
+          link(B.cells, b0 + 0, FB, b0 + 2, FA, false);
+          link(B.cells, b0 + 0, FC, b0 + 3, FA, false);
+          link(B.cells, b0 + 0, FD, b0 + 4, FA, false);
+          if (surface) {
+            const int s1 = mirror ? 1 : 2, s2 = mirror ? 3 : 4;
+            B.cells[b0 + s1].faces[FD].flags |= R3D_FACE_REFLECT | R3D_FACE_COLLECT;
+            B.cells[b0 + s2].faces[FD].flags |= R3D_FACE_REFLECT | R3D_FACE_COLLECT;
+          }
+          const int block = base(i, j, k);
+          const bool adjmirror = !mirror;
+          if (i > 0) link_blocks(base(i - 1, j, k), block, FC, adjmirror);
+          if (j > 0) link_blocks(base(i, j - 1, k), block, FB, adjmirror);
+          if (k > 0) link_blocks(base(i, j, k - 1), block, FD, adjmirror);
+        }
+  }
+  if ((int)B.cells.size() > cells_cap || (int)B.scat.size() > het_cap) return -1;
+  for (size_t i = 0; i < B.cells.size(); i++) cells_out[i] = B.cells[i];
+  for (size_t s = 0; s < B.scat.size(); s++) {
+    const Het& h = B.scat[s];
+    const double v[6] = {h.nu, h.eps, h.a, h.kappa, h.el, h.gam0};
+    for (int k = 0; k < 6; k++) het_out[6 * s + k] = v[k];
+  }
+  if (n_scat) *n_scat = (int)B.scat.size();
+  return (int)B.cells.size();
 }
 
 }  // extern "C"

@@ -27,6 +27,11 @@ def lib():
         L.r3d_oracle_moment_tensor.argtypes = [C.c_int, _dp, C.c_int, C.c_double, _dp, _dp, _dp]
         L.r3d_oracle_source.argtypes = [_dp, _dp, C.c_uint64, C.POINTER(_dp), _dp]
         L.r3d_oracle_seismometer.argtypes = [C.c_int, C.c_double, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp]
+        from radiative3d_amd import _ffi
+        L.r3d_oracle_build_cells.restype = C.c_int
+        L.r3d_oracle_build_cells.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_ffi.GridNode), C.c_double,
+                                             C.c_double, C.c_int, C.POINTER(_ffi.Cell), C.c_int, _dp, C.c_int,
+                                             C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -94,3 +99,19 @@ def seismometer(map_code, earth_radius, event_loc, loc, rtz, r_in, r_out):
     lib().r3d_oracle_seismometer(map_code, earth_radius, _p(_vec(event_loc)), _p(_vec(loc)), int(rtz), _p(_vec(r_in)),
                                  _p(_vec(r_out)), _p(axes), _p(area))
     return axes, area
+
+
+def build_cells(kind, dims, nodes, frequency, cylinder_range=0.0, one_dummy_scatterer=False):
+    """Model::BuildCellArray_{Cylinder, WCGTetra, SphericalShells} (model.cpp:647-934, :1017-1228) from the
+    grid's nodes -> (array of _ffi.Cell, het[n_scat, 6] in creation order)."""
+    from radiative3d_amd import _ffi
+    ni, nj, nk = dims
+    cap = max(1, (ni - 1) * (nj - 1) * (nk - 1) * 5 if kind == 1 else nk)
+    cells = (_ffi.Cell * cap)()
+    het = np.zeros((cap, 6))
+    n_scat = C.c_int()
+    n = lib().r3d_oracle_build_cells(kind, ni, nj, nk, nodes, frequency, cylinder_range, int(one_dummy_scatterer), cells,
+                                     cap, _p(het), cap, C.byref(n_scat))
+    if n < 0:
+        raise RuntimeError("r3d_oracle_build_cells: output too small")
+    return cells, n, het[:n_scat.value]

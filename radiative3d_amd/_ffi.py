@@ -66,6 +66,12 @@ class ModelDesc(C.Structure):
                 ("toa_degree", C.c_int32), ("pad_", C.c_int32)]
 
 
+class GridNode(C.Structure):
+    """r3dh_grid_node (include/r3d_host.h) == r3d_oracle_node (oracle/r3d_tables_oracle.cpp)."""
+    _fields_ = [("loc", C.c_double * 3), ("radius", C.c_double), ("side", (C.c_double * 9) * 2),
+                ("n_sets", C.c_int32), ("pad_", C.c_int32)]
+
+
 class Result(C.Structure):
     _fields_ = [("energy", _dp), ("counts", C.POINTER(C.c_uint64)), ("n_lost", C.c_uint64),
                 ("n_timeout", C.c_uint64), ("n_invalid", C.c_uint64),
@@ -153,6 +159,10 @@ def host_lib():
         L.r3dh_write_outputs.argtypes = [C.c_void_p, C.POINTER(Result), C.c_char_p, C.c_char_p, C.c_char_p]
         L.r3dh_model_coordinates.restype = C.c_int
         L.r3dh_model_coordinates.argtypes = [C.c_void_p, C.POINTER(C.c_int), _dp, C.POINTER(C.c_int)]
+        L.r3dh_grid_size.restype = C.c_int
+        L.r3dh_grid_size.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.r3dh_grid_nodes.restype = C.c_int
+        L.r3dh_grid_nodes.argtypes = [C.c_void_p, C.POINTER(GridNode), C.c_size_t]
         L.r3dh_seismometer_axes.restype = C.c_int
         L.r3dh_seismometer_axes.argtypes = [C.c_void_p, C.c_int]
         _host = L

@@ -1,6 +1,7 @@
 // capi.cpp -- C-ABI of the host model builder (include/r3d_host.h).
 // Exceptions never cross the boundary: they become a NULL / non-zero return
 // plus a thread-local message.
+#include <cstring>
 #include <sstream>
 
 #include "../../include/r3d_host.h"
@@ -158,6 +159,46 @@ int r3dh_model_coordinates(const r3dh_model* m, int* map_code, double* earth_rad
   if (earth_radius) *earth_radius = m->model->EarthRadius();
   if (flattened) *flattened = m->params.Flatten ? 1 : 0;
   return 0;
+}
+
+int r3dh_grid_size(const r3dh_model* m, int dims[3]) {
+  if (!m || !dims) return 1;
+  const Grid& g = m->model->GetGridRef();
+  dims[0] = (int)g.Ni(), dims[1] = (int)g.Nj(), dims[2] = (int)g.Nk();
+  return 0;
+}
+
+int r3dh_grid_nodes(const r3dh_model* m, r3dh_grid_node* out, size_t capacity) {
+  if (!m || !out) return 1;
+  try {
+    // (through the global coordinate system, which still holds this model's mapping only if no
+    //  other model was built since -- as for r3dh_grid_dump)
+    const Grid& g = m->model->GetGridRef();
+    if ((size_t)g.N() > capacity) throw Runtime("r3dh_grid_nodes: output too small");
+    size_t at = 0;
+    for (Index k = 0; k < g.Nk(); k++)
+      for (Index j = 0; j < g.Nj(); j++)
+        for (Index i = 0; i < g.Ni(); i++) {
+          const GridNode& n = g.Node(i, j, k);
+          r3dh_grid_node& o = out[at++];
+          std::memset(&o, 0, sizeof o);
+          const R3::XYZ loc = n.Loc();
+          o.loc[0] = loc.x(), o.loc[1] = loc.y(), o.loc[2] = loc.z();
+          o.radius = ECS.CurvedCoords() ? n.GetRawLoc().Radius(ECS) : 0.0;
+          o.n_sets = n.NumAttributeSets();
+          if (o.n_sets == 0) continue;
+          for (int s = 0; s < 2; s++) {
+            const GridData d = n.Data(s == 0 ? GridNode::GN_ABOVE : GridNode::GN_BELOW);
+            const double v[9] = {d.Vp(), d.Vs(), d.Rho(), d.Qp(), d.Qs(), d.getHS().nu(), d.getHS().eps(),
+                                 d.getHS().a(), d.getHS().kappa()};
+            for (int q = 0; q < 9; q++) o.side[s][q] = v[q];
+          }
+        }
+    return 0;
+  } catch (const std::exception& e) {
+    g_error = e.what();
+  }
+  return 1;
 }
 
 int r3dh_seismometer_axes(const r3dh_model* m, int i) {

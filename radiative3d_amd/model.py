@@ -161,6 +161,17 @@ class Model:
         self._lib.r3dh_model_coordinates(self._h, C.byref(code), C.byref(rad), C.byref(flat))
         return code.value, rad.value, bool(flat.value)
 
+    def grid_nodes(self):
+        """((ni, nj, nk), array of _ffi.GridNode): the grid as the cell builders see it.  Call right
+        after building the model (the coordinate system is process-global, as in the reference)."""
+        dims = (C.c_int * 3)()
+        self._lib.r3dh_grid_size(self._h, dims)
+        n = dims[0] * dims[1] * dims[2]
+        nodes = (_ffi.GridNode * n)()
+        if self._lib.r3dh_grid_nodes(self._h, nodes, n):
+            raise RuntimeError("r3dh_grid_nodes failed: " + self._lib.r3dh_last_error().decode())
+        return tuple(dims), nodes
+
     def seismometer_axes(self, i):
         """0 ENZ, 1 RTZ (model.cpp:486-491)."""
         return int(self._lib.r3dh_seismometer_axes(self._h, i))

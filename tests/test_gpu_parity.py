@@ -609,7 +609,9 @@ def test_reproducible_build_defines_every_history_to_the_bit(models, monkeypatch
         torch.cuda.synchronize()
         rc = total.to_result()
         assert (rc.counts == ra.counts).all() and rc.events == ra.events
-        assert np.allclose(rc.energy, ra.energy, rtol=1e-12, atol=1e-300)
+        # (identical terms added by atomics in another order: a bin of thousands of catches of very
+        #  different sizes moves by ~n eps)
+        assert np.allclose(rc.energy, ra.energy, rtol=1e-10, atol=1e-300)
         check_against_oracle(big, min(n, 5000), first_id=5, seed=3)
         big.close(), small.close()
 

@@ -204,3 +204,52 @@ def test_committed_scatterer_rows_at_toa_degree_9():
     row = rows["halfspace"][0]
     assert [info["mfp_p"], info["mfp_s"]] == pytest.approx(row["mfp"], rel=1e-12)
     assert [info["dipole_p"], info["dipole_s"]] == pytest.approx(row["dipole"], rel=1e-11)
+
+
+# ------------------------------------------------------------ cell arrays ----
+def _cell_fields(c, kind):
+    """What the traversal reads of an r3d_cell, as one flat list (faces: normal, point, radius, neighbour, flags)."""
+    out = [list(c.vel_c), list(c.vel_a), [x for g in c.vel_grad for x in g], [c.rho_c, c.rho_a], list(c.rho_grad),
+           list(c.q), list(c.zero_rad2)]
+    faces = []
+    for f in range(c.n_faces):
+        F = c.faces[f]
+        faces.append((list(F.normal), list(F.point), F.radius, F.neighbor, F.flags))
+    return out, faces, c.scatterer, c.n_faces
+
+
+@pytest.mark.parametrize("name", ["halfspace", "lopnor", "lopnor_vids", "crustpinch", "upthrust", "sphere", "toysphere_vids",
+                                  "crustpinch_vids"])
+def test_host_cell_builders_match_the_oracle(name):
+    """The three cell-array builders (layered cylinder, warped-Cartesian-grid tetra, spherical shells) of
+    radiative3d_amd/host against the oracle's, from the same grid nodes: every cell's velocity / density
+    fit, attenuation Q, faces (normal, point, radius), links, flags (collect, reflect, adjoin, discontinuity)
+    and scatterer index, and the scatterers' medium parameters in creation order -- for the four benchmark
+    grids and the remaining user models (model.cpp:647-934, :1017-1228; media.cpp:130-156, :353-395, :578-626)."""
+    args = CONFIGS[name](2)
+    m = Model(args)
+    dims, nodes = m.grid_nodes()
+    d = m.desc
+    rng = [float(a.split("=")[1]) for a in args if a.startswith("--range=")]
+    freq = [float(a.split("=")[1]) for a in args if a.startswith("--frequency=")][0]
+    one_dummy = any(a.startswith("--overridemfp") for a in args) and "--nodeflect" in args
+    cells, n, het = T.build_cells(d.cell_kind, dims, nodes, freq, rng[0] if rng else 600.0, one_dummy)
+    assert n == d.n_cells and len(het) == d.n_scatterers
+    for s in range(d.n_scatterers):
+        assert list(d.scatterers[s].het) == pytest.approx(list(het[s]), rel=1e-15, abs=0), (name, s)
+    worst = 0.0
+    for i in range(n):
+        got_num, got_faces, got_scat, got_nf = _cell_fields(d.cells[i], d.cell_kind)
+        want_num, want_faces, want_scat, want_nf = _cell_fields(cells[i], d.cell_kind)
+        assert (got_scat, got_nf) == (want_scat, want_nf), (name, i)
+        for g, w in zip(got_num, want_num):
+            # the two solve the same 4 x 4 systems with different pivoting: agreement to rounding of the solve
+            assert np.allclose(g, w, rtol=1e-9, atol=1e-9 * max(1e-3, float(np.max(np.abs(w))) if len(w) else 0)), (name, i, g, w)
+            fin = np.isfinite(w)          # (a uniform shell has an infinite zero-velocity radius, on both sides)
+            if fin.any():
+                ga, wa = np.array(g)[fin], np.array(w)[fin]
+                worst = max(worst, float(np.max(np.abs(ga - wa) / np.maximum(np.abs(wa), 1e-3))))
+        for (gn, gp, gr, gnb, gfl), (wn, wp, wr, wnb, wfl) in zip(got_faces, want_faces):
+            assert (gnb, gfl) == (wnb, wfl), (name, i)
+            assert gr == wr and np.allclose(gn, wn, rtol=0, atol=1e-14) and np.allclose(gp, wp, rtol=0, atol=1e-12 * (1 + abs(wr)))
+    print(f"{name}: {n} cells, {len(het)} scatterers; largest relative difference of a fitted coefficient {worst:.1e}")
