@@ -607,35 +607,57 @@ R3D_HD RtChoice rt_choose(const Phonon& p, Iface f, double u_pol, double u_out) 
   if (no_transmit && choice >= T_P) choice -= 3;  // T_x -> R_x
   return RtChoice{choice, intype};
 }
-// Returns true if the phonon crossed into the neighbour.
-R3D_HD bool rt_apply(Phonon& p, Iface f, RtChoice ch) {
-  const V3 fnorm = f.normal;
-  const V3 fpara = in_plane_unit_perp(fnorm, p.dir);
-  const V3 fparash = cross(fnorm, fpara);
-  const double sini = dot(fpara, p.dir);
-  if (!f.has_neighbor) f.rhoT = 0.0, f.vT[0] = f.vT[1] = 1e-12;
+// The chosen outcome applied: new type, direction, polarisation (GetChosenRayDirection /
+// GetChosenParticleDOM, rtcoef.cpp:529-588).  fnorm: the face normal; v_in: the incident ray's velocity
+// at the crossing point; v_out: the chosen ray's, on the side it ends up on.  Returns true if the
+// phonon crossed into the neighbour.
+//
+// The reference forms unit axes fpara (in the plane of incidence, along the face) and fparash (normal
+// to that plane) and writes out = sin(o) fpara + (+-cos(o)) fnorm with sin(o) = v_out p, p = sin(i) / v_in.
+// As in bend(): sin(i) fpara IS the tangential part of the direction, dt = d - (n.d) n, so
+// out = (v_out / v_in) dt +- cos(o) n needs neither axis, no division by sin(i) and nothing of the
+// interface but the two velocities; and w = n x d = sin(i) fparash serves for the particle motion, its
+// scale divided away by the projection onto (theta^, phi^).  Normal incidence (w = 0) takes the
+// reference's substitute axis (geom_r3.cpp:146-171).  (The first form of this function re-derived the
+// whole interface -- four velocities, two densities -- and both unit axes: 350 instructions, now 150.)
+R3D_HD bool rt_apply(Phonon& p, V3 fnorm, double v_in, double v_out, RtChoice ch) {
   const int choice = ch.choice;
   const bool reflected = choice < T_P;
-  // GetChosenRayDirection, rtcoef.cpp:529-548
-  double comp_para, comp_norm;
-  rt_ray(f, sini, ch.intype, choice, comp_para, comp_norm);
-  if (comp_para > 1.0) comp_para = 1.0;
+  const double cn = dot(fnorm, p.dir);
+  const V3 dt = p.dir - cn * fnorm;
+  const double m2 = mag2(dt);                      // sin^2(i)
+  const double r = v_out * frcp(v_in);
+  const double so2 = (r * r) * m2;                 // sin^2 of the outgoing angle
+  // real part of the outgoing cosine (0 beyond the critical angle: sqrt_real), and the reference's
+  // clamp of the sine at 1 (rtcoef.cpp:541): the tangential part then has unit length
+  const bool beyond = so2 > 1.0;
+  double comp_norm = beyond ? 0.0 : fsqrt(1.0 - so2);
+  const double kt = beyond ? frsqrt(m2) : r;
   if (reflected) comp_norm = -comp_norm;
-  V3 out = comp_para * fpara + comp_norm * fnorm;
+  const V3 out = kt * dt + comp_norm * fnorm;
   p.type = (choice == R_P || choice == T_P) ? RAY_P : RAY_S;
-  // (the reference sets mDir from outdir.Theta(), outdir.Phi(): `out` is a unit vector to rounding --
-  //  orthonormal fpara, fnorm with sine and cosine as coefficients -- and the round trip through the
-  //  angles, a change of ~1e-16, is skipped as in the advance functions)
-  const V3 nd = out;
-  if (p.type == RAY_S) {  // GetChosenParticleDOM, rtcoef.cpp:559-588
+  if (p.type == RAY_S) {
+    V3 w = cross(fnorm, p.dir);                    // sin(i) fparash
+    if (is_zero(w)) {
+      w = cross(fnorm, v3(1, 0, 0));
+      if (is_zero(w)) w = cross(fnorm, v3(0, 1, 0));
+    }
     V3 dopm;
-    if (choice == T_SH || choice == R_SH) dopm = fparash;
-    else if (choice == R_SV) dopm = cross(out, fparash);
-    else dopm = cross(fparash, out);
-    set_pol(p, dopm, nd);
+    if (choice == T_SH || choice == R_SH) dopm = w;
+    else if (choice == R_SV) dopm = cross(out, w);
+    else dopm = cross(w, out);
+    set_pol(p, dopm, out);
   }
-  p.dir = nd;
+  p.dir = out;
   return !reflected;
+}
+// The two velocities rt_apply wants, from a whole interface (the one-call form below).
+R3D_HD bool rt_apply(Phonon& p, Iface f, RtChoice ch) {
+  if (!f.has_neighbor) f.vT[0] = f.vT[1] = 1e-12;
+  const double v_in = f.vR[ch.intype == 0 ? 0 : 1];
+  const bool out_p = (ch.choice == R_P) | (ch.choice == T_P), out_t = ch.choice >= T_P;
+  const double v_p = out_t ? f.vT[0] : f.vR[0], v_s = out_t ? f.vT[1] : f.vR[1];
+  return rt_apply(p, f.normal, v_in, out_p ? v_p : v_s, ch);
 }
 R3D_HD bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
   double u_pol, u_out;

@@ -437,7 +437,13 @@ R3D_HD RtChoice rt_event_choose(const KArgs& a, const Tables<KIND>& T, const Pho
 template <int KIND>
 R3D_HD void rt_event_apply(const KArgs& a, const Tables<KIND>& T, Phonon& p, LaneStats& st, const Pending& ev,
                            int nbr, RtChoice ch) {
-  const bool crossed = rt_apply(p, rt_interface<KIND>(a, T, p, ev, nbr), ch);
+  // what is read again of the tables: the face normal and two velocities -- the incident ray's and
+  // the chosen ray's, in the cell it ends up in (a choice folded to a reflection stays in this one)
+  const bool out_p = (ch.choice == R_P) | (ch.choice == T_P), out_t = ch.choice >= T_P;
+  const V3 fnorm = cell_face_normal(cell_rec<KIND>(T, p.cell, p.type), ev.face, p.loc);
+  const double v_in = velocity_in<KIND>(T, p.cell, p.loc, p.type);
+  const double v_out = velocity_in<KIND>(T, out_t ? nbr : p.cell, p.loc, out_p ? RAY_P : RAY_S);
+  const bool crossed = rt_apply(p, fnorm, v_in, v_out, ch);
   if (crossed) {
     p.cell = nbr, st.transfer++;
   } else {
