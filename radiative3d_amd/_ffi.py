@@ -67,7 +67,7 @@ class ModelDesc(C.Structure):
 
 
 class GridNode(C.Structure):
-    """r3dh_grid_node (include/r3d_host.h) == r3d_oracle_node (oracle/r3d_tables_oracle.cpp)."""
+    """r3dh_grid_node (include/r3d_host.h): one grid node as the cell builders see it."""
     _fields_ = [("loc", C.c_double * 3), ("radius", C.c_double), ("side", (C.c_double * 9) * 2),
                 ("n_sets", C.c_int32), ("pad_", C.c_int32)]
 
