@@ -609,9 +609,12 @@ def test_reproducible_build_defines_every_history_to_the_bit(models, monkeypatch
         torch.cuda.synchronize()
         rc = total.to_result()
         assert (rc.counts == ra.counts).all() and rc.events == ra.events
-        # (identical terms added by atomics in another order: a bin of thousands of catches of very
-        #  different sizes moves by ~n eps)
-        assert np.allclose(rc.energy, ra.energy, rtol=1e-10, atol=1e-300)
+        # (the production kernels against the diagnostic one: another compilation of the same code, so a
+        #  component that is tiny against its bin's energy -- particle motion all but normal to that
+        #  axis, its projection a difference of nearly equal products -- moves in its leading digits;
+        #  held to 1e-12 of the bin's energy by type, and the sums to the order of the atomics)
+        scale = ra.energy[:, :, 3:].sum(-1, keepdims=True)
+        assert np.all(np.abs(rc.energy - ra.energy) <= 1e-12 * scale + 1e-300)
         check_against_oracle(big, min(n, 5000), first_id=5, seed=3)
         big.close(), small.close()
 
