@@ -35,8 +35,12 @@ all: host engine repro oracle cli
 
 host: $(LIBDIR)/libr3d_host.so
 engine: $(LIBDIR)/libr3d_hip.so
-# the same engine with every wave-voted series choice taken out (r3d_math.h all_lanes): a history's
-# result is then bit-defined by (model, seed, id); loaded under R3D_REPRODUCIBLE=1
+# the same engine with every wave-voted series choice taken out (r3d_math.h all_lanes) and no
+# contraction of a * b + c into fused multiply-adds beyond the ones the sources spell out (the
+# compiler contracts differently in each kernel it inlines the physics into: the diagnostic and the
+# production kernels then differ in the last bits, ~1e-10 after an ill-conditioned travel time): a
+# history's result is then bit-defined by (model, seed, id) in every kernel; loaded under
+# R3D_REPRODUCIBLE=1.  Costs 5-10 %.
 repro: $(LIBDIR)/libr3d_hip_repro.so
 oracle: oracle/libr3d_oracle.so oracle/libr3d_tables_oracle.so
 cli: main
@@ -56,7 +60,7 @@ $(LIBDIR)/libr3d_hip.so: $(ENGINE_SRC) $(ENGINE_HDR)
 
 $(LIBDIR)/libr3d_hip_repro.so: $(ENGINE_SRC) $(ENGINE_HDR)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -DR3D_REPRODUCIBLE -shared -pthread -o $@ $(ENGINE_SRC)
+	$(HIPCC) $(HIPFLAGS) -DR3D_REPRODUCIBLE -ffp-contract=off -shared -pthread -o $@ $(ENGINE_SRC)
 
 oracle/libr3d_oracle.so: oracle/r3d_oracle.cpp oracle/philox.h include/r3d.h
 	$(CXX) $(CXXFLAGS) -shared -o $@ oracle/r3d_oracle.cpp

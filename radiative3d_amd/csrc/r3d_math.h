@@ -89,8 +89,9 @@ R3D_HD double frcp(double x) {
 // wave, and the forms differ in the last bit or two -- so a history's results are defined to
 // rounding (~1e-16 relative per call), not to the bit, and which histories share a wave is decided
 // by the pool's scheduling.  Building with -DR3D_REPRODUCIBLE (make repro -> libr3d_hip_repro.so,
-// loaded under R3D_REPRODUCIBLE=1) makes every vote fail, i.e. the general form serves every
-// lane always: a history's result is then a function of (model, seed, id) alone, bit for bit,
+// loaded under R3D_REPRODUCIBLE=1; that build also turns floating-point contraction off, so that the
+// diagnostic and the production kernels round alike) makes every vote fail, i.e. the general form
+// serves every lane always: a history's result is then a function of (model, seed, id) alone, bit for bit,
 // whatever the pool size, launch boundaries or batch-mates (tests/test_gpu_parity.py
 // test_reproducible_build_*), at the cost stated in DESIGN.md section 4.
 R3D_HD bool all_lanes(bool c) {
