@@ -253,3 +253,42 @@ def test_host_cell_builders_match_the_oracle(name):
             assert (gnb, gfl) == (wnb, wfl), (name, i)
             assert gr == wr and np.allclose(gn, wn, rtol=0, atol=1e-14) and np.allclose(gp, wp, rtol=0, atol=1e-12 * (1 + abs(wr)))
     print(f"{name}: {n} cells, {len(het)} scatterers; largest relative difference of a fitted coefficient {worst:.1e}")
+
+
+# ------------------------------------------- the CLI's --event-test mission ----
+@pytest.mark.parametrize("source,kind,params", [
+    ("EXPL", "USGS", [1, 1, 1, 0, 0, 0]), ("EQ", "USGS", [0, -1, 1, 0, 0, 0]),
+    ("SDR,22.5,90,0", "SDR", [22.5, 90, 0, 0.0, 1.0]), ("SDR,125,40,90", "SDR", [125, 40, 90, 0.0, 1.0])])
+def test_event_test_mission_prints_the_oracles_radiation_patterns(tmp_path, source, kind, params):
+    """`./main --event-test --source=...` (main.cpp:86-104): 3 x 1280 rows `lon lat size symbol` on the degree-3
+    take-off set, size = sqrt(whole-space share x differential probability x nTOA) x 0.2
+    (PhononSource::output_differential_probabilities, sources.cpp:71-87) -- against the same rows formed from
+    the oracle's tessellation, moment tensor and P / SH / SV tables."""
+    import subprocess
+    main = os.path.join(os.path.dirname(GOLDEN.rstrip("/")), "..", "main")
+    main = os.path.abspath(main)
+    if not os.path.exists(main):
+        subprocess.check_call(["make", "-C", os.path.dirname(main), "cli"])
+    out = subprocess.run([main, "--event-test", f"--source={source}", "--source-loc=0,0,-10"], capture_output=True,
+                         text=True, cwd=tmp_path, timeout=120)
+    assert out.returncode == 0, out.stderr[-500:]
+    rows = [ln.split() for ln in out.stdout.splitlines() if len(ln.split()) == 4 and ln.split()[3] in ("c", "-", "y")]
+    assert len(rows) == 3 * 1280
+    toa = T.toa(3)
+    mt, _ = T.moment_tensor(kind, params, 0, 6371.0, [0, 0, -10])
+    cdf, whole = T.source(mt, toa)
+    n = len(toa)
+    at = 0
+    for t, sym in enumerate(("c", "-", "y")):
+        share = (whole[t] - (whole[t - 1] if t else 0.0)) / whole[2]
+        mag = cdf[t][-1]
+        diff = np.diff(np.concatenate([[0.0], cdf[t]])) / mag if mag else np.zeros(n)
+        want = np.sqrt(share * diff * n) * 0.2
+        for k in range(n):
+            lon, lat, size, s_ = rows[at]
+            at += 1
+            assert s_ == sym
+            # (printed with the stream's default 6 significant digits)
+            assert float(lon) == pytest.approx(np.degrees(toa[k, 1]), rel=6e-6, abs=1e-6)
+            assert float(lat) == pytest.approx(90.0 - np.degrees(toa[k, 0]), rel=6e-6, abs=1e-6)
+            assert float(size) == pytest.approx(want[k], rel=6e-6, abs=1e-9), (source, sym, k)
