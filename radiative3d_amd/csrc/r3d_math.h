@@ -104,6 +104,27 @@ R3D_HD bool all_lanes(bool c) {
 #endif
 }
 
+// A per-lane truth value held as the wave's 64-bit mask in scalar registers (on the host: a bool).
+// Conditions that are only ever combined with one another and then used to select -- the tetra face
+// search forms a hundred of them per move -- cost one scalar instruction per AND / OR in this form; as
+// C++ bools the compiler turned the mixed selects into exec-mask branches, fifteen scalar instructions
+// per test (and scalar issue is not free: a hundred gratuitous s_add per move cost the NSCP launch 4 %).
+// lm(c): the mask of the lanes where c holds; lm_lane(m): this lane's bit, as a select condition
+// (v_cndmask takes the scalar pair directly); m must come from lm() under the same exec mask.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned long long LaneMask;
+R3D_HD LaneMask lm(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+R3D_HD bool lm_lane(LaneMask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+R3D_HD LaneMask lm_andnot(LaneMask a, LaneMask b) { return a & ~b; }
+R3D_HD LaneMask lm_all() { return ~0ull; }
+#else
+typedef bool LaneMask;
+R3D_HD LaneMask lm(bool c) { return c; }
+R3D_HD bool lm_lane(LaneMask m) { return m; }
+R3D_HD LaneMask lm_andnot(LaneMask a, LaneMask b) { return a && !b; }
+R3D_HD LaneMask lm_all() { return true; }
+#endif
+
 // arcsin for |x| <= 0.5: x + x t P(t) / Q(t), t = x^2 -- the classical rational
 // approximation (fdlibm e_asin.c, error below one ulp on this interval).  Used where a small
 // angle is known by its sine and the sign of its cosine (the arc length of a tetra leg):

@@ -165,19 +165,21 @@ struct Gcad {
   double entry_lo;            // sine of (entry - 1e-10 rad), or +-inf: the Inside() test's lower bound
   double exit, half;          // sines of the exit and bisector angles, or +-inf
   double exit_cos;            // cosine of the exit angle where that is finite
-  bool continuous;
+  LaneMask continuous;        // the inside region is ONE interval [entry, exit] (else: two pieces)
 };
 R3D_HD Gcad tet_face_arc(const double n[3], double dplane, const TetArc& A, double inv_R) {
-  // (written with selects and non-short-circuit logic: this runs four times per
-  //  iteration for every lane, and branches here cost more than the arithmetic)
+  // (written with selects and lane masks: this runs four times per iteration for every lane, and
+  //  branches here cost more than the arithmetic)
   const double inf = pos_inf();
   V3 nn = v3(n);
   const double rx = dot(nn, A.v1), rz = dot(nn, A.v3);      // in-plane components of the face normal
   const double ir = frsqrt(rx * rx + rz * rz);
   const double sb = rx * ir, cb = rz * ir;                  // sin, cos of the bisector angle
   const double ratio = ((dplane - dot(nn, A.center)) * ir) * inv_R;   // cos q
-  const bool front = cb > 0;            // bisector within (-pi/2, pi/2)
-  const bool crosses = (ratio < 1) & (ratio > -1);
+  const LaneMask FRONT = lm(cb > 0);            // bisector within (-pi/2, pi/2)
+  const LaneMask CROSS = lm(ratio < 1) & lm(ratio > -1);
+  const LaneMask ALL_IN = lm(ratio >= 1), ALL_OUT = lm(ratio <= -1);
+  const bool front = lm_lane(FRONT), crosses = lm_lane(CROSS);
   const double sq = fsqrt(fmax(0.0, 1.0 - ratio * ratio));   // sin q > 0 when the circle crosses the plane
   const double se = sb * ratio + cb * sq, ce = cb * ratio - sb * sq;   // entry = bis + q
   const double sx = sb * ratio - cb * sq, cx = cb * ratio + sb * sq;   // exit  = bis - q
@@ -192,24 +194,17 @@ R3D_HD Gcad tet_face_arc(const double n[3], double dplane, const TetArc& A, doub
   double entry_cos = crosses ? ce : 1.0;
   Gcad g;
   g.exit_cos = crosses ? cx : 1.0;
-  g.continuous = crosses ? !front : true;
+  // continuous = crosses ? !front : true, then false where all_out (which excludes crosses)
+  g.continuous = lm_andnot(lm_andnot(lm_all(), FRONT & CROSS), ALL_OUT);
   g.half = front ? sb : inf;
-  const bool all_in = ratio >= 1, all_out = ratio <= -1;
+  const bool all_in = lm_lane(ALL_IN), all_out = lm_lane(ALL_OUT);
   entry = all_in ? -inf : (all_out ? inf : entry);
   exit = all_in ? inf : (all_out ? -inf : exit);
   g.half = all_out ? -inf : g.half;
-  g.continuous = all_out ? false : g.continuous;
   g.exit = exit;
   // the reference's 1e-10 rad of slack on the entry side becomes 1e-10 cos(entry) in sine space
   g.entry_lo = entry - 0.0000000001 * entry_cos;
   return g;
-}
-// GCAD_RetVal::Inside (media_cellface.cpp:767-782); th is a sine or +-inf.
-R3D_HD bool gcad_inside(const Gcad& g, double th) {
-  const double inf = pos_inf();
-  const bool below = th <= g.exit, above = th >= g.entry_lo;
-  const bool two_piece = ((th > -inf) & below) | (above & (th < inf));
-  return g.continuous ? (below & above) : two_piece;
 }
 // reference Tetra::GetPathToBoundary, media.cpp:518-567 (search part).
 // Result: face, and the exit point on the circle as (sin, cos); len is filled
@@ -224,14 +219,28 @@ R3D_HD TetExit tet_exit(const CellTet& c, const TetArc& A) {
 #pragma unroll
   for (int i = 0; i < 4; i++) rv[i] = tet_face_arc(c.n[i], c.d[i], A, inv_R);
   TetExit e{pos_inf(), 1.0, 0};
+  const double ninf = -pos_inf();
 #pragma unroll
   for (int i = 0; i < 4; i++) {
+    // Is face i's exit angle x inside the forward region of each of the other three faces
+    // (GCAD_RetVal::Inside, media_cellface.cpp:767-782)?  With A = (x >= entry_lo), B = (x <= exit):
+    //   one interval:  A & B;     two pieces:  ((x > -inf) & B) | (A & (x < inf)).
+    // For finite x the second is A | B; for x = -inf it is A, and so is A & B (B holds); for x = +inf
+    // the exit is never taken (x < e.s fails below), so the test's value is immaterial.  Hence
+    //   inside = (A & B) | (two_piece & (x > -inf) & (A | B)),
+    // five scalar instructions on lane masks per pair of faces.
     const double x = rv[i].exit;
-    const bool proper = gcad_inside(rv[(i + 1) & 3], x) & gcad_inside(rv[(i + 2) & 3], x) &
-                        gcad_inside(rv[(i + 3) & 3], x);
+    const LaneMask GT = lm(x > ninf);
+    LaneMask proper = lm_all();
+#pragma unroll
+    for (int jj = 1; jj < 4; jj++) {
+      const Gcad& o = rv[(i + jj) & 3];
+      const LaneMask Am = lm(x >= o.entry_lo), Bm = lm(x <= o.exit);
+      proper = proper & ((Am & Bm) | (lm_andnot(GT, o.continuous) & (Am | Bm)));
+    }
     // an exit behind the phonon (negative arc) is dismissed only beyond the face's bisector
-    const bool dismissed = (x < A.s0) & (A.s0 > rv[i].half);
-    const bool take = proper & !dismissed & (x < e.s);
+    const LaneMask dismissed = lm(x < A.s0) & lm(A.s0 > rv[i].half);
+    const bool take = lm_lane(lm_andnot(proper, dismissed) & lm(x < e.s));
     e.s = take ? x : e.s, e.c = take ? rv[i].exit_cos : e.c, e.face = take ? i : e.face;
   }
   return e;
