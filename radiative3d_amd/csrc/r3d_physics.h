@@ -161,6 +161,7 @@ R3D_HD TetArc tet_arc(const CellTet& c, const Phonon& p) {
 // PlaneFace::GetCircArcDistToFace, media_cellface.cpp:333-426): the arc is
 // outside the face between the exit angle bis - q and the entry angle bis + q,
 // bis = direction of the in-plane normal, cos q = (centre-to-trace distance)/R.
+constexpr double kTetBig = 2.0;   // stands for an infinite angle among sines (see tet_face_arc)
 struct Gcad {
   double entry_lo;            // sine of (entry - 1e-10 rad), or +-inf: the Inside() test's lower bound
   double exit, half;          // sines of the exit and bisector angles, or +-inf
@@ -170,7 +171,10 @@ struct Gcad {
 R3D_HD Gcad tet_face_arc(const double n[3], double dplane, const TetArc& A, double inv_R) {
   // (written with selects and lane masks: this runs four times per iteration for every lane, and
   //  branches here cost more than the arithmetic)
-  const double inf = pos_inf();
+  // (the reference's +-infinity angles are carried as sines of +-2 here: every real sine lies in
+  //  [-1, 1] to rounding, so all orderings carry over, and +-2 is an inline constant of the vector
+  //  unit where an infinity is a literal that costs two moves each time it is selected)
+  const double inf = kTetBig;
   V3 nn = v3(n);
   const double rx = dot(nn, A.v1), rz = dot(nn, A.v3);      // in-plane components of the face normal
   const double ir = frsqrt(rx * rx + rz * rz);
@@ -191,7 +195,8 @@ R3D_HD Gcad tet_face_arc(const double n[3], double dplane, const TetArc& A, doub
   entry = bis_nan ? cb : entry, exit = bis_nan ? cb : exit;
   // ratio outside (-1, 1) or NaN: the reference's defaults, then its two overrides
   entry = crosses ? entry : 0.0, exit = crosses ? exit : 0.0;
-  double entry_cos = crosses ? ce : 1.0;
+  // (the slack below applies to real entry angles only: where the entry is a sentinel, ce <= 0)
+  double entry_cos = crosses ? fmax(ce, 0.0) : 1.0;
   Gcad g;
   g.exit_cos = crosses ? cx : 1.0;
   // continuous = crosses ? !front : true, then false where all_out (which excludes crosses)
@@ -218,8 +223,8 @@ R3D_HD TetExit tet_exit(const CellTet& c, const TetArc& A) {
   Gcad rv[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) rv[i] = tet_face_arc(c.n[i], c.d[i], A, inv_R);
-  TetExit e{pos_inf(), 1.0, 0};
-  const double ninf = -pos_inf();
+  TetExit e{kTetBig, 1.0, 0};
+  const double ninf = -kTetBig;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     // Is face i's exit angle x inside the forward region of each of the other three faces
@@ -248,7 +253,8 @@ R3D_HD TetExit tet_exit(const CellTet& c, const TetArc& A) {
 // Arc length to the exit: R (a_exit - a0), the difference taken from its sine
 // and cosine (both angles lie in [-pi/2, pi/2]).
 R3D_HD double tet_exit_length(const TetArc& A, const TetExit& e) {
-  if (!(e.s > -pos_inf() && e.s < pos_inf())) return e.s;   // +-inf (NaN propagates)
+  if (!(e.s > -kTetBig && e.s < kTetBig))   // the sentinels back to the reference's +-inf (NaN propagates)
+    return e.s >= kTetBig ? pos_inf() : e.s <= -kTetBig ? -pos_inf() : e.s;
   const double sd = e.s * A.c0 - e.c * A.s0, cd = e.c * A.c0 + e.s * A.s0;   // sine, cosine of the arc angle
   return A.R * angle_from_sincos(sd, cd);
 }
