@@ -17,6 +17,13 @@ CXXFLAGS ?= -std=c++17 -O2 -fPIC -Wall -Wno-unused-function -Wno-unknown-pragmas
 # inside atan2 on every iteration.  Without the hoist: 199 VGPRs, no spills, -15 % kernel time.
 HIPFLAGS ?= -std=c++17 -O3 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical \
             -mllvm -disable-machine-licm
+# The traversal kernels are one translation unit per cell kind (csrc/r3d_kernels_kind.hip), each with
+# the instruction scheduler that suits it: under the compiler's max-ILP strategy the spherical-shell
+# kernel runs 3.4 % faster (no vector register spilled, against 4) and the layered one 0.4 %, the
+# tetra kernel 1.4 % slower (10 spilled against 4).
+HIPFLAGS_CYL ?= -mllvm -amdgpu-sched-strategy=max-ilp
+HIPFLAGS_TET ?=
+HIPFLAGS_SPH ?= -mllvm -amdgpu-sched-strategy=max-ilp
 
 LIBDIR   := radiative3d_amd/lib
 HOSTDIR  := radiative3d_amd/host
@@ -26,8 +33,30 @@ HOST_SRC := $(HOSTDIR)/ecs.cpp $(HOSTDIR)/grid.cpp $(HOSTDIR)/model.cpp \
             $(HOSTDIR)/models_builtin.cpp $(HOSTDIR)/cmdline.cpp $(HOSTDIR)/dataout.cpp \
             $(HOSTDIR)/capi.cpp
 HOST_HDR := $(wildcard $(HOSTDIR)/*.hpp) include/r3d.h include/r3d_host.h
-ENGINE_SRC := $(CSRC)/r3d_engine.hip $(CSRC)/r3d_tables_build.hip
+ENGINE_SRC := $(CSRC)/r3d_engine.hip $(CSRC)/r3d_tables_build.hip $(CSRC)/r3d_kernels_kind.hip
 ENGINE_HDR := $(wildcard $(CSRC)/*.h) include/r3d.h
+OBJDIR   := build/obj
+# engine_objects(tag, extra flags): the five objects of one engine build
+define engine_objects
+$(OBJDIR)/$(1)_engine.o: $(CSRC)/r3d_engine.hip $(ENGINE_HDR)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(2) -c -o $$@ $(CSRC)/r3d_engine.hip
+$(OBJDIR)/$(1)_tables.o: $(CSRC)/r3d_tables_build.hip $(ENGINE_HDR)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(2) -c -o $$@ $(CSRC)/r3d_tables_build.hip
+$(OBJDIR)/$(1)_cyl.o: $(CSRC)/r3d_kernels_kind.hip $(ENGINE_HDR)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_CYL) $(2) -DR3D_KIND=0 -c -o $$@ $(CSRC)/r3d_kernels_kind.hip
+$(OBJDIR)/$(1)_tet.o: $(CSRC)/r3d_kernels_kind.hip $(ENGINE_HDR)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_TET) $(2) -DR3D_KIND=1 -c -o $$@ $(CSRC)/r3d_kernels_kind.hip
+$(OBJDIR)/$(1)_sph.o: $(CSRC)/r3d_kernels_kind.hip $(ENGINE_HDR)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_SPH) $(2) -DR3D_KIND=2 -c -o $$@ $(CSRC)/r3d_kernels_kind.hip
+endef
+engine_objs = $(OBJDIR)/$(1)_engine.o $(OBJDIR)/$(1)_tables.o $(OBJDIR)/$(1)_cyl.o $(OBJDIR)/$(1)_tet.o $(OBJDIR)/$(1)_sph.o
+$(eval $(call engine_objects,main,))
+$(eval $(call engine_objects,repro,-DR3D_REPRODUCIBLE -ffp-contract=off))
 
 .PHONY: default all host engine repro oracle cli clean
 default: all
@@ -54,13 +83,13 @@ $(LIBDIR)/libr3d_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -shared -pthread -o $@ $(HOST_SRC)
 
-$(LIBDIR)/libr3d_hip.so: $(ENGINE_SRC) $(ENGINE_HDR)
+$(LIBDIR)/libr3d_hip.so: $(call engine_objs,main)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -pthread -o $@ $(ENGINE_SRC)
+	$(HIPCC) --offload-arch=gfx950 -shared -pthread -o $@ $(call engine_objs,main)
 
-$(LIBDIR)/libr3d_hip_repro.so: $(ENGINE_SRC) $(ENGINE_HDR)
+$(LIBDIR)/libr3d_hip_repro.so: $(call engine_objs,repro)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -DR3D_REPRODUCIBLE -ffp-contract=off -shared -pthread -o $@ $(ENGINE_SRC)
+	$(HIPCC) --offload-arch=gfx950 -shared -pthread -o $@ $(call engine_objs,repro)
 
 oracle/libr3d_oracle.so: oracle/r3d_oracle.cpp oracle/philox.h include/r3d.h
 	$(CXX) $(CXXFLAGS) -shared -o $@ oracle/r3d_oracle.cpp
@@ -72,9 +101,17 @@ oracle/libr3d_tables_oracle.so: oracle/r3d_tables_oracle.cpp
 
 clean:
 	rm -f $(LIBDIR)/*.so oracle/*.so main
+	rm -rf $(OBJDIR)
 
 # Developer variants of the engine (timing-only / diagnostic builds, never shipped as libr3d_hip.so):
 #   make variant NAME=PHASE DEFS="-DR3D_PHASE_TIMING"   ->  radiative3d_amd/lib/variant_PHASE.so
 # run with R3D_HIP_LIB=radiative3d_amd/lib/variant_PHASE.so (tools/time_chain.py, tools/pool_stats.py)
 variant:
-	$(HIPCC) $(HIPFLAGS) $(DEFS) -shared -pthread -o $(LIBDIR)/variant_$(NAME).so $(ENGINE_SRC)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -c -o $(OBJDIR)/v$(NAME)_engine.o $(CSRC)/r3d_engine.hip & \
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -c -o $(OBJDIR)/v$(NAME)_tables.o $(CSRC)/r3d_tables_build.hip & \
+	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_CYL) $(DEFS) $(DEFS_CYL) -DR3D_KIND=0 -c -o $(OBJDIR)/v$(NAME)_cyl.o $(CSRC)/r3d_kernels_kind.hip & \
+	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_TET) $(DEFS) $(DEFS_TET) -DR3D_KIND=1 -c -o $(OBJDIR)/v$(NAME)_tet.o $(CSRC)/r3d_kernels_kind.hip & \
+	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_SPH) $(DEFS) $(DEFS_SPH) -DR3D_KIND=2 -c -o $(OBJDIR)/v$(NAME)_sph.o $(CSRC)/r3d_kernels_kind.hip & wait
+	$(HIPCC) --offload-arch=gfx950 -shared -pthread -o $(LIBDIR)/variant_$(NAME).so $(OBJDIR)/v$(NAME)_engine.o \
+	    $(OBJDIR)/v$(NAME)_tables.o $(OBJDIR)/v$(NAME)_cyl.o $(OBJDIR)/v$(NAME)_tet.o $(OBJDIR)/v$(NAME)_sph.o

@@ -89,7 +89,7 @@ def kernel_source_hash(csrc=None):
             text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)          # block comments
             text = re.sub(r"//[^\n]*", " ", text)                       # line comments (no string in these sources holds //)
             h.update(" ".join(text.split()).encode())
-    for line in open(os.path.join(REPO, "Makefile")):
+    for line in open(os.path.join(REPO, "Makefile")):   # (HIPFLAGS and the per-kind HIPFLAGS_CYL / _TET / _SPH)
         if line.startswith("HIPFLAGS") or line.lstrip().startswith("-mllvm"):
             h.update(line.encode())
     return h.hexdigest()[:16]

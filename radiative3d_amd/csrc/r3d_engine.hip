@@ -31,65 +31,7 @@
 #include "r3d_step.h"
 #include "r3d_tables_build.h"
 
-namespace r3d {
-
-// ---------------------------------------------------- wave-level helpers ----
-// number of set bits of m below this lane
-__device__ __forceinline__ unsigned rank_in(unsigned long long m) {
-  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-}
-__device__ __forceinline__ double bcast(double v, int src) {
-  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ V3 bcast(V3 v, int src) { return v3(bcast(v.x, src), bcast(v.y, src), bcast(v.z, src)); }
-
-// Per-workgroup accumulators for seismometer bins, in LDS.  First arrivals pile
-// onto a handful of (seismometer, time-bin) records -- in the LopNor runs one bin
-// takes a quarter of all catches and sixteen take 58 % -- and atomics on one
-// address are served one after the other by a single L2 channel: measured, that
-// contention alone was half of the LopNor kernel time.  So a catch first tries a
-// small open-addressed table here (first come, first admitted; hot bins show up
-// early and often); the block adds each entry to HBM once, at the end.  A catch
-// that finds no entry takes the queue above.
-struct BinCache {
-  double* e;        // [n][5] energies X, Y, Z, P, S
-  uint32_t* key;    // [n]    seismometer * n_bins + bin, or kEmpty
-  uint32_t* cnt;    // [n][2] catches by type
-  uint32_t mask, shift;   // n - 1, 32 - log2 n
-  bool on;
-};
-constexpr uint32_t kEmpty = 0xFFFFFFFFu;
-constexpr size_t kAccEntryBytes = 5 * sizeof(double) + 3 * sizeof(uint32_t);
-
-__device__ __forceinline__ bool bin_cache_add(const BinCache& bc, uint32_t bin, uint32_t type, double ex,
-                                              double ey, double ez, double et) {
-  uint32_t idx = (bin * 2654435761u) >> bc.shift;
-  for (int probe = 0; probe < 4; probe++) {
-    const uint32_t old = atomicCAS(&bc.key[idx], kEmpty, bin);
-    if (old == kEmpty || old == bin) {
-      double* e = bc.e + idx * 5u;
-      unsafeAtomicAdd(e + 0, ex);
-      unsafeAtomicAdd(e + 1, ey);
-      unsafeAtomicAdd(e + 2, ez);
-      unsafeAtomicAdd(e + 3 + type, et);
-      atomicAdd(&bc.cnt[idx * 2u + type], 1u);
-      return true;
-    }
-    idx = (idx + 1u) & bc.mask;
-  }
-  return false;
-}
-
-// RES: which of the small tables are staged in LDS.  RES_ALL: the cell records and the
-// scatterer heads (layered and spherical models: a few dozen cells); RES_TABLES: the scatterer
-// heads only (tetra models: the cell records come through L1 / L2); RES_NONE: neither (models
-// with thousands of scatterers, whose heads alone would crowd out the phonon pool).
-enum { RES_ALL = 0, RES_TABLES = 1, RES_NONE = 2 };
-
-}  // namespace r3d
-#include "r3d_pool.h"
+#include "r3d_kernels.h"
 namespace r3d {
 
 // ------------------------------------------------------------------- engine --
@@ -226,67 +168,24 @@ const GuideCell* make_guide(r3d_engine* e, const double* d_cdf, uint64_t n, uint
   return d_guide;
 }
 
-// Call f(kind, res) with the engine's cell kind and table residency as compile-time constants.
-template <class F>
-hipError_t with_kernel(const r3d_engine* e, F&& f) {
-  auto by_res = [&](auto kind) {
-    switch (e->res) {
-      case RES_ALL: return f(kind, std::integral_constant<int, RES_ALL>{});
-      case RES_TABLES: return f(kind, std::integral_constant<int, RES_TABLES>{});
-      default: return f(kind, std::integral_constant<int, RES_NONE>{});
-    }
-  };
-#ifdef R3D_DEV_ONLY_KIND   // developer builds: one cell kind only (a sixth of the compile time)
-  if (e->kind != R3D_DEV_ONLY_KIND) return hipErrorInvalidValue;
-  return by_res(std::integral_constant<int, R3D_DEV_ONLY_KIND>{});
-#else
-  switch (e->kind) {
-    case R3D_CELL_CYLINDER: return by_res(std::integral_constant<int, CELL_CYL>{});
-    case R3D_CELL_TETRA:   // (tetra grids run to thousands of cells: their records are never staged in LDS,
-                           //  so that variant is not compiled)
-      if (e->res == RES_NONE) return f(std::integral_constant<int, CELL_TET>{}, std::integral_constant<int, RES_NONE>{});
-      return f(std::integral_constant<int, CELL_TET>{}, std::integral_constant<int, RES_TABLES>{});
-    default: return by_res(std::integral_constant<int, CELL_SPH>{});
-  }
-#endif
-}
-
-// pool kernels: res 0 = cell records + scatterer heads in LDS, 1 = scatterer heads only, 2 = neither
-template <class F>
-hipError_t with_pool_kernel(const r3d_engine* e, F&& f) {
-  return with_kernel(e, [&](auto kind, auto res) {
-    constexpr int R = decltype(res)::value;
-    return f(kind, std::integral_constant<bool, R == RES_ALL>{}, std::integral_constant<bool, R != RES_NONE>{});
-  });
-}
-
+// The traversal kernels live in one translation unit per cell kind (r3d_kernels_kind.hip, compiled
+// three times): each kind gets the instruction scheduler that suits it (Makefile) and the three
+// compile side by side.
 hipError_t launch_any(r3d_engine* e, const KArgs& a, bool trace, hipStream_t s, bool drain_only = false) {
-  return with_pool_kernel(e, [&](auto kind, auto cells, auto scat) {
-    constexpr int K = decltype(kind)::value;
-    constexpr bool C = decltype(cells)::value, H = decltype(scat)::value;
-    if (drain_only && !trace)
-      hipLaunchKernelGGL((pool_drain_kernel<K, C, H>), dim3(e->grid_blocks), dim3(kPoolBlock), e->lds_bytes, s, a);
-    else if (trace)
-      hipLaunchKernelGGL((pool_kernel<K, C, H, true>), dim3(e->grid_blocks), dim3(kPoolBlock), e->lds_bytes, s, a);
-    else
-      hipLaunchKernelGGL((pool_kernel<K, C, H, false>), dim3(e->grid_blocks), dim3(kPoolBlock), e->lds_bytes, s, a);
-    return hipGetLastError();
-  });
+  const unsigned grid = (unsigned)e->grid_blocks;
+  switch (e->kind) {
+    case R3D_CELL_CYLINDER: return launch_pool_cyl(e->res, trace, drain_only, grid, e->lds_bytes, s, a);
+    case R3D_CELL_TETRA: return launch_pool_tet(e->res, trace, drain_only, grid, e->lds_bytes, s, a);
+    default: return launch_pool_sph(e->res, trace, drain_only, grid, e->lds_bytes, s, a);
+  }
 }
 
 hipError_t set_lds_attr(const r3d_engine* e) {
-  return with_pool_kernel(e, [&](auto kind, auto cells, auto scat) {
-    constexpr int K = decltype(kind)::value;
-    constexpr bool C = decltype(cells)::value, H = decltype(scat)::value;
-    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_kernel<K, C, H, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
-    if (r != hipSuccess) return r;
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_drain_kernel<K, C, H>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
-    if (r != hipSuccess) return r;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_kernel<K, C, H, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes);
-  });
+  switch (e->kind) {
+    case R3D_CELL_CYLINDER: return pool_lds_attr_cyl(e->res, (int)e->lds_bytes);
+    case R3D_CELL_TETRA: return pool_lds_attr_tet(e->res, (int)e->lds_bytes);
+    default: return pool_lds_attr_sph(e->res, (int)e->lds_bytes);
+  }
 }
 
 bool check_model(const r3d_model_desc* m) {
@@ -788,11 +687,16 @@ int r3d_selftest_math(int device, int which, const double* x, const double* y, d
 
 #ifdef R3D_PHASE_TIMING
 // diagnostic builds only: per queue of the pool kernel, batches served / lanes filled / wave cycles
-// since the last call (slot 6 of the first row: idle polls)
+// since the last call (slot 6 of the first row: idle polls), summed over the three kernel units
 int r3d_debug_pool_stats(unsigned long long out[40]) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pool_stats), 40 * sizeof(unsigned long long)) != hipSuccess) return 1;
-  unsigned long long zero[40] = {};
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_pool_stats), zero, sizeof zero) != hipSuccess;
+  for (int i = 0; i < 40; i++) out[i] = 0;
+  unsigned long long part[40];
+  int (*const read[3])(unsigned long long*) = {pool_stats_cyl, pool_stats_tet, pool_stats_sph};
+  for (int k = 0; k < 3; k++) {
+    if (read[k](part)) return 1;
+    for (int i = 0; i < 40; i++) out[i] += part[i];
+  }
+  return 0;
 }
 #endif
 

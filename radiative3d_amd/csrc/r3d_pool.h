@@ -42,18 +42,11 @@
 #ifndef R3D_POOL_H_
 #define R3D_POOL_H_
 
+#include "r3d_kernels.h"
+#include "r3d_wave.h"
+
 namespace r3d {
 
-#ifndef R3D_POOL_BLOCK
-#define R3D_POOL_BLOCK 768
-#endif
-// 12 waves = 3 per SIMD, i.e. a budget of 168 registers per lane.  At two waves per SIMD a wave that
-// waits (memory round trips, dependent fp64 chains) is covered by one other only, so a third is
-// worth 15-25 % -- once every phase fits the budget: the R/T solve in two halves with nothing but
-// the choice carried across, event counters that live for one batch, the launch arguments fetched
-// per batch (0-4 vector registers spilled).  Measured at 512 / 768 threads, same code otherwise:
-// NSCP 15.8 / 12.8 ms, LopNor 13.9 / 11.0, SphereEarth 40.8 / 33.0 per 3e6 histories.
-constexpr int kPoolBlock = R3D_POOL_BLOCK;
 // Wave priority: raised while a wave is between batches (hand-off, scheduling, take) -- serial LDS
 // round trips during which it holds slots other waves may be polling for -- and lowered for the
 // phase's arithmetic: from the hand-off until the next batch's state is in registers
@@ -66,7 +59,6 @@ constexpr int kPoolBlock = R3D_POOL_BLOCK;
 #define R3D_PRIO_MOVE() __builtin_amdgcn_s_setprio(1)
 constexpr int kPoolWaves = kPoolBlock / 64;
 
-enum { Q_MOVE = 0, Q_COLLECT = 1, Q_RT = 2, Q_SCATTER = 3, Q_FREE = 4, Q_NUM = 5 };
 constexpr uint16_t kRingEmpty = 0xFFFFu;
 // The rings are polled with volatile accesses.  Through a plain (generic) pointer those compile to
 // FLAT instructions with system-scope cache bits and a wait for every outstanding memory operation
@@ -74,14 +66,6 @@ constexpr uint16_t kRingEmpty = 0xFFFFu;
 // LDS address space they are the ds_read_u16 / ds_write_b16 they should be.
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
-// One history in flight = one slot number; its state is spread over field-major arrays in LDS
-// (fd[field][slot] doubles, fu[field][slot] words), so that a batch of neighbouring slot numbers
-// reads and writes each field without bank conflicts (slot-major 128-byte records measured 77 % of
-// the LDS cycles as conflicts).  meta: bit 0 ray type | bits 1-3 pending face + 1 (0: none) |
-// bits 8-15 that face's flags | bits 16-18 the queue the slot is in (for carry-over).
-enum { FD_T, FD_PATH, FD_RECENT, FD_LAMP, FD_LX, FD_LY, FD_LZ, FD_DX, FD_DY, FD_DZ, FD_PC, FD_PS, FD_NUM };
-enum { FU_CELL, FU_MOVES, FU_K, FU_META, FU_IDLO, FU_IDHI, FU_CATCH, FU_NBR, FU_NUM };   // NBR: the cell behind the pending face
-constexpr size_t kSlotBytes = FD_NUM * sizeof(double) + FU_NUM * sizeof(uint32_t);   // 128
 
 // Queue control: word[q] = head ticket << 16 | published entries (a consumer moves both with one
 // compare-and-swap), tail[q] = next ticket for producers; word[kDrainedWord] = the global id
@@ -269,7 +253,7 @@ __device__ __forceinline__ uint32_t pool_collect_pairs(const KArgs& a, const Tab
 #ifdef R3D_PHASE_TIMING
 // diagnostic build: per queue, batches served, lanes filled, wave cycles spent; slot 6: idle polls;
 // slot 7 of rows 0 / 1: move sub-iterations run / lanes live in them
-__device__ unsigned long long g_pool_stats[5][8];   // rows 3 / 4: cycles in the take / in the hand-off
+static __device__ unsigned long long g_pool_stats[5][8];   // rows 3 / 4: cycles in the take / in the hand-off
 #endif
 
 // Moves a batch may make before its slots go back to the queues: lanes whose move ends with nothing

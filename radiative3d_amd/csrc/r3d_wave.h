@@ -1,0 +1,67 @@
+// r3d_wave.h -- wave-level helpers and the per-workgroup bin accumulators of the traversal kernel
+// (device code; included by r3d_kernels_kind.hip ahead of r3d_pool.h).
+#ifndef R3D_WAVE_H_
+#define R3D_WAVE_H_
+
+#include <hip/hip_runtime.h>
+
+#include "r3d_kernels.h"
+#include "r3d_step.h"
+
+namespace r3d {
+
+// ---------------------------------------------------- wave-level helpers ----
+// number of set bits of m below this lane
+__device__ __forceinline__ unsigned rank_in(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+__device__ __forceinline__ double bcast(double v, int src) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ V3 bcast(V3 v, int src) { return v3(bcast(v.x, src), bcast(v.y, src), bcast(v.z, src)); }
+
+// Per-workgroup accumulators for seismometer bins, in LDS.  First arrivals pile
+// onto a handful of (seismometer, time-bin) records -- in the LopNor runs one bin
+// takes a quarter of all catches and sixteen take 58 % -- and atomics on one
+// address are served one after the other by a single L2 channel: measured, that
+// contention alone was half of the LopNor kernel time.  So a catch first tries a
+// small open-addressed table here (first come, first admitted; hot bins show up
+// early and often); the block adds each entry to HBM once, at the end.  A catch
+// that finds no entry takes the queue above.
+struct BinCache {
+  double* e;        // [n][5] energies X, Y, Z, P, S
+  uint32_t* key;    // [n]    seismometer * n_bins + bin, or kEmpty
+  uint32_t* cnt;    // [n][2] catches by type
+  uint32_t mask, shift;   // n - 1, 32 - log2 n
+  bool on;
+};
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+
+__device__ __forceinline__ bool bin_cache_add(const BinCache& bc, uint32_t bin, uint32_t type, double ex,
+                                              double ey, double ez, double et) {
+  uint32_t idx = (bin * 2654435761u) >> bc.shift;
+  for (int probe = 0; probe < 4; probe++) {
+    const uint32_t old = atomicCAS(&bc.key[idx], kEmpty, bin);
+    if (old == kEmpty || old == bin) {
+      double* e = bc.e + idx * 5u;
+      unsafeAtomicAdd(e + 0, ex);
+      unsafeAtomicAdd(e + 1, ey);
+      unsafeAtomicAdd(e + 2, ez);
+      unsafeAtomicAdd(e + 3 + type, et);
+      atomicAdd(&bc.cnt[idx * 2u + type], 1u);
+      return true;
+    }
+    idx = (idx + 1u) & bc.mask;
+  }
+  return false;
+}
+
+// RES: which of the small tables are staged in LDS (the enum itself: r3d_kernels.h).  RES_ALL: the cell records and the
+// scatterer heads (layered and spherical models: a few dozen cells); RES_TABLES: the scatterer
+// heads only (tetra models: the cell records come through L1 / L2); RES_NONE: neither (models
+// with thousands of scatterers, whose heads alone would crowd out the phonon pool).
+
+}  // namespace r3d
+#endif

@@ -22,7 +22,7 @@ def pytest_configure(config):
             os.path.join(REPO, "oracle", "libr3d_oracle.so"),
             os.path.join(REPO, "oracle", "libr3d_tables_oracle.so")]
     if not all(os.path.exists(p) for p in need):
-        subprocess.check_call(["make", "-C", REPO, "all"])
+        subprocess.check_call(["make", "-C", REPO, "-j", "8", "all"])
 
 
 @pytest.fixture(scope="session")

@@ -1,14 +1,22 @@
 #!/bin/bash
 # tools/disasm.sh KIND [extra hipcc flags] -- disassembly with source lines of the traversal kernels of one cell
-# kind (0 cylinder, 1 tetra, 2 sphere): /tmp/r3d_disasm_K/dev.lst (+ per-kernel files k_<mangled>.lst)
+# kind (0 cylinder, 1 tetra, 2 sphere): /tmp/r3d_disasm_K/dev.lst (+ per-kernel files k_<mangled>.lst); built with
+# the kind's own flags of the Makefile (HIPFLAGS_CYL / _TET / _SPH).
 set -e
 kind=$1; shift
 out=/tmp/r3d_disasm_$kind; mkdir -p $out
+case $kind in 0) tag=CYL;; 1) tag=TET;; *) tag=SPH;; esac
+kflags=$(make -s -f - print <<MK
+include Makefile
+print:
+	@echo \$(HIPFLAGS_$tag)
+MK
+)
 /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-bitwise-instead-of-logical \
-   -mllvm -disable-machine-licm -gline-tables-only -DR3D_DEV_ONLY_KIND=$kind "$@" -shared -pthread -o $out/lib.so \
-   radiative3d_amd/csrc/r3d_engine.hip radiative3d_amd/csrc/r3d_tables_build.hip
+   -mllvm -disable-machine-licm $kflags -gline-tables-only -DR3D_KIND=$kind "$@" -c -o $out/unit.o \
+   radiative3d_amd/csrc/r3d_kernels_kind.hip
 L=/opt/rocm/lib/llvm/bin
-$L/llvm-objcopy -O binary --only-section=.hip_fatbin $out/lib.so $out/fat.bin
+$L/llvm-objcopy -O binary --only-section=.hip_fatbin $out/unit.o $out/fat.bin
 $L/clang-offload-bundler --type=o --unbundle --input=$out/fat.bin --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=$out/dev.co
 $L/llvm-objdump -d -l --no-show-raw-insn $out/dev.co > $out/dev.lst
 python3 - $out <<'PY'

@@ -16,11 +16,19 @@ KEYS = ("name", "vgpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spill_coun
 def kernel_rows(lib=DEFAULT_LIB):
     """One dict per kernel of the gfx950 code object in `lib`: the KEYS above plus `demangled`."""
     tmp = tempfile.mkdtemp()
-    # the fat binary sits in .hip_fatbin: pull it out, then unbundle
+    # the fat binaries sit in .hip_fatbin, one offload bundle per translation unit: pull the section
+    # out, cut it at the bundle magic, unbundle each
     subprocess.check_call([f"{LLVM}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, tmp + "/fat.bin"])
-    subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--type=o", "--unbundle", "--input=" + tmp + "/fat.bin",
-                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + tmp + "/dev.co"])
-    notes = subprocess.check_output([f"{LLVM}/llvm-readelf", "--notes", tmp + "/dev.co"], text=True)
+    blob = open(tmp + "/fat.bin", "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+    notes = ""
+    for n, at in enumerate(starts):
+        end = starts[n + 1] if n + 1 < len(starts) else len(blob)
+        open(f"{tmp}/fat{n}.bin", "wb").write(blob[at:end])
+        subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--type=o", "--unbundle", f"--input={tmp}/fat{n}.bin",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={tmp}/dev{n}.co"])
+        notes += subprocess.check_output([f"{LLVM}/llvm-readelf", "--notes", f"{tmp}/dev{n}.co"], text=True)
     cur, rows = {}, []
     for line in notes.split("\n"):
         m = re.match(r"\s+- \.(agpr_count|args):", line)
