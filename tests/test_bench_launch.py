@@ -44,6 +44,38 @@ def test_a_failing_rank_stops_the_job():
     assert rc != 0
 
 
+def test_a_rendezvous_port_taken_in_between_is_retried_on_a_fresh_one(monkeypatch):
+    """free_port() releases its probe socket before rank 0 binds MASTER_PORT; if another process takes
+    the port in between, rank 0 fails at once -- spawn_ranks then starts the job again on a fresh port
+    (never when the caller fixed the port)."""
+    import socket
+    taken = socket.socket()
+    taken.bind(("127.0.0.1", 0))
+    taken.listen(1)
+    busy = taken.getsockname()[1]
+    handed_out = []
+    real_free_port = launch.free_port
+
+    def fake_free_port():
+        handed_out.append(busy if not handed_out else real_free_port())
+        return handed_out[-1]
+
+    monkeypatch.setattr(launch, "free_port", fake_free_port)
+    prog = ("import os, socket, sys\n"
+            "if os.environ['RANK'] == '0':\n"
+            "    s = socket.socket()\n"
+            "    try:\n"
+            "        s.bind(('127.0.0.1', int(os.environ['MASTER_PORT'])))\n"
+            "    except OSError:\n"
+            "        sys.exit(1)\n")
+    try:
+        assert launch.spawn_ranks(2, [sys.executable, "-c", prog]) == 0
+        assert len(handed_out) == 2 and handed_out[0] == busy and handed_out[1] != busy
+        assert launch.spawn_ranks(2, [sys.executable, "-c", prog], port=busy) != 0     # a named port is not replaced
+    finally:
+        taken.close()
+
+
 def test_under_launcher_detection():
     assert not launch.under_launcher({})
     assert launch.under_launcher({"RANK": "0", "WORLD_SIZE": "1", "MASTER_PORT": "1"})
