@@ -481,11 +481,16 @@ def main():
         cpu_parts = None
         if rank == 0:
             note("building host tables and timing the CPU baseline (oracle) ...")
-            t0 = time.perf_counter()
-            host_model = Model(wl["args"](args.toa_degree))
-            line["host"]["host_tables_model_build_s"] = round(time.perf_counter() - t0, 2)
-            line["cpu_baseline"], cpu_parts, per_thread = cpu_baseline(host_model)
-            plan[0], plan[1] = len(cpu_parts), per_thread
+            try:   # (whatever happens here, the other ranks are waiting in the broadcast below)
+                t0 = time.perf_counter()
+                host_model = Model(wl["args"](args.toa_degree))
+                line["host"]["host_tables_model_build_s"] = round(time.perf_counter() - t0, 2)
+                line["cpu_baseline"], cpu_parts, per_thread = cpu_baseline(host_model)
+                plan[0], plan[1] = len(cpu_parts), per_thread
+            except Exception as exc:   # noqa: BLE001 -- reported in the line, the timed figures stand
+                line["cpu_baseline"] = None
+                line["cpu_baseline_error"] = f"{type(exc).__name__}: {exc}"
+                cpu_parts = None
         if launched:
             dist.broadcast(plan, src=0)
         n_batches, per_batch = int(plan[0].item()), int(plan[1].item())
@@ -504,6 +509,14 @@ def main():
                     g_e.append(r.energy / per_batch), g_c.append(r.counts)
             return batch_moments(g_e, g_c) if rank == 0 else None
 
+        if n_batches == 0:   # (the CPU leg failed on rank 0: nothing to compare with)
+            if rank == 0:
+                print(json.dumps(line), flush=True)
+            engine.close()
+            if launched:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
         note("envelope check: GPU batches ...")
         # the GPU sample mirrors the CPU sample's batch structure (same count, same size), on ids
         # beyond every range used above: two independent samples of 1e7 histories each when the
