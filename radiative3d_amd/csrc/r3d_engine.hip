@@ -9,8 +9,10 @@
 // read-only tables (cells of layered and spherical models, scatterer heads) are staged in LDS,
 // tetra cells, receiver tables, CDFs (GBs at TOA degree 9) and bins stay in HBM / L2; bins are
 // accumulated through per-workgroup LDS accumulators into native fp64 / u64 global atomics; RNG
-// is counter-based Philox keyed by history id (r3d_rng.h): results are independent of lane, wave,
-// launch geometry, launch boundaries and GPU count.
+// is counter-based Philox keyed by history id (r3d_rng.h): which lane, wave, launch or GPU serves a
+// history changes its result by rounding at most (a few series pick their form by a vote of the
+// wave, r3d_math.h all_lanes) and not at all in the reproducible build (make repro).  The kernels
+// themselves are instantiated in r3d_kernels_kind.hip, one translation unit per cell kind.
 //
 // The product has no CPU path: without a HIP device every entry point fails with an error
 // message.
