@@ -88,6 +88,16 @@ typedef struct r3dh_grid_node {
   int32_t n_sets;
   int32_t pad_;
 } r3dh_grid_node;
+/* The same nodes as the model definition wrote them, BEFORE the coordinate system's conversion: the
+ * raw coordinate triple (GridNode::GetRawLoc) and the attribute sets in the order given, each as
+ * vp vs rho | which Q is the unknown (0 Qp, 1 Qs, 2 Qk) and the stored Qp Qs Qk | nu eps a kappa.  */
+typedef struct r3dh_grid_node_raw {
+  double  x[3];
+  double  set[2][11];
+  int32_t n_sets;
+  int32_t pad_;
+} r3dh_grid_node_raw;
+int r3dh_grid_nodes_raw(const r3dh_model* m, r3dh_grid_node_raw* out, size_t capacity);
 int r3dh_grid_size(const r3dh_model* m, int dims[3]);
 int r3dh_grid_nodes(const r3dh_model* m, r3dh_grid_node* out, size_t capacity);
 int r3dh_seismometer_axes(const r3dh_model* m, int i);

@@ -700,4 +700,75 @@ int r3d_oracle_build_cells(int kind, int ni, int nj, int nk, const r3d_oracle_no
   return (int)B.cells.size();
 }
 
+
+// ------------------------------------------------------ grid nodes -> model space --
+// What Model sees of a grid node: GridNode::Loc() = ECS.Convert(raw location) (grid.cpp:95-97,
+// ecs.cpp:319-372), GetRawLoc().Radius(ECS) (ecs.cpp:61-92), and GridNode::Data(side)
+// (grid.cpp:106-124: the one attribute set for both sides, or the first above / the second below)
+// through ECS.Convert(location, data) = Earth-flattening of the velocities (ecs.cpp:540-577; density,
+// Q and heterogeneity spectrum untouched, :595-677), with Qp / Qs solved from the two Qs given
+// (elastic.cpp:10-52).  map: 0 ENU_ORTHO, 1 RAE_ORTHO, 2 RAE_CURVED, 3 RAE_SPHERICAL.
+typedef struct r3d_oracle_node_raw {
+  double  x[3];
+  double  set[2][11];   /* vp vs rho | unknown-Q code (0 Qp, 1 Qs, 2 Qk), Qp, Qs, Qk | nu eps a kappa */
+  int32_t n_sets;
+  int32_t pad_;
+} r3d_oracle_node_raw;
+
+int r3d_oracle_convert_nodes(int map, double radE, int flatten, size_t n, const r3d_oracle_node_raw* raw,
+                             r3d_oracle_node* out) {
+  const double DtoR_ = PI / 180.0;
+  for (size_t i = 0; i < n; i++) {
+    const r3d_oracle_node_raw& r = raw[i];
+    r3d_oracle_node& o = out[i];
+    std::memset(&o, 0, sizeof o);
+    // EarthCoords::FlattenDepth, ecs.cpp:540-545
+    auto flatten_depth = [&](double z) { return radE * std::log((radE + z) / radE); };
+    double X, Y, Z;
+    if (map == 0) {
+      X = r.x[0], Y = r.x[1], Z = flatten ? flatten_depth(r.x[2]) : r.x[2];
+    } else if (map == 1) {
+      const double range = r.x[0], phi = DtoR_ * (90.0 - r.x[1]);
+      X = range * std::cos(phi), Y = range * std::sin(phi), Z = flatten ? flatten_depth(r.x[2]) : r.x[2];
+    } else {
+      const double range = r.x[0], theta = range / radE, phi = DtoR_ * (90.0 - r.x[1]);
+      const double rr = radE + r.x[2];
+      if (rr < 0 || theta > PI) return 1;
+      X = rr * std::sin(theta) * std::cos(phi), Y = rr * std::sin(theta) * std::sin(phi);
+      Z = (rr * std::cos(theta)) + (map == 2 ? -radE : 0.0);   // + GetEarthCenter().z()
+      o.radius = rr;                                            // ExtractRadius
+    }
+    o.loc[0] = X, o.loc[1] = Y, o.loc[2] = Z;
+    o.n_sets = r.n_sets;
+    if (r.n_sets == 0) continue;
+    for (int side = 0; side < 2; side++) {
+      const double* d = r.set[r.n_sets == 1 ? 0 : side];   // grid.cpp:113-120
+      double vp = d[0], vs = d[1];
+      if (flatten) {                                        // FlattenVelocity, ecs.cpp:564-577
+        const double f = radE / (radE + r.x[2]);
+        vp = vp * f, vs = vs * f;
+      }
+      // Elastic::Q::Qp / Qs, elastic.cpp:10-52 (L = (4/3)(beta/alpha)^2)
+      double L = vs / vp;
+      L *= L;
+      L *= (4. / 3.);
+      const int unknown = (int)d[3];
+      const double mQp = d[4], mQs = d[5], mQk = d[6];
+      double qp = mQp, qs = mQs;
+      if (unknown == 0) {
+        double q = (L == 0.) ? 0 : L / mQs;
+        q += (1. - L) / mQk;
+        qp = 1. / q;
+      } else if (unknown == 1) {
+        double q = 1. / mQp;
+        q -= (1. - L) / mQk;
+        qs = L / q;
+      }
+      const double v[9] = {vp, vs, d[2], qp, qs, d[7], d[8], d[9], d[10]};
+      for (int q = 0; q < 9; q++) o.side[side][q] = v[q];
+    }
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -32,6 +32,9 @@ def lib():
         L.r3d_oracle_build_cells.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_ffi.GridNode), C.c_double,
                                              C.c_double, C.c_int, C.POINTER(_ffi.Cell), C.c_int, _dp, C.c_int,
                                              C.POINTER(C.c_int)]
+        L.r3d_oracle_convert_nodes.restype = C.c_int
+        L.r3d_oracle_convert_nodes.argtypes = [C.c_int, C.c_double, C.c_int, C.c_size_t, C.POINTER(_ffi.GridNodeRaw),
+                                               C.POINTER(_ffi.GridNode)]
         _lib = L
     return _lib
 
@@ -115,3 +118,14 @@ def build_cells(kind, dims, nodes, frequency, cylinder_range=0.0, one_dummy_scat
     if n < 0:
         raise RuntimeError("r3d_oracle_build_cells: output too small")
     return cells, n, het[:n_scat.value]
+
+
+def convert_nodes(map_code, earth_radius, flatten, raw_nodes):
+    """ECS.Convert of every node's location and attributes (ecs.cpp:319-372, :540-577; grid.cpp:95-124;
+    elastic.cpp:10-52) -> array of _ffi.GridNode, what the cell builders read."""
+    from radiative3d_amd import _ffi
+    n = len(raw_nodes)
+    out = (_ffi.GridNode * n)()
+    if lib().r3d_oracle_convert_nodes(map_code, earth_radius, int(flatten), n, raw_nodes, out):
+        raise RuntimeError("r3d_oracle_convert_nodes: radius or range out of bounds")
+    return out

@@ -72,6 +72,11 @@ class GridNode(C.Structure):
                 ("n_sets", C.c_int32), ("pad_", C.c_int32)]
 
 
+class GridNodeRaw(C.Structure):
+    """r3dh_grid_node_raw (include/r3d_host.h): one grid node as the model definition wrote it."""
+    _fields_ = [("x", C.c_double * 3), ("set", (C.c_double * 11) * 2), ("n_sets", C.c_int32), ("pad_", C.c_int32)]
+
+
 class Result(C.Structure):
     _fields_ = [("energy", _dp), ("counts", C.POINTER(C.c_uint64)), ("n_lost", C.c_uint64),
                 ("n_timeout", C.c_uint64), ("n_invalid", C.c_uint64),
@@ -163,6 +168,8 @@ def host_lib():
         L.r3dh_grid_size.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.r3dh_grid_nodes.restype = C.c_int
         L.r3dh_grid_nodes.argtypes = [C.c_void_p, C.POINTER(GridNode), C.c_size_t]
+        L.r3dh_grid_nodes_raw.restype = C.c_int
+        L.r3dh_grid_nodes_raw.argtypes = [C.c_void_p, C.POINTER(GridNodeRaw), C.c_size_t]
         L.r3dh_seismometer_axes.restype = C.c_int
         L.r3dh_seismometer_axes.argtypes = [C.c_void_p, C.c_int]
         _host = L

@@ -201,6 +201,38 @@ int r3dh_grid_nodes(const r3dh_model* m, r3dh_grid_node* out, size_t capacity) {
   return 1;
 }
 
+int r3dh_grid_nodes_raw(const r3dh_model* m, r3dh_grid_node_raw* out, size_t capacity) {
+  if (!m || !out) return 1;
+  try {
+    const Grid& g = m->model->GetGridRef();
+    if ((size_t)g.N() > capacity) throw Runtime("r3dh_grid_nodes_raw: output too small");
+    size_t at = 0;
+    for (Index k = 0; k < g.Nk(); k++)
+      for (Index j = 0; j < g.Nj(); j++)
+        for (Index i = 0; i < g.Ni(); i++) {
+          const GridNode& n = g.Node(i, j, k);
+          r3dh_grid_node_raw& o = out[at++];
+          std::memset(&o, 0, sizeof o);
+          const EarthCoords::Generic raw = n.GetRawLoc();
+          o.x[0] = raw.x1(), o.x[1] = raw.x2(), o.x[2] = raw.x3();
+          o.n_sets = n.NumAttributeSets();
+          for (int s = 0; s < o.n_sets && s < 2; s++) {
+            const GridData d = n.RawData(s);
+            int missing;
+            Real qp, qs, qk;
+            d.getQ().Stored(missing, qp, qs, qk);
+            const double v[11] = {d.Vp(), d.Vs(), d.Rho(), (double)missing, qp, qs, qk, d.getHS().nu(),
+                                  d.getHS().eps(), d.getHS().a(), d.getHS().kappa()};
+            for (int q = 0; q < 11; q++) o.set[s][q] = v[q];
+          }
+        }
+    return 0;
+  } catch (const std::exception& e) {
+    g_error = e.what();
+  }
+  return 1;
+}
+
 int r3dh_seismometer_axes(const r3dh_model* m, int i) {
   if (!m || i < 0 || i >= (int)m->model->SeisAxesDesc().size()) return -1;
   return m->model->SeisAxesDesc()[i] == "RTZ" ? 1 : 0;

@@ -72,6 +72,11 @@ class Q {
     Real l = L(v);
     return (1. - l) / (1. / mQp - l / mQs);
   }
+  // As given (for tests that restate the conversions): which of the three is the unknown
+  // (0 Qp, 1 Qs, 2 Qk) and the three stored values.
+  void Stored(int& missing, Real& qp, Real& qs, Real& qk) const {
+    missing = (int)mMissing, qp = mQp, qs = mQs, qk = mQk;
+  }
 };
 
 struct Qinf : Q {

@@ -172,6 +172,16 @@ class Model:
             raise RuntimeError("r3dh_grid_nodes failed: " + self._lib.r3dh_last_error().decode())
         return tuple(dims), nodes
 
+    def grid_nodes_raw(self):
+        """array of _ffi.GridNodeRaw in the grid's own order: the nodes before the coordinate system's conversion."""
+        dims = (C.c_int * 3)()
+        self._lib.r3dh_grid_size(self._h, dims)
+        n = dims[0] * dims[1] * dims[2]
+        nodes = (_ffi.GridNodeRaw * n)()
+        if self._lib.r3dh_grid_nodes_raw(self._h, nodes, n):
+            raise RuntimeError("r3dh_grid_nodes_raw failed: " + self._lib.r3dh_last_error().decode())
+        return nodes
+
     def seismometer_axes(self, i):
         """0 ENZ, 1 RTZ (model.cpp:486-491)."""
         return int(self._lib.r3dh_seismometer_axes(self._h, i))

@@ -292,3 +292,26 @@ def test_event_test_mission_prints_the_oracles_radiation_patterns(tmp_path, sour
             assert float(lon) == pytest.approx(np.degrees(toa[k, 1]), rel=6e-6, abs=1e-6)
             assert float(lat) == pytest.approx(90.0 - np.degrees(toa[k, 0]), rel=6e-6, abs=1e-6)
             assert float(size) == pytest.approx(want[k], rel=6e-6, abs=1e-9), (source, sym, k)
+
+
+@pytest.mark.parametrize("name", ["halfspace", "lopnor", "lopnor_vids", "crustpinch", "upthrust", "sphere", "toysphere_vids"])
+def test_coordinate_conversion_of_the_grid_matches_the_oracle(name):
+    """The step between the model definition's grid (anchored to the reference's own user.cpp by byte-identical
+    grid dumps, tests/test_user_models_compile.py) and the nodes the cell builders read: ECS.Convert of every
+    location (ortho, range-azimuth, curved, spherical; Earth-flattened depths), the flattened velocities, and
+    Qp / Qs solved from the two Q values given (ecs.cpp:319-372, :540-577; grid.cpp:95-124; elastic.cpp:10-52)."""
+    m = Model(CONFIGS[name](2))
+    code, rad_e, flat = m.coordinates
+    dims, nodes = m.grid_nodes()
+    raw = m.grid_nodes_raw()
+    want = T.convert_nodes(code, rad_e, flat, raw)
+    assert len(want) == len(nodes) == dims[0] * dims[1] * dims[2]
+    if name == "lopnor":
+        assert flat and any(abs(raw[i].x[2] - nodes[i].loc[2]) > 1e-3 for i in range(len(raw)))   # depths really move
+    for i in range(len(nodes)):
+        g, w = nodes[i], want[i]
+        assert g.n_sets == w.n_sets
+        assert np.allclose(list(g.loc), list(w.loc), rtol=1e-14, atol=1e-11), (name, i)
+        assert g.radius == pytest.approx(w.radius, rel=1e-15, abs=0)
+        for side in range(2):
+            assert np.allclose(list(g.side[side]), list(w.side[side]), rtol=1e-14, atol=0, equal_nan=True), (name, i, side)
