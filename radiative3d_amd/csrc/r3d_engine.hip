@@ -400,8 +400,18 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
     // every compiled variant can be held against the oracle on any model
     int force_res = 0;
     if (const char* s = getenv("R3D_FORCE_RES")) force_res = atoi(s);
-    const bool scat_fit = scat_bytes <= 24 * 1024 && force_res < RES_NONE;
-    const bool cells_fit = scat_fit && cell_bytes + scat_bytes <= 24 * 1024 && force_res < RES_TABLES &&
+    uint32_t acc_bits = m->n_seismometers > 0 ? 8u : 0u;   // 256 accumulators = 13 KB ...
+    if (const char* s = getenv("R3D_ACC_BITS")) acc_bits = (uint32_t)atoi(s);   // developer tuning
+    if (acc_bits && acc_bits < 5) acc_bits = 0;
+    const size_t acc_bytes = acc_bits ? (kAccEntryBytes << acc_bits) : 0;
+    // The pool's field arrays have kSlotStride entries each (r3d_pool.h: a constant distance between a
+    // slot's fields), 128 KB in all, and the rings one entry per slot: what is staged beside them is
+    // what the remaining ~20 KB hold -- the bin accumulators first, then the scatterer heads, then
+    // the cell records.
+    const size_t pool_bytes = (size_t)kSlotStride * kSlotBytes, ring_bytes = (size_t)Q_NUM * kSlotStride * sizeof(uint16_t);
+    const size_t room = kLds - kStatic - pool_bytes - ring_bytes - 64 - acc_bytes;   // (64: alignment of up to four blocks)
+    const bool scat_fit = scat_bytes <= room && force_res < RES_NONE;
+    const bool cells_fit = scat_fit && cell_bytes + scat_bytes <= room && force_res < RES_TABLES &&
                            m->cell_kind != R3D_CELL_TETRA;
     e->res = cells_fit ? RES_ALL : scat_fit ? RES_TABLES : RES_NONE;
     size_t off = 0;
@@ -412,23 +422,10 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
       a.lds_scat_off = (uint32_t)off, off = align16(off + head_bytes);
       a.lds_scatptr_off = (uint32_t)off, off = align16(off + scat_bytes - head_bytes);
     }
-    uint32_t acc_bits = m->n_seismometers > 0 ? 8u : 0u;   // 256 accumulators = 13 KB ...
-    if (const char* s = getenv("R3D_ACC_BITS")) acc_bits = (uint32_t)atoi(s);   // developer tuning
-    if (acc_bits && acc_bits < 5) acc_bits = 0;
     a.lds_acc_off = (uint32_t)off, a.acc_bits = acc_bits;
-    if (acc_bits) off = align16(off + (kAccEntryBytes << acc_bits));
-    const size_t left = kLds - kStatic - off;
-    // S slots need 124 S bytes + one ring of (power of two >= S) u16 per queue: try the largest first
-    uint32_t slots = 0, cap = 0;
-    for (uint32_t s_try = 1984; s_try >= 128; s_try -= 64) {   // (a ring entry has 11 bits for the slot number)
-      uint32_t c = 64;
-      while (c < s_try) c <<= 1;
-      if ((size_t)s_try * kSlotBytes + (size_t)Q_NUM * c * sizeof(uint16_t) <= left) {
-        slots = s_try, cap = c;
-        break;
-      }
-    }
-    if (const char* s = getenv("R3D_POOL_SLOTS")) {   // developer tuning (never more than fits)
+    if (acc_bits) off = align16(off + acc_bytes);
+    uint32_t slots = kSlotStride, cap = kSlotStride;
+    if (const char* s = getenv("R3D_POOL_SLOTS")) {   // developer tuning: fewer slots in circulation
       uint32_t want = (uint32_t)atoi(s) / 64 * 64;   // at least a slot per lane of the workgroup
       if (want < (uint32_t)kPoolBlock) want = (uint32_t)kPoolBlock;
       if (want < slots) {
@@ -436,12 +433,8 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
         while (cap < slots) cap <<= 1;
       }
     }
-    if (slots < (uint32_t)kPoolBlock) {
-      g_error = "internal error: the model's LDS tables leave no room for the phonon pool";
-      return nullptr;
-    }
     a.pool_slots = slots, a.pool_ring_mask = cap - 1;
-    a.lds_pool_off = (uint32_t)off, off = align16(off + (size_t)slots * kSlotBytes);
+    a.lds_pool_off = (uint32_t)off, off = align16(off + pool_bytes);
     a.lds_ring_off = (uint32_t)off, off = align16(off + (size_t)Q_NUM * cap * sizeof(uint16_t));
     e->lds_bytes = off;
     if (e->lds_bytes + kStatic > kLds) {
@@ -455,7 +448,7 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   // persistent grid: one workgroup per CU (the pool takes the CU's whole LDS), all resident at
   // once, so every workgroup is running while there is work and none queues behind
   e->grid_blocks = prop.multiProcessorCount;
-  e->carry_bytes = (size_t)e->grid_blocks * a.pool_slots * kSlotBytes;
+  e->carry_bytes = (size_t)e->grid_blocks * kSlotStride * kSlotBytes;
 
   // ---- result scratch, work counter, stream, events ----
   R3D_HIP_OK(e->d_energy.alloc_zero((size_t)std::max(1, e->n_seis) * e->n_bins * R3D_N_ENERGY * sizeof(double)));

@@ -33,6 +33,7 @@ enum { Q_MOVE = 0, Q_COLLECT = 1, Q_RT = 2, Q_SCATTER = 3, Q_FREE = 4, Q_NUM = 5
 enum { FD_T, FD_PATH, FD_RECENT, FD_LAMP, FD_LX, FD_LY, FD_LZ, FD_DX, FD_DY, FD_DZ, FD_PC, FD_PS, FD_NUM };
 enum { FU_CELL, FU_MOVES, FU_K, FU_META, FU_IDLO, FU_IDHI, FU_CATCH, FU_NBR, FU_NUM };   // NBR: the cell behind the pending face
 constexpr size_t kSlotBytes = FD_NUM * sizeof(double) + FU_NUM * sizeof(uint32_t);   // 128
+constexpr uint32_t kSlotStride = 1024;   // entries per field array of the pool (>= the slots in circulation)
 
 // bytes of one bin accumulator of the per-workgroup table (BinCache, r3d_wave.h)
 constexpr size_t kAccEntryBytes = 5 * sizeof(double) + 3 * sizeof(uint32_t);

@@ -331,8 +331,12 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   // ---- the pool, its queues, the block's tallies ----
   const uint32_t S = a.pool_slots, rcap = a.pool_ring_mask + 1u, rmask = a.pool_ring_mask;
   const uint32_t rlog = 31u - (uint32_t)__builtin_clz(rcap);   // (a power of two)
-  double* const fd = reinterpret_cast<double*>(smem + a.lds_pool_off);          // [FD_NUM][S]
-  uint32_t* const fu = reinterpret_cast<uint32_t*>(fd + (size_t)FD_NUM * S);    // [FU_NUM][S]
+  // (field arrays of kSlotStride entries whatever S is: with the distance between a slot's fields a
+  //  constant, a field's address is the slot's plus an immediate offset, and two fields come with one
+  //  ds_read2st64 / go with one ds_write2st64)
+  constexpr uint32_t F = kSlotStride;
+  double* const fd = reinterpret_cast<double*>(smem + a.lds_pool_off);          // [FD_NUM][F]
+  uint32_t* const fu = reinterpret_cast<uint32_t*>(fd + (size_t)FD_NUM * F);    // [FU_NUM][F]
   lds_u16* const rings = (lds_u16*)(smem + a.lds_ring_off);                      // [Q_NUM][rcap]
   __shared__ PoolCtl ctl;
   __shared__ unsigned long long s_tally[R3D_N_SCALARS];
@@ -341,7 +345,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   if (tid < 8) ctl.word[tid] = 0u, ctl.tail[tid] = 0u;
   __syncthreads();
   auto ring = [&](int q) { return rings + (uint32_t)q * rcap; };
-  const size_t image_words = (size_t)S * (kSlotBytes / 4);   // the pool's state as 32-bit words
+  const size_t image_words = (size_t)F * (kSlotBytes / 4);   // the pool's state as 32-bit words
   if (a.carry_in) {
     // resume: the pool image this workgroup parked at the end of the engine's previous launch;
     // every slot goes back to the queue named in its meta word
@@ -352,38 +356,30 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
     for (uint32_t base = 0; base < S; base += kPoolBlock) {
       const uint32_t s = base + tid;
       const bool have = s < S;
-      const int tag = have ? (int)((fu[FU_META * S + s] >> 16) & 7u) : 0;
+      const int tag = have ? (int)((fu[FU_META * F + s] >> 16) & 7u) : 0;
       q_push_all(ctl, rings, rcap, rlog, lane, have, tag, s);
     }
   } else {
     for (uint32_t s = tid; s < S; s += kPoolBlock) {
       ring(Q_FREE)[s] = (uint16_t)s;
-      fu[FU_META * S + s] = meta_pack(0, -1, 0u, Q_FREE);
+      fu[FU_META * F + s] = meta_pack(0, -1, 0u, Q_FREE);
     }
     if (tid == 0) ctl.tail[Q_FREE] = S, ctl.word[Q_FREE] = S;
   }
   __syncthreads();
 
   constexpr int kEv = 3 + R3D_INV_NUM;
-  // Tallies: the per-lane event counters of r3d_step.h (LaneStats) live for one batch and are
-  // then summed over the wave (one packed butterfly) into the block's LDS tallies; fates and
-  // wave-uniform counts go there by ballot / directly.  (Counters that ran on in registers for the
-  // whole launch were ten registers that every phase had to carry -- or spill -- around its peak.)
+  // Tallies: the per-lane event counters of r3d_step.h (LaneStats) start from zero for every move or
+  // face event, so "this lane's counter moved" is a lane mask the compiler already holds (the
+  // condition the increment sat under); the masks are counted with scalar instructions and the
+  // batch's sums go to the block's LDS tallies once, from lane 0.  (Counters that ran on in registers
+  // for the whole launch were ten registers that every phase had to carry -- or spill -- around its
+  // peak; per-batch counters summed by a wave butterfly were ~40 vector instructions a batch.)
   auto tally_n = [&](int slot, unsigned long long n) {
     if (lane == 0 && n) atomicAdd(&s_tally[slot], n);
   };
   auto tally = [&](bool cond, int slot) { tally_n(slot, (unsigned long long)__popcll(__ballot(cond))); };
-  auto tally_stats = [&](const LaneStats& st) {   // iterations, transfers, reflections (each <= 32 per lane and batch)
-    unsigned long long v = (unsigned long long)st.iterations | ((unsigned long long)st.transfer << 16) |
-                           ((unsigned long long)st.reflect << 32);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if (lane == 0) {
-      if (v & 0xFFFFull) atomicAdd(&s_tally[kEv + R3D_EV_ITERATIONS], v & 0xFFFFull);
-      if ((v >> 16) & 0xFFFFull) atomicAdd(&s_tally[kEv + R3D_EV_TRANSFER], (v >> 16) & 0xFFFFull);
-      if ((v >> 32) & 0xFFFFull) atomicAdd(&s_tally[kEv + R3D_EV_REFLECT], (v >> 32) & 0xFFFFull);
-    }
-  };
+  auto count = [&](bool cond) { return (uint32_t)__popcll(__ballot(cond)); };
   // Report stream (diagnostic kernel only; include/r3d.h r3d_event): the lanes for which `cond`
   // holds append one record each; the wave claims the slots with one atomic.
   auto report = [&](bool cond, int tag, const Phonon& q, uint64_t hid) {
@@ -434,24 +430,24 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   auto load_state = [&](unsigned id, Phonon& p, Rng& rng, uint32_t& meta) {
     const double* d = fd + id;
     const uint32_t* u = fu + id;
-    p.t = d[FD_T * S], p.path = d[FD_PATH * S], p.recent = d[FD_RECENT * S], p.lamp = d[FD_LAMP * S];
-    p.loc = v3(d[FD_LX * S], d[FD_LY * S], d[FD_LZ * S]);
-    p.dir = v3(d[FD_DX * S], d[FD_DY * S], d[FD_DZ * S]);
-    p.pc = d[FD_PC * S], p.ps = d[FD_PS * S];
-    p.cell = (int32_t)u[FU_CELL * S], p.moves = u[FU_MOVES * S];
-    meta = u[FU_META * S];
+    p.t = d[FD_T * F], p.path = d[FD_PATH * F], p.recent = d[FD_RECENT * F], p.lamp = d[FD_LAMP * F];
+    p.loc = v3(d[FD_LX * F], d[FD_LY * F], d[FD_LZ * F]);
+    p.dir = v3(d[FD_DX * F], d[FD_DY * F], d[FD_DZ * F]);
+    p.pc = d[FD_PC * F], p.ps = d[FD_PS * F];
+    p.cell = (int32_t)u[FU_CELL * F], p.moves = u[FU_MOVES * F];
+    meta = u[FU_META * F];
     p.type = (int32_t)(meta & 1u);
-    rng.k = u[FU_K * S], rng.id_lo = u[FU_IDLO * S], rng.id_hi = u[FU_IDHI * S];
+    rng.k = u[FU_K * F], rng.id_lo = u[FU_IDLO * F], rng.id_hi = u[FU_IDHI * F];
   };
   // (the fields a move or a face event can change: everything but the history id)
   auto store_state = [&](unsigned id, const Phonon& p, const Rng& rng, uint32_t meta) {
     double* d = fd + id;
     uint32_t* u = fu + id;
-    d[FD_T * S] = p.t, d[FD_PATH * S] = p.path, d[FD_RECENT * S] = p.recent, d[FD_LAMP * S] = p.lamp;
-    d[FD_LX * S] = p.loc.x, d[FD_LY * S] = p.loc.y, d[FD_LZ * S] = p.loc.z;
-    d[FD_DX * S] = p.dir.x, d[FD_DY * S] = p.dir.y, d[FD_DZ * S] = p.dir.z;
-    d[FD_PC * S] = p.pc, d[FD_PS * S] = p.ps;
-    u[FU_CELL * S] = (uint32_t)p.cell, u[FU_MOVES * S] = p.moves, u[FU_K * S] = rng.k, u[FU_META * S] = meta;
+    d[FD_T * F] = p.t, d[FD_PATH * F] = p.path, d[FD_RECENT * F] = p.recent, d[FD_LAMP * F] = p.lamp;
+    d[FD_LX * F] = p.loc.x, d[FD_LY * F] = p.loc.y, d[FD_LZ * F] = p.loc.z;
+    d[FD_DX * F] = p.dir.x, d[FD_DY * F] = p.dir.y, d[FD_DZ * F] = p.dir.z;
+    d[FD_PC * F] = p.pc, d[FD_PS * F] = p.ps;
+    u[FU_CELL * F] = (uint32_t)p.cell, u[FU_MOVES * F] = p.moves, u[FU_K * F] = rng.k, u[FU_META * F] = meta;
   };
 #ifdef R3D_PHASE_TIMING
   __shared__ unsigned long long s_stats[5][8];
@@ -528,7 +524,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
     const unsigned long long t_begin = __builtin_readcyclecounter();
 #endif
     int dest = Q_FREE;   // where each active lane's slot goes after this phase
-    LaneStats st = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t n_iter = 0, n_transfer = 0, n_reflect = 0;   // the batch's event counts (wave-uniform)
 
 #ifndef R3D_PRIO_NARROW
     if (q == Q_FREE) R3D_PRIO_LOW();
@@ -550,7 +546,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         rng_init(rng, hid);
         spray(a, p, rng);
         store_state(id, p, rng, meta_pack(p.type, -1, 0u, Q_MOVE));
-        fu[FU_IDLO * S + id] = rng.id_lo, fu[FU_IDHI * S + id] = rng.id_hi, fu[FU_CATCH * S + id] = 0u;
+        fu[FU_IDLO * F + id] = rng.id_lo, fu[FU_IDHI * F + id] = rng.id_hi, fu[FU_CATCH * F + id] = 0u;
         dest = Q_MOVE;
       }
       report(fresh, 0, p, hid);   // GEN
@@ -577,6 +573,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         Pending ev;
         ev.vel = 0.0, ev.face = -1, ev.flags = 0u, ev.nbr = -1;
         bool leaving = false;
+        LaneStats st = {0, 0, 0, 0, 0, 0, 0};
         if (live) {
           fate = step_move<KIND>(a, T, p, rng, st, &reason, ev);
           leaving = true;
@@ -595,16 +592,12 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
           }
         }
         const bool light = live && !leaving;
-        if (light) {
-          const uint32_t tr0 = st.transfer, rf0 = st.reflect;
-          step_event<KIND, EV_BEND>(a, T, p, rng, st, ev, ev.nbr);
-          if (TRACE) {
-            report(st.reflect != rf0, 2, p, hid);    // REF
-            report(st.transfer != tr0, 4, p, hid);   // CEL
-          }
-        } else if (TRACE) {
-          report(false, 2, p, hid), report(false, 4, p, hid);
+        if (light) step_event<KIND, EV_BEND>(a, T, p, rng, st, ev, ev.nbr);
+        if (TRACE) {
+          report(st.reflect != 0u, 2, p, hid);    // REF
+          report(st.transfer != 0u, 4, p, hid);   // CEL
         }
+        n_iter += count(st.iterations != 0u), n_transfer += count(st.transfer != 0u), n_reflect += count(st.reflect != 0u);
         live = light;
         const unsigned n_live = (unsigned)__popcll(__ballot(live));
         // a full batch goes on while most of its lanes can (the others' slots are wanted by the
@@ -622,14 +615,14 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
           if (keep) {
             store_state(id, p, rng, meta_pack(p.type, dest == Q_MOVE ? -1 : ev.face, dest == Q_MOVE ? 0u : ev.flags, dest));
             if (dest == Q_RT || dest == Q_COLLECT)   // (the cell's record is at hand here: the later phase need not wait for it)
-              fu[FU_NBR * S + id] = (uint32_t)ev.nbr;
+              fu[FU_NBR * F + id] = (uint32_t)ev.nbr;
           } else
-            fu[FU_META * S + id] = meta_pack(0, -1, 0u, Q_FREE);
+            fu[FU_META * F + id] = meta_pack(0, -1, 0u, Q_FREE);
         }
         if (last) break;
       }
       const bool died = act && dest == Q_FREE;
-      finish(died, fate, reason, p, hid, (TRACE && died) ? fu[FU_CATCH * S + id] : 0u);
+      finish(died, fate, reason, p, hid, (TRACE && died) ? fu[FU_CATCH * F + id] : 0u);
     } else if (q == Q_COLLECT) {
       // ---- arrival at a collection face: the receivers, with the incident state
       //      (phonons.cpp:629-631), then on to what the face itself asks for ----
@@ -680,26 +673,25 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         }
       }
       const bool light = act && dest == Q_MOVE;
+      LaneStats st = {0, 0, 0, 0, 0, 0, 0};
       if (light) {
-        const uint32_t tr0 = st.transfer, rf0 = st.reflect;
-        step_event<KIND, EV_BEND>(a, T, p, rng, st, ev, (int)fu[FU_NBR * S + id]);
-        if (TRACE) {
-          report(st.reflect != rf0, 2, p, hid);    // REF
-          report(st.transfer != tr0, 4, p, hid);   // CEL
-        }
+        step_event<KIND, EV_BEND>(a, T, p, rng, st, ev, (int)fu[FU_NBR * F + id]);
         double* d = fd + id;
-        d[FD_DX * S] = p.dir.x, d[FD_DY * S] = p.dir.y, d[FD_DZ * S] = p.dir.z;
-        d[FD_PC * S] = p.pc, d[FD_PS * S] = p.ps;
-        fu[FU_CELL * S + id] = (uint32_t)p.cell;
-      } else if (TRACE) {
-        report(false, 2, p, hid), report(false, 4, p, hid);
+        d[FD_DX * F] = p.dir.x, d[FD_DY * F] = p.dir.y, d[FD_DZ * F] = p.dir.z;
+        d[FD_PC * F] = p.pc, d[FD_PS * F] = p.ps;
+        fu[FU_CELL * F + id] = (uint32_t)p.cell;
       }
+      if (TRACE) {
+        report(st.reflect != 0u, 2, p, hid);    // REF
+        report(st.transfer != 0u, 4, p, hid);   // CEL
+      }
+      n_transfer += count(st.transfer != 0u), n_reflect += count(st.reflect != 0u);
       if (act) {
-        fu[FU_META * S + id] = died ? meta_pack(0, -1, 0u, Q_FREE)
+        fu[FU_META * F + id] = died ? meta_pack(0, -1, 0u, Q_FREE)
                                     : meta_pack(p.type, light ? -1 : ev.face, light ? 0u : ev.flags, dest);
-        if (TRACE) fu[FU_CATCH * S + id] += catches;
+        if (TRACE) fu[FU_CATCH * F + id] += catches;
       }
-      finish(died, FATE_LOST, 0, p, hid, (TRACE && died) ? fu[FU_CATCH * S + id] : 0u);
+      finish(died, FATE_LOST, 0, p, hid, (TRACE && died) ? fu[FU_CATCH * F + id] : 0u);
     } else {
       // ---- RT: reflection / transmission solve; SCATTER: deflection drawn from the scatterer's
       //      tables (phonons.cpp:611-618, :640-661) ----
@@ -707,7 +699,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       Rng rng;
       uint32_t meta = 0;
       uint64_t hid = 0;
-      const uint32_t tr0 = st.transfer, rf0 = st.reflect;
+      LaneStats st = {0, 0, 0, 0, 0, 0, 0};
       if (act) {
         load_state(id, p, rng, meta);
 #ifndef R3D_PRIO_NARROW
@@ -718,12 +710,12 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         ev.vel = 0.0, ev.face = (int)((meta >> 1) & 7u) - 1, ev.flags = (meta >> 8) & 0xFFu, ev.nbr = -1;
         if (q == Q_RT) {
 #ifdef R3D_ABLATE_RT
-          step_event<KIND, EV_RT>(a, T, p, rng, st, ev, (int)fu[FU_NBR * S + id]);
+          step_event<KIND, EV_RT>(a, T, p, rng, st, ev, (int)fu[FU_NBR * F + id]);
 #else
           // the solve in two halves with nothing but the choice, the draw counter and the slot
           // number carried across (everything else is read again from the slot and the tables):
           // what is live while the weights are formed decides whether three waves fit a SIMD
-          const int nbr = (int)fu[FU_NBR * S + id];
+          const int nbr = (int)fu[FU_NBR * F + id];
           const RtChoice ch = rt_event_choose<KIND>(a, T, p, rng, st, ev, nbr);
           const uint32_t draws = rng.k;
           asm volatile("" ::: "memory");   // (the second half must not reuse the first half's loads)
@@ -734,26 +726,28 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
           rng.k = draws;
           Pending ev2;
           ev2.vel = 0.0, ev2.face = (int)((meta >> 1) & 7u) - 1, ev2.flags = (meta >> 8) & 0xFFu, ev2.nbr = -1;
-          rt_event_apply<KIND>(a, T, p, st, ev2, (int)fu[FU_NBR * S + id], ch);
+          rt_event_apply<KIND>(a, T, p, st, ev2, (int)fu[FU_NBR * F + id], ch);
 #endif
         } else {
           step_event<KIND, EV_SCATTER>(a, T, p, rng, st, ev);
         }
         double* d = fd + id;
-        d[FD_DX * S] = p.dir.x, d[FD_DY * S] = p.dir.y, d[FD_DZ * S] = p.dir.z;
-        d[FD_PC * S] = p.pc, d[FD_PS * S] = p.ps;
-        fu[FU_CELL * S + id] = (uint32_t)p.cell, fu[FU_K * S + id] = rng.k;
-        fu[FU_META * S + id] = meta_pack(p.type, -1, 0u, Q_MOVE);
+        d[FD_DX * F] = p.dir.x, d[FD_DY * F] = p.dir.y, d[FD_DZ * F] = p.dir.z;
+        d[FD_PC * F] = p.pc, d[FD_PS * F] = p.ps;
+        fu[FU_CELL * F + id] = (uint32_t)p.cell, fu[FU_K * F + id] = rng.k;
+        fu[FU_META * F + id] = meta_pack(p.type, -1, 0u, Q_MOVE);
         dest = Q_MOVE;
       }
       if (TRACE) {
         report(act && q == Q_SCATTER, 1, p, hid);   // SCT
-        report(st.reflect != rf0, 2, p, hid);       // REF
-        report(st.transfer != tr0, 4, p, hid);      // CEL
+        report(st.reflect != 0u, 2, p, hid);        // REF
+        report(st.transfer != 0u, 4, p, hid);       // CEL
       }
+      if (q == Q_RT) n_transfer += count(st.transfer != 0u), n_reflect += count(st.reflect != 0u);
     }
     if (q == Q_SCATTER) tally_n(kEv + R3D_EV_SCATTER, k);
-    else if (q != Q_FREE) tally_stats(st);
+    tally_n(kEv + R3D_EV_ITERATIONS, n_iter), tally_n(kEv + R3D_EV_TRANSFER, n_transfer);
+    tally_n(kEv + R3D_EV_REFLECT, n_reflect);
     if (q == Q_RT) tally_n(kEv + R3D_EV_RTSOLVE, k);
 #ifdef R3D_PHASE_TIMING
     const unsigned long long t_push = __builtin_readcyclecounter();

@@ -216,17 +216,6 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
     p.recent = 0;
   }
   st.iterations++;
-#if defined(R3D_EXP_SALU) && defined(__HIP_DEVICE_COMPILE__)
-  {   // experiment: R3D_EXP_SALU gratuitous scalar adds per move -- does scalar issue cost time?
-    unsigned x0 = p.moves & 0u, x1 = 1u, x2 = 2u, x3 = 3u;
-    x0 = __builtin_amdgcn_readfirstlane(x0);
-#pragma unroll
-    for (int i = 0; i < R3D_EXP_SALU / 4; i++)
-      asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1"
-                   : "+s"(x0), "+s"(x1), "+s"(x2), "+s"(x3));
-    if (x0 + x1 + x2 + x3 == 0x12345u) st.iterations++;
-  }
-#endif
   // Tetra records come from L2, a round trip of a microsecond under load.  The WHOLE record is read
   // into registers here, ahead of the move's random number: the fence below keeps later code from
   // moving up, so loads written at their uses -- inside the boundary search, and the links and the
