@@ -15,8 +15,11 @@ CXXFLAGS ?= -std=c++17 -O2 -fPIC -Wall -Wno-unused-function -Wno-unknown-pragmas
 # -disable-machine-licm: the kernel is one long loop; hoisting every libm polynomial constant
 # out of it costs ~60 registers, which were then spilled and reloaded (with a full wait each)
 # inside atan2 on every iteration.  Without the hoist: 199 VGPRs, no spills, -15 % kernel time.
+# -amdgpu-atomic-optimizer-strategy=None: the kernels' atomics on a uniform address are issued by ONE
+# lane already (a batch's tallies, the id counter); the optimiser still wraps each in its generic
+# reduction (lane election, a scalar loop over the active lanes): 1-2.5 % of the kernel time.
 HIPFLAGS ?= -std=c++17 -O3 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical \
-            -mllvm -disable-machine-licm
+            -mllvm -disable-machine-licm -mllvm -amdgpu-atomic-optimizer-strategy=None
 # The traversal kernels are one translation unit per cell kind (csrc/r3d_kernels_kind.hip), each with
 # the instruction scheduler that suits it: under the compiler's max-ILP strategy the spherical-shell
 # kernel runs 3.4 % faster (no vector register spilled, against 4) and the layered one 0.4 %, the

@@ -122,10 +122,12 @@ __device__ __forceinline__ unsigned q_pop(PoolCtl& ctl, lds_u16* ring, uint32_t 
     do {
       v = *e;
     } while (v == kRingEmpty || (uint32_t)(v >> kSlotBits) != want);
-    *e = kRingEmpty;
     id = v & ((1u << kSlotBits) - 1u);
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  R3D_LDS_ACQUIRE();
+  // (the entry is marked empty after the fence: nothing waits for this store, and the slot's state is
+  //  requested right behind it)
+  if (lane < k) ring[(pos + lane) & mask] = kRingEmpty;
   return k;
 }
 
@@ -133,27 +135,37 @@ __device__ __forceinline__ unsigned q_pop(PoolCtl& ctl, lds_u16* ring, uint32_t 
 // takes the tail tickets of queue q and publishes its count, so the whole distribution costs one
 // round of LDS atomics each way).
 __device__ __forceinline__ void q_push_all(PoolCtl& ctl, lds_u16* rings, uint32_t rcap, uint32_t log2cap,
-                                           unsigned lane, bool act, int dest, unsigned id) {
+                                           unsigned lane, bool act, int dest_, unsigned id) {
+  const int dest = act ? dest_ : -1;   // (no queue: the compares below then ARE the lane masks)
   unsigned long long m[Q_NUM];
   uint32_t kq = 0, rank = 0;
 #pragma unroll
   for (int q = 0; q < Q_NUM; q++) {
-    m[q] = __ballot(act && dest == q);
-    kq = (lane == (unsigned)q) ? (uint32_t)__popcll(m[q]) : kq;
+    m[q] = ballot(dest == q);
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(kq) : "s"((uint32_t)__popcll(m[q])), "n"(q));   // lane q: entries for queue q
     rank = (dest == q) ? rank_in(m[q]) : rank;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the slots' state before their numbers
+  // the tail tickets are asked for first; their round trip also sees the slots' state written (this
+  // wave's LDS accesses return in order), and the release fence sits where it is needed: between
+  // the state and the slot numbers
   uint32_t pos = 0;
   if (lane < Q_NUM && kq) pos = atomicAdd(&ctl.tail[lane], kq);
-  const uint32_t mine = (uint32_t)__shfl((int)pos, act ? dest : 0);
+  R3D_LDS_RELEASE();
+  // (each lane's queue's ticket through scalar registers: a cross-lane fetch would be one more LDS
+  //  round trip in a chain of them)
+  uint32_t t = rank;
+#pragma unroll
+  for (int q = 0; q < Q_NUM; q++) {
+    const uint32_t pq = (uint32_t)__builtin_amdgcn_readlane((int)pos, q);
+    t = (dest == q) ? rank + pq : t;
+  }
   if (act) {
-    const uint32_t t = mine + rank;
-    volatile lds_u16* e = rings + (uint32_t)dest * rcap + (t & (rcap - 1u));
+    volatile lds_u16* e = rings + (((uint32_t)dest << log2cap) | (t & (rcap - 1u)));   // (rcap = 1 << log2cap)
     while (*e != kRingEmpty) {
     }
     *e = (uint16_t)((lap_of(t, log2cap) << kSlotBits) | id);
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  R3D_LDS_RELEASE();
   if (lane < Q_NUM && kq) atomicAdd(&ctl.word[lane], kq);
 }
 
@@ -227,7 +239,7 @@ __device__ __forceinline__ uint32_t pool_collect_pairs(const KArgs& a, const Tab
         }
       }
     }
-    const unsigned long long hm = __ballot(hit);
+    const unsigned long long hm = ballot(hit);
     if (!hm) continue;
     n_hits += (uint32_t)__popcll(hm);
     if (TRACE) {   // per-history catch counts for the final records
@@ -378,13 +390,13 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   auto tally_n = [&](int slot, unsigned long long n) {
     if (lane == 0 && n) atomicAdd(&s_tally[slot], n);
   };
-  auto tally = [&](bool cond, int slot) { tally_n(slot, (unsigned long long)__popcll(__ballot(cond))); };
-  auto count = [&](bool cond) { return (uint32_t)__popcll(__ballot(cond)); };
+  auto tally = [&](bool cond, int slot) { tally_n(slot, (unsigned long long)__popcll(ballot(cond))); };
+  auto count = [&](bool cond) { return (uint32_t)__popcll(ballot(cond)); };
   // Report stream (diagnostic kernel only; include/r3d.h r3d_event): the lanes for which `cond`
   // holds append one record each; the wave claims the slots with one atomic.
   auto report = [&](bool cond, int tag, const Phonon& q, uint64_t hid) {
     if (!TRACE || !a.evlog || !((a.evlog_mask >> tag) & 1u)) return;
-    const unsigned long long m = __ballot(cond);
+    const unsigned long long m = ballot(cond);
     if (!m) return;
     const int first = __ffsll((long long)m) - 1;
     unsigned long long base = 0;
@@ -403,10 +415,10 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   };
   // A history ended (lanes with `died`): loss counters, report line, final record.
   auto finish = [&](bool died, int fate, int reason, const Phonon& p, uint64_t hid, uint32_t catches) {
-    if (!__any(died)) return;
+    if (!any_lane(died)) return;
     tally(died && fate == FATE_LOST, 0);
     tally(died && fate == FATE_TIMEOUT, 1);
-    if (__any(died && fate == FATE_INVALID)) {   // rare
+    if (any_lane(died && fate == FATE_INVALID)) {   // rare
       tally(died && fate == FATE_INVALID, 2);
 #pragma unroll
       for (int r = 0; r < R3D_INV_NUM; r++) tally(died && fate == FATE_INVALID && reason == r, 3 + r);
@@ -533,7 +545,8 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       // ---- fresh histories: ids from the global counter, source spray (events.cpp:111-124) ----
       unsigned long long base = 0;
       if (lane == 0) base = atomicAdd(a.next, (unsigned long long)k);
-      base = __shfl(base, 0);
+      base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), 0) << 32) |
+             (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
       const unsigned take = base >= a.n ? 0u : (a.n - base < k ? (unsigned)(a.n - base) : k);
       if (take < k && lane == 0)
         __hip_atomic_store(&ctl.word[kDrainedWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -599,7 +612,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         }
         n_iter += count(st.iterations != 0u), n_transfer += count(st.transfer != 0u), n_reflect += count(st.reflect != 0u);
         live = light;
-        const unsigned n_live = (unsigned)__popcll(__ballot(live));
+        const unsigned n_live = (unsigned)__popcll(ballot(live));
         // a full batch goes on while most of its lanes can (the others' slots are wanted by the
         // queues); a thin one -- the tail of a launch, where nobody waits for these lanes -- goes on
         // while any can: the longest histories are what a drain waits for, and a move in registers
@@ -657,7 +670,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #endif
       report(act, 3, p, hid);   // COL: the incident state
       tally_n(kEv + R3D_EV_COLLECT, k);
-      if (__any(k1 > k0)) {
+      if (any_lane(k1 > k0)) {
         const uint32_t hits = pool_collect_pairs<KIND, TRACE>(a, T, p, vel, k0, k1, LDS_SEIS ? lds_gitems : nullptr,
                                                               lane, catches, bc);
         tally_n(kEv + R3D_EV_CATCH, hits);

@@ -11,6 +11,15 @@
 namespace r3d {
 
 // ---------------------------------------------------- wave-level helpers ----
+// the lanes for which c holds, as the compare instruction leaves them (HIP's __ballot(int) goes
+// through a 0 / 1 value and a second compare)
+__device__ __forceinline__ unsigned long long ballot(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+__device__ __forceinline__ bool any_lane(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+// Ordering of this wave's LDS accesses as other waves of the workgroup see them (queue entries
+// against slot state).  Named for the LDS alone: the generic fence also waits for every outstanding
+// access to HBM -- a collection's bin updates, microseconds -- which no queue protocol depends on.
+#define R3D_LDS_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
+#define R3D_LDS_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
 // number of set bits of m below this lane
 __device__ __forceinline__ unsigned rank_in(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/disasm.sh KIND [extra hipcc flags] -- disassembly with source lines of the traversal kernels of one cell
 # kind (0 cylinder, 1 tetra, 2 sphere): /tmp/r3d_disasm_K/dev.lst (+ per-kernel files k_<mangled>.lst); built with
-# the kind's own flags of the Makefile (HIPFLAGS_CYL / _TET / _SPH).
+# the Makefile's flags (HIPFLAGS and the kind's own HIPFLAGS_CYL / _TET / _SPH).
 set -e
 kind=$1; shift
 out=/tmp/r3d_disasm_$kind; mkdir -p $out
@@ -9,11 +9,10 @@ case $kind in 0) tag=CYL;; 1) tag=TET;; *) tag=SPH;; esac
 kflags=$(make -s -f - print <<MK
 include Makefile
 print:
-	@echo \$(HIPFLAGS_$tag)
+	@echo \$(HIPFLAGS) \$(HIPFLAGS_$tag)
 MK
 )
-/opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-bitwise-instead-of-logical \
-   -mllvm -disable-machine-licm $kflags -gline-tables-only -DR3D_KIND=$kind "$@" -c -o $out/unit.o \
+/opt/rocm/bin/hipcc $kflags -gline-tables-only -DR3D_KIND=$kind "$@" -c -o $out/unit.o \
    radiative3d_amd/csrc/r3d_kernels_kind.hip
 L=/opt/rocm/lib/llvm/bin
 $L/llvm-objcopy -O binary --only-section=.hip_fatbin $out/unit.o $out/fat.bin
