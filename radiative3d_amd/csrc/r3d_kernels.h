@@ -25,15 +25,13 @@ constexpr int kPoolBlock = R3D_POOL_BLOCK;
 
 enum { Q_MOVE = 0, Q_COLLECT = 1, Q_RT = 2, Q_SCATTER = 3, Q_FREE = 4, Q_NUM = 5 };
 
-// One history in flight = one slot number; its state is spread over field-major arrays in LDS
-// (fd[field][slot] doubles, fu[field][slot] words), so that a batch of neighbouring slot numbers
-// reads and writes each field without bank conflicts (slot-major 128-byte records measured 77 % of
+// One history in flight = one slot number; its state is eight 16-byte records (twelve doubles, eight
+// words: r3d_pool.h), each kind of record an array over the slots in LDS, so that a batch of slot
+// numbers reads and writes a record across the banks (slot-major 128-byte blocks measured 77 % of
 // the LDS cycles as conflicts).  meta: bit 0 ray type | bits 1-3 pending face + 1 (0: none) |
 // bits 8-15 that face's flags | bits 16-18 the queue the slot is in (for carry-over).
-enum { FD_T, FD_PATH, FD_RECENT, FD_LAMP, FD_LX, FD_LY, FD_LZ, FD_DX, FD_DY, FD_DZ, FD_PC, FD_PS, FD_NUM };
-enum { FU_CELL, FU_MOVES, FU_K, FU_META, FU_IDLO, FU_IDHI, FU_CATCH, FU_NBR, FU_NUM };   // NBR: the cell behind the pending face
-constexpr size_t kSlotBytes = FD_NUM * sizeof(double) + FU_NUM * sizeof(uint32_t);   // 128
-constexpr uint32_t kSlotStride = 1024;   // entries per field array of the pool (>= the slots in circulation)
+constexpr size_t kSlotBytes = 128;
+constexpr uint32_t kSlotStride = 1024;   // entries per record array of the pool (>= the slots in circulation)
 
 // bytes of one bin accumulator of the per-workgroup table (BinCache, r3d_wave.h)
 constexpr size_t kAccEntryBytes = 5 * sizeof(double) + 3 * sizeof(uint32_t);
