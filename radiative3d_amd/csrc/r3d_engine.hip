@@ -392,7 +392,7 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
     // heads are staged in LDS, then a minimum of bin accumulators, and everything else goes to
     // the pool: S slots of 124 B (field-major) plus the rings of 16-bit slot numbers.
     auto align16 = [](size_t x) { return (x + 15) & ~size_t(15); };
-    const size_t kLds = 160 * 1024, kStatic = 1024;   // static: queue control words, tallies
+    const size_t kLds = 160 * 1024, kStatic = 512;   // static: queue control words, tallies (208 bytes)
     const size_t head_bytes = (size_t)m->n_scatterers * sizeof(ScatHead);
     const size_t scat_bytes = head_bytes + (size_t)m->n_scatterers * sizeof(ScatPtrs);   // heads + table addresses
     // R3D_FORCE_RES=1 / 2 (developer and test switch): run the kernel variant that keeps the cell

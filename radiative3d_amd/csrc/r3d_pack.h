@@ -262,20 +262,23 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm, bool for_engine
 
   // ---- cells ----
   if (m.cell_kind == R3D_CELL_CYLINDER) {
-    pm.cyl.resize(m.n_cells);
+    pm.cyl.resize((size_t)2 * m.n_cells);   // one record per cell and ray type (r3d_tables.h)
     for (int i = 0; i < m.n_cells; i++) {
       const r3d_cell& c = m.cells[i];
-      CellCyl& d = pm.cyl[i];
-      std::memset(&d, 0, sizeof d);
-      for (int t = 0; t < 2; t++) d.v[t] = c.vel_c[t], d.att[t] = kPiF / c.q[t];
-      d.rho = c.rho_c;
-      for (int f = 0; f < 2; f++) {
-        for (int k = 0; k < 3; k++) d.n[f][k] = c.faces[f].normal[k];
-        d.d[f] = dot3(c.faces[f].normal, c.faces[f].point);
-        d.nbr[f] = (c.faces[f].flags & R3D_FACE_ADJOIN) ? c.faces[f].neighbor : -1;
+      const uint32_t flags = pack_flags_classified(m, i);
+      for (int t = 0; t < 2; t++) {
+        CellCyl& d = pm.cyl[(size_t)2 * i + t];
+        std::memset(&d, 0, sizeof d);
+        d.v = c.vel_c[t], d.att = kPiF / c.q[t];
+        d.rho = c.rho_c;
+        for (int f = 0; f < 2; f++) {
+          for (int k = 0; k < 3; k++) d.n[f][k] = c.faces[f].normal[k];
+          d.d[f] = dot3(c.faces[f].normal, c.faces[f].point);
+          d.nbr[f] = (c.faces[f].flags & R3D_FACE_ADJOIN) ? c.faces[f].neighbor : -1;
+        }
+        d.flags = flags;
+        d.scat = c.scatterer;
       }
-      d.flags = pack_flags_classified(m, i);
-      d.scat = c.scatterer;
     }
     a.cyl_radius2 = m.cells[0].faces[2].radius * m.cells[0].faces[2].radius;
     a.cells = pm.cyl.data();
@@ -306,22 +309,23 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm, bool for_engine
     a.cells = pm.tet.data();
     a.rho = pm.rho.data();
   } else {
-    pm.sph.resize(m.n_cells);
+    pm.sph.resize((size_t)2 * m.n_cells);
     for (int i = 0; i < m.n_cells; i++) {
       const r3d_cell& c = m.cells[i];
-      CellSph& d = pm.sph[i];
-      std::memset(&d, 0, sizeof d);
+      const uint32_t flags = pack_flags_classified(m, i);
       for (int t = 0; t < 2; t++) {
-        d.a[t] = c.vel_a[t], d.c[t] = c.vel_c[t], d.zero_rad2[t] = c.zero_rad2[t];
-        d.att[t] = kPiF / c.q[t];
+        CellSph& d = pm.sph[(size_t)2 * i + t];
+        std::memset(&d, 0, sizeof d);
+        d.a = c.vel_a[t], d.c = c.vel_c[t], d.zero_rad2 = c.zero_rad2[t];
+        d.att = kPiF / c.q[t];
+        d.rho_a = c.rho_a, d.rho_c = c.rho_c;
+        for (int f = 0; f < 2; f++) {
+          d.radius[f] = c.faces[f].radius;
+          d.nbr[f] = (c.faces[f].flags & R3D_FACE_ADJOIN) ? c.faces[f].neighbor : -1;
+        }
+        d.flags = flags;
+        d.scat = c.scatterer;
       }
-      d.rho_a = c.rho_a, d.rho_c = c.rho_c;
-      for (int f = 0; f < 2; f++) {
-        d.radius[f] = c.faces[f].radius;
-        d.nbr[f] = (c.faces[f].flags & R3D_FACE_ADJOIN) ? c.faces[f].neighbor : -1;
-      }
-      d.flags = pack_flags_classified(m, i);
-      d.scat = c.scatterer;
     }
     a.cells = pm.sph.data();
   }

@@ -108,10 +108,10 @@ R3D_HD Exit cyl_exit(const CellCyl& c, double wall_rad2, const Phonon& p) {
 // reference RCUCylinder::AdvanceLength + Phonon::Move, media.cpp:208-222,
 // phonons.cpp:62-70
 R3D_HD void cyl_advance(const CellCyl& c, Phonon& p, double len) {
-  double time = len * frcp(c.v[p.type]);
+  double time = len * frcp(c.v);
   p.path += len, p.t += time, p.recent += time;
   p.loc = p.loc + len * p.dir;
-  p.lamp += c.att[p.type] * time;
+  p.lamp += c.att * time;
   p.moves += 1;
 }
 
@@ -314,8 +314,7 @@ R3D_HD V3 down_at(const double ec[3], V3 loc) {  // ECS.GetDown, ecs.cpp:147-167
 }
 R3D_HD SphArc sph_arc(const CellSph& c, const double ec[3], const Phonon& p) {
   SphArc A;
-  const int t = p.type;
-  A.straight = (c.a[t] == 0);
+  A.straight = (c.a == 0);
   if (A.straight) {
     A.radius = pos_inf(), A.rad2 = pos_inf(), A.S2 = 0, A.inv_TwoSQ = 0, A.CotZetaBy2 = 0;
     A.timeCoef = 0, A.s0 = 0, A.c0 = 1, A.center = v3(0, 0, 0), A.u1 = p.dir, A.u3 = v3(0, 0, 0);
@@ -330,11 +329,11 @@ R3D_HD SphArc sph_arc(const CellSph& c, const double ec[3], const Phonon& p) {
   double r2 = mag2(p.loc);
   // (the quotients below whose operands are plain positive numbers use frcp; the one whose zero
   //  divisor means "vertical ray, infinite radius" stays a division)
-  const double G = sini * fsqrt(r2) * frcp(c.c[t] + c.a[t] * r2);
-  const double TwoGA = 2. * G * c.a[t];
-  const double urad = 1. - (2. * TwoGA * G * c.c[t]);
+  const double G = sini * fsqrt(r2) * frcp(c.c + c.a * r2);
+  const double TwoGA = 2. * G * c.a;
+  const double urad = 1. - (2. * TwoGA * G * c.c);
   double bottom = (urad > 1) ? (1. - fsqrt(urad)) * frcp(TwoGA) : 0;
-  A.radius = (c.zero_rad2[t] / bottom - bottom) / 2.0;
+  A.radius = (c.zero_rad2 / bottom - bottom) / 2.0;
   A.rad2 = A.radius * A.radius;
   A.center = p.loc + ((A.radius * cosi) * w1 + (-A.radius * sini) * w3);
   A.u3 = down_at(ec, A.center);
@@ -347,10 +346,10 @@ R3D_HD SphArc sph_arc(const CellSph& c, const double ec[3], const Phonon& p) {
   A.S2 = mag2(A.center);
   double S = fsqrt(A.S2);
   A.inv_TwoSQ = frcp(2 * S * A.radius);
-  double cz = (A.S2 + A.radius * A.radius - c.zero_rad2[t]) * A.inv_TwoSQ;
+  double cz = (A.S2 + A.radius * A.radius - c.zero_rad2) * A.inv_TwoSQ;
   double isz = frsqrt(1 - cz * cz);     // 1 / sin zeta
   A.CotZetaBy2 = (1 + cz) * isz;
-  A.timeCoef = -isz * frcp(c.a[t] * S);
+  A.timeCoef = -isz * frcp(c.a * S);
   V3 cl = p.loc - A.center;
   const double y = dot(A.u1, cl), x = dot(A.u3, cl);   // the reference's a0 = atan2(y, x)
   const double h2 = x * x + y * y;
@@ -414,14 +413,13 @@ R3D_HD SphExit sph_exit(const CellSph& c, const SphArc& A, const Phonon& p) {
 // reference SphereShell::AdvanceLength_* (media.cpp:877-957) + Phonon::Move.  (s1, c1): sine /
 // cosine of the end angle on the arc (ignored for straight rays).
 R3D_HD void sph_advance(const CellSph& c, const SphArc& A, Phonon& p, double len, double s1, double c1) {
-  const int t = p.type;
   double time, att_time;
   if (A.straight || A.radius == pos_inf()) {
     V3 nl = p.loc + len * p.dir;
-    time = att_time = len / c.c[t];
+    time = att_time = len / c.c;
     if (!A.straight) {  // vertical ray in a graded shell: analytic time, straight-line attenuation
       double r0 = mag(p.loc), r1 = mag(nl);
-      double sqnac = sqrt(-c.a[t] * c.c[t]), sqnaoc = sqrt(-c.a[t] / c.c[t]);
+      double sqnac = sqrt(-c.a * c.c), sqnaoc = sqrt(-c.a / c.c);
       time = fabs((atanh(sqnaoc * r1) - atanh(sqnaoc * r0)) / sqnac);
     }
     p.loc = nl;
@@ -440,7 +438,7 @@ R3D_HD void sph_advance(const CellSph& c, const SphArc& A, Phonon& p, double len
     p.dir = nd;
   }
   p.path += len, p.t += time, p.recent += time;
-  p.lamp += c.att[t] * att_time;
+  p.lamp += c.att * att_time;
   p.moves += 1;
 }
 

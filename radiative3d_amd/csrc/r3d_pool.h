@@ -303,7 +303,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       const unsigned long long* s = reinterpret_cast<const unsigned long long*>(src);
       for (size_t i = tid; i < bytes / 8; i += kPoolBlock) d[i] = s[i];
     };
-    if (LDS_CELLS) copy_words(smem + a.lds_cells_off, a.cells, (size_t)a.n_cells * sizeof(Cell));
+    if (LDS_CELLS) copy_words(smem + a.lds_cells_off, a.cells, (size_t)2 * a.n_cells * sizeof(Cell));   // (a record per cell and ray type)
     if (LDS_SCAT) {
       copy_words(smem + a.lds_scat_off, a.scat_head, (size_t)a.n_scat * sizeof(ScatHead));
       copy_words(smem + a.lds_scatptr_off, a.scat_ptrs, (size_t)a.n_scat * sizeof(ScatPtrs));

@@ -51,17 +51,17 @@ struct Tables {
 };
 
 // ---- per-kind property lookups --------------------------------------------
-// The record a phonon of ray type `type` in cell `cell` works from: layered and spherical cells have
-// one record, tetra cells one per ray type (r3d_tables.h CellTet).
+// The record a phonon of ray type `type` in cell `cell` works from (one per cell and ray type:
+// r3d_tables.h).  Where a record has been copied into registers, its small arrays are picked from
+// by selects: an index would make the copy a table in scratch memory.
 template <int KIND>
 R3D_HD const typename CellOf<KIND>::type& cell_rec(const Tables<KIND>& T, int cell, int type) {
-  if constexpr (KIND == CELL_TET) return T.cells[2 * cell + type];
-  else return T.cells[cell];
+  return T.cells[2 * cell + type];
 }
-// velocity of ray type t at p, from a record that holds it (tetra: the record of type t)
-R3D_HD double cell_velocity(const CellCyl& c, V3, int t) { return c.v[t]; }
+// velocity of its ray type at p, from the record that holds it
+R3D_HD double cell_velocity(const CellCyl& c, V3, int) { return c.v; }
 R3D_HD double cell_velocity(const CellTet& c, V3 p, int) { return dot(p, v3(c.g)) + c.v0; }
-R3D_HD double cell_velocity(const CellSph& c, V3 p, int t) { return c.c[t] + c.a[t] * mag2(p); }
+R3D_HD double cell_velocity(const CellSph& c, V3 p, int) { return c.c + c.a * mag2(p); }
 template <int KIND>
 R3D_HD double velocity_in(const Tables<KIND>& T, int cell, V3 p, int t) {
   return cell_velocity(cell_rec<KIND>(T, cell, t), p, t);
@@ -74,15 +74,17 @@ R3D_HD double cell_density(const KArgs& a, const CellTet&, int idx, V3 p) {
 }
 R3D_HD double cell_density(const KArgs&, const CellSph& c, int, V3 p) { return c.rho_c + c.rho_a * mag2(p); }
 
-R3D_HD V3 cell_face_normal(const CellCyl& c, int f, V3) { return v3(c.n[f]); }
+R3D_HD V3 cell_face_normal(const CellCyl& c, int f, V3) {
+  return f == 0 ? v3(c.n[0]) : v3(c.n[1]);   // (the wall, face 2, is never asked for: a phonon is lost there)
+}
 R3D_HD V3 cell_face_normal(const CellTet& c, int f, V3) { return v3(c.n[f]); }
 R3D_HD V3 cell_face_normal(const CellSph& c, int f, V3 loc) {  // media_cellface.cpp:624-627
   V3 u = unit_else(loc, v3(0, 0, 1));
-  return c.radius[f] > 0 ? u : -u;
+  return (f == 0 ? c.radius[0] : c.radius[1]) > 0 ? u : -u;
 }
-R3D_HD int cell_neighbor(const CellCyl& c, int f) { return f < 2 ? c.nbr[f] : -1; }
+R3D_HD int cell_neighbor(const CellCyl& c, int f) { return f == 0 ? c.nbr[0] : f == 1 ? c.nbr[1] : -1; }
 R3D_HD int cell_neighbor(const CellTet& c, int f) { return tet_link_neighbor(c.link[f]); }
-R3D_HD int cell_neighbor(const CellSph& c, int f) { return c.nbr[f]; }
+R3D_HD int cell_neighbor(const CellSph& c, int f) { return f == 0 ? c.nbr[0] : c.nbr[1]; }
 R3D_HD uint32_t cell_face_flags(const CellCyl& c, int f) { return face_flags(c.flags, f); }
 R3D_HD uint32_t cell_face_flags(const CellTet& c, int f) { return tet_link_flags(c.link[f]); }
 R3D_HD uint32_t cell_face_flags(const CellSph& c, int f) { return face_flags(c.flags, f); }
@@ -216,14 +218,15 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
     p.recent = 0;
   }
   st.iterations++;
-  // Tetra records come from L2, a round trip of a microsecond under load.  The WHOLE record is read
-  // into registers here, ahead of the move's random number: the fence below keeps later code from
-  // moving up, so loads written at their uses -- inside the boundary search, and the links and the
-  // attenuation constant at the very end of the move -- would be issued after the draw and, the late
-  // ones, cost the wave a second and a third round trip.  (Layered and spherical records sit in LDS.)
-  using CellHere = typename std::conditional<KIND == CELL_TET, const Cell, const Cell&>::type;
+  // The WHOLE cell record is read into registers here, ahead of the move's random number: the fence
+  // below keeps later code from moving up, so loads written at their uses -- inside the boundary
+  // search, and the links and the attenuation constant at the very end of the move -- would be
+  // issued after the draw and each cost the wave a round trip of its own: a microsecond under load
+  // for a tetra record (L2), a few hundred cycles for a layered or spherical one (LDS, behind the
+  // other waves' slot traffic), eight times a move.
+  using CellHere = const Cell;
   CellHere c = cell_rec<KIND>(T, p.cell, p.type);
-  if constexpr (KIND == CELL_TET) R3D_SCHED_FENCE();   // (the loads above, THEN the draw: left to itself the scheduler puts the draw first)
+  R3D_SCHED_FENCE();   // (the loads above, THEN the draw: left to itself the scheduler puts the draw first)
   // The move's one uniform (for the free path, below) is drawn here: it depends on nothing, and
   // its hundred integer instructions fill the wait for the cell record, which everything else
   // in the move needs.
@@ -234,6 +237,14 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
   asm volatile("" : "+v"(u_free));
 #endif
   R3D_SCHED_FENCE();
+  // (the mean free path hangs on the record's scatterer index: for records in LDS it is asked for as
+  //  soon as that is in, not where the free path is formed, a boundary search later; the tetra
+  //  kernel has no register to spare for it across the search: +2 % with two spilled)
+  double mfp = 0;
+  if constexpr (KIND != CELL_TET) {
+    mfp = T.scat_head[cell_scat(c)].mfp[p.type];
+    R3D_SCHED_FENCE();
+  }
 
   // --- where does the ray leave the cell? (phonons.cpp:590)
   Exit e;
@@ -259,7 +270,7 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
   //     (scatterers.cpp:297-307, phonons.cpp:601)
   // scatlen = -ln(u) mfp.  Since -ln(u) >= 1 - u, (1-u) mfp >= len already rules a scatter
   // out, and the logarithm is only taken for the lanes that pass this screen.
-  const double mfp = T.scat_head[cell_scat(c)].mfp[p.type];
+  if constexpr (KIND == CELL_TET) mfp = T.scat_head[cell_scat(c)].mfp[p.type];
   double scatlen = pos_inf();
   if (!((1.0 - u_free) * mfp >= e.len)) scatlen = -log_lean(u_free) * mfp;
   const bool scatters = scatlen < e.len;

@@ -29,18 +29,22 @@ enum : uint32_t { F_COLLECT = 1u, F_REFLECT = 2u, F_ADJOIN = 4u, F_DISCON = 8u,
                   F_STEP = 32u };   // always exceeds it: Snell bend
 
 // ---- cells -----------------------------------------------------------------
+// EVERY KIND HAS ONE RECORD PER CELL AND RAY TYPE (index 2 * cell + type), holding what a move of
+// that type reads and nothing of the other type: a move copies its record into registers in one
+// go of 16-byte loads (r3d_step.h step_move), where fields indexed by the ray type would be a table
+// in scratch memory -- or loads left at their uses, each a round trip of its own.
 // Layered cylinder cell (reference RCUCylinder, media.hpp:312-331): uniform
 // velocity, top and bottom planes; the lateral wall radius is a model constant.
 struct alignas(16) CellCyl {
-  double v[2];        // Vp, Vs
-  double att[2];      // -pi f / Q
-  double rho;
+  double v, att;      // velocity of this ray type; -pi f / Q
   double n[2][3];     // outward unit normals of top, bottom
   double d[2];        // plane offsets n . point
   int32_t nbr[2];
   uint32_t flags;     // byte f = flags of face f
   int32_t scat;
+  double rho, pad_;
 };
+static_assert(sizeof(CellCyl) == 112, "seven 16-byte loads");
 
 // Tetrahedral cell with linear velocity (reference Tetra, media.hpp:400-408): ONE RECORD PER CELL
 // AND RAY TYPE (index 2 * cell + type), three 64-byte lines holding everything a move of that type
@@ -73,15 +77,16 @@ R3D_TBL_HD inline int tet_link_scat(const uint32_t link[4]) {
   return (int)((link[0] >> 28) | ((link[1] >> 28) << 4) | ((link[2] >> 28) << 8) | ((link[3] >> 28) << 12));
 }
 
-// Spherical shell, v(r) = a r^2 + c (reference SphereShell, media.hpp:467-478).
+// Spherical shell, v(r) = a r^2 + c (reference SphereShell, media.hpp:467-478); per ray type, as above.
 struct alignas(16) CellSph {
-  double a[2], c[2], zero_rad2[2], att[2];
-  double rho_a, rho_c;
+  double a, c, zero_rad2, att;
   double radius[2];   // signed: +top (outward normal), -bottom (inward)
   int32_t nbr[2];
   uint32_t flags;
   int32_t scat;
+  double rho_a, rho_c;
 };
+static_assert(sizeof(CellSph) == 80, "five 16-byte loads");
 
 struct RhoLin {       // density side table for tetra cells
   double g[3], c;
