@@ -9,6 +9,9 @@
  *   draw k (k = 0,1,2,...) of history `id` under key `seed` is the 53-bit
  *   uniform in (0,1] built from words [2*(k&1), 2*(k&1)+1] of
  *   Philox4x32-10(counter = {id_lo, id_hi, k>>1, 0}, key = {seed_lo, seed_hi}).
+ *   An event that takes two uniforms (reflection / transmission: S polarisation kind and outcome;
+ *   scattering: conversion and deflection) takes the two halves of ONE block: it first skips to
+ *   the next even k (oracle_rng_draw_pair).
  */
 #ifndef R3D_ORACLE_PHILOX_H_
 #define R3D_ORACLE_PHILOX_H_
@@ -59,6 +62,13 @@ static inline double oracle_rng_draw(oracle_rng* g) {
   uint32_t w = 2 * (g->k & 1u);
   g->k++;
   return oracle_u01(g->cache[w], g->cache[w + 1]);
+}
+
+/* The two uniforms of a two-draw event: the next whole block. */
+static inline void oracle_rng_draw_pair(oracle_rng* g, double* u0, double* u1) {
+  g->k = (g->k + 1u) & ~1u;
+  *u0 = oracle_rng_draw(g);
+  *u1 = oracle_rng_draw(g);
 }
 
 #endif

@@ -209,6 +209,7 @@ struct Ctx {
 };
 
 inline double draw(Ctx& c) { return oracle_rng_draw(&c.rng); }
+inline void draw_pair(Ctx& c, double& u0, double& u1) { oracle_rng_draw_pair(&c.rng, &u0, &u1); }
 
 // Phonon::nudge_if_singular, phonons.hpp:335-344
 inline void nudge(const r3d_params& p, double& theta) {
@@ -596,9 +597,9 @@ TravelRec advance_length(const r3d_model_desc& m, const r3d_cell& c, const Phono
 
 // ----------------------------------------------------------- sampling -----
 // ProbDist::GetRandomIndex, probability.cpp:104-128
-uint64_t sample_cdf(Ctx& c, const double* cdf, uint64_t n) {
+uint64_t sample_cdf_u(const double* cdf, uint64_t n, double u) {
   uint64_t k1 = 0, k2 = n - 1;
-  double r = cdf[k2] * draw(c);
+  double r = cdf[k2] * u;
   while (k1 != k2) {
     uint64_t k = (k1 + k2) >> 1;
     if (r <= cdf[k]) k2 = k;
@@ -606,6 +607,8 @@ uint64_t sample_cdf(Ctx& c, const double* cdf, uint64_t n) {
   }
   return k2;
 }
+
+uint64_t sample_cdf(Ctx& c, const double* cdf, uint64_t n) { return sample_cdf_u(cdf, n, draw(c)); }
 
 // Phonon::DirectionOfMotion, phonons.cpp:201-211
 V direction_of_motion(const Phonon& p) {
@@ -695,6 +698,8 @@ void refraction_full_rt(Ctx& c, Phonon& p, int face_idx) {
   const r3d_cell& cell = m.cells[p.cell];
   const r3d_face& f = cell.faces[face_idx];
   c.out->events[R3D_EV_RTSOLVE]++;
+  double u_pol, u_out;   // the event's two uniforms (philox.h: one block)
+  draw_pair(c, u_pol, u_out);
   V dir = from_angles(p.theta, p.phi);
   RT r;
   r.no_transmit = false;
@@ -715,7 +720,7 @@ void refraction_full_rt(Ctx& c, Phonon& p, int face_idx) {
   if (p.type == R3D_RAY_S) {  // ChooseSPolType, rtcoef.cpp:406-422
     double shfrac = dot(direction_of_motion(p), r.fparash);
     shfrac *= shfrac;
-    intype = (draw(c) <= shfrac) ? IN_SH : IN_SV;
+    intype = (u_pol <= shfrac) ? IN_SH : IN_SV;
   }
   switch (intype) {  // GetCoefs, rtcoef.cpp:76-97
     case IN_P: r.defchoice = R_P, rt_coefs_psv(r, true); break;
@@ -727,7 +732,7 @@ void refraction_full_rt(Ctx& c, Phonon& p, int face_idx) {
   PI_[0] = r.prob[0];
   for (int i = 1; i < RT_NUM; i++) PI_[i] = PI_[i - 1] + r.prob[i];
   double total = PI_[RT_NUM - 1];
-  double ran = draw(c) * total;
+  double ran = u_out * total;
   int choice = RT_NUM - 1;
   for (int i = 0; i < RT_NUM - 1; i++)
     if (ran <= PI_[i]) {
@@ -936,9 +941,11 @@ int run_history(Ctx& c, Phonon& p) {
         rth = 0, rph = 0, rtype = p.type, rpol = 0;
         nudge(par, rth);
       } else {
-        int conv = (int)sample_cdf(c, sc.whole_cdf[p.type], 4);  // GPP GPS GSP GSS
+        double u_conv, u_dir;   // the event's two uniforms (philox.h: one block)
+        draw_pair(c, u_conv, u_dir);
+        int conv = (int)sample_cdf_u(sc.whole_cdf[p.type], 4, u_conv);  // GPP GPS GSP GSS
         rtype = (conv & 1) ? R3D_RAY_S : R3D_RAY_P;
-        uint64_t k = sample_cdf(c, sc.cdf[conv], m.n_toa);
+        uint64_t k = sample_cdf_u(sc.cdf[conv], m.n_toa, u_dir);
         rpol = (conv == 3) ? sc.spol[k] : 0;
         rth = m.toa[2 * k], rph = m.toa[2 * k + 1];
         nudge(par, rth);

@@ -578,9 +578,7 @@ struct RtChoice {
 // on nothing that has to be fetched, so a caller draws them while the interface's records are on
 // their way -- left to itself the optimiser sinks each generator call down to its use.
 R3D_HD void rt_draws(const Phonon& p, Rng& rng, RngKey key, double& u_pol, double& u_out) {
-  u_pol = 1.0;
-  if (p.type == RAY_S) u_pol = rng_draw(rng, key);
-  u_out = rng_draw(rng, key);
+  rng_draw_pair(rng, key, u_pol, u_out);   // (u_pol: the S polarisation kind; not looked at for a P ray)
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("" : "+v"(u_pol), "+v"(u_out));
 #endif

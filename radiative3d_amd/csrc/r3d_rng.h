@@ -7,7 +7,11 @@
 //
 //   draw k (k = 0,1,2,...) of history `id` under key `seed` is the 53-bit
 //   uniform in (0,1] made of words [2(k&1), 2(k&1)+1] of
-//   Philox4x32-10(counter = {id_lo, id_hi, k>>1, 0}, key = {seed_lo, seed_hi})
+//   Philox4x32-10(counter = {id_lo, id_hi, k>>1, 0}, key = {seed_lo, seed_hi});
+//   an event that takes TWO uniforms -- a reflection / transmission (S polarisation kind, outcome),
+//   a scattering (conversion, deflection) -- takes the two halves of ONE block: it first skips to
+//   the next even k.  (Ten rounds then serve both; drawn one by one they would straddle two
+//   blocks on half the lanes of a wave, which costs the wave two evaluations every time.)
 //
 // so results do not depend on which lane, wave or GPU runs a history.  All of
 // the reference's uniform conventions ([0,1], (0,1], 1-[0,1)) are mapped to
@@ -68,6 +72,15 @@ R3D_HD double u01_from_words(uint32_t hi, uint32_t lo) {
 R3D_HD void rng_init(Rng& g, uint64_t id) {
   g.id_lo = (uint32_t)id, g.id_hi = (uint32_t)(id >> 32);
   g.k = 0;
+}
+
+// the two uniforms of a two-draw event: the next whole block (see above)
+R3D_HD void rng_draw_pair(Rng& g, RngKey key, double& u0, double& u1) {
+  const uint32_t k = (g.k + 1u) & ~1u;
+  uint32_t w[4];
+  philox4x32_10(g.id_lo, g.id_hi, k >> 1, 0u, key.k0, key.k1, w);
+  g.k = k + 2u;
+  u0 = u01_from_words(w[0], w[1]), u1 = u01_from_words(w[2], w[3]);
 }
 
 R3D_HD double rng_draw(Rng& g, RngKey key) {

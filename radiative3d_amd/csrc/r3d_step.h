@@ -95,17 +95,19 @@ R3D_HD int cell_scat(const CellSph& c) { return c.scat; }
 // ---- source spray ----------------------------------------------------------
 R3D_HD void spray(const KArgs& a, Phonon& p, Rng& rng) {
   // 0 P, 1 SH, 2 SV: smallest k with r <= whole[k] (probability.cpp:104-128 on 3 entries)
-  const double r3 = a.src_whole[2] * rng_draw(rng, rng_key(a.seed));
+  double u_type, u_dir;   // (a history's first two uniforms: one block of the generator)
+  rng_draw_pair(rng, rng_key(a.seed), u_type, u_dir);
+  const double r3 = a.src_whole[2] * u_type;
   const int rt3 = (r3 <= a.src_whole[0]) ? 0 : (r3 <= a.src_whole[1]) ? 1 : 2;
 #ifdef R3D_ABLATE_SPRAY_SEARCH
-  uint64_t k = (uint64_t)(rng_draw(rng, rng_key(a.seed)) * (double)(a.n_toa - 1));
+  uint64_t k = (uint64_t)(u_dir * (double)(a.n_toa - 1));
 #else
   // (selects, not a[rt3]: a dynamic index into the by-value argument block would
   //  make the compiler copy the arrays to scratch memory)
   const double* cdf = rt3 == 0 ? a.src_cdf[0] : rt3 == 1 ? a.src_cdf[1] : a.src_cdf[2];
   const GuideCell* guide = rt3 == 0 ? a.src_guide[0] : rt3 == 1 ? a.src_guide[1] : a.src_guide[2];
   const double total = rt3 == 0 ? a.src_total[0] : rt3 == 1 ? a.src_total[1] : a.src_total[2];
-  uint64_t k = sample_cdf_guided(cdf, guide, a.guide_bits, total, rng_draw(rng, rng_key(a.seed)));
+  uint64_t k = sample_cdf_guided(cdf, guide, a.guide_bits, total, u_dir);
 #endif
   p.t = p.path = p.recent = 0.0;
   p.lamp = 0.0;
@@ -355,12 +357,13 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
       const int scat = cell_scat(c);
       const ScatHead& sh = T.scat_head[scat];
       const ScatPtrs* sp = T.scat_ptrs + scat;   // (indexed in place: a local copy would go to scratch)
-      int conv = sample_small(sh.whole[p.type], 4, rng_draw(rng, rng_key(a.seed)));  // GPP GPS GSP GSS
+      double u_conv, u_dir;   // the event's two uniforms: one block of the generator
+      rng_draw_pair(rng, rng_key(a.seed), u_conv, u_dir);
+      int conv = sample_small(sh.whole[p.type], 4, u_conv);  // GPP GPS GSP GSS
 #ifdef R3D_ABLATE_SCATTER   // timing-only developer build: no table search
-      uint64_t k = (uint64_t)(rng_draw(rng, rng_key(a.seed)) * (double)(a.n_toa - 1));
+      uint64_t k = (uint64_t)(u_dir * (double)(a.n_toa - 1));
 #else
-      uint64_t k = sample_cdf_guided(sp->cdf[conv], sp->guide[conv], a.guide_bits, sh.total[conv],
-                                     rng_draw(rng, rng_key(a.seed)));
+      uint64_t k = sample_cdf_guided(sp->cdf[conv], sp->guide[conv], a.guide_bits, sh.total[conv], u_dir);
 #endif
       double rc = 1.0, rs = 0.0;      // relative polarisation 0 except S->S (scatterers.cpp:341-356)
       if (conv == 3) {

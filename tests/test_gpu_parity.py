@@ -236,13 +236,16 @@ def test_full_size_crustpinch_properties():
     assert abs(a.events["catch"] / n - loss["catches_per_history"]) <= tol
     # a disjoint id range is an independent sample: per-bin arrival counts are (compound)
     # Poisson -- a reverberating phonon can be caught more than once per bin -- so their
-    # normalised differences look normal with a spread a little above 1; total energy agrees to ~1 %
+    # normalised differences look normal with a spread a little above 1; total energy agrees to ~1 %.
+    # (Their MEAN is not that of 21 000 independent bins: a few reverberating histories move a
+    #  sample's total catches by +-0.5 %, all bins together -- twelve disjoint pairs of 1e7 gave means
+    #  between -0.18 and +0.09 whatever the kernel.)
     b = e.run(n, first_id=n)
     na, nb = a.counts.astype(float), b.counts.astype(float)
     sel = (na + nb) >= 50
     assert sel.sum() > 5000
     z = (na[sel] - nb[sel]) / np.sqrt(na[sel] + nb[sel])
-    assert abs(z.mean()) < 0.05 and 0.9 < z.std() < 1.5
+    assert abs(z.mean()) < 0.4 and 0.9 < z.std() < 1.5
     assert a.energy.sum() == pytest.approx(b.energy.sum(), rel=0.02)
     # small-sample oracle comparison on the big tables too: diagnostic and production kernels
     check_against_oracle(e, 3000, first_id=123456789)
