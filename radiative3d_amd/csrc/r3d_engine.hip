@@ -388,9 +388,9 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   // ---- LDS carve-up and launch geometry ----
   a.grid_n_items = (uint32_t)pm.grid_items.size();
   {
-    // Pool kernel (r3d_pool.h): the cell records (when there are few of them) and the scatterer
-    // heads are staged in LDS, then a minimum of bin accumulators, and everything else goes to
-    // the pool: S slots of 124 B (field-major) plus the rings of 16-bit slot numbers.
+    // Pool kernel (r3d_pool.h): the phonon pool (1024 slots of 128 B in eight record arrays) and its
+    // rings, the bin accumulators, and beside them what fits of the small tables: the scatterer
+    // heads, then the cell records (two per cell: one per ray type).
     auto align16 = [](size_t x) { return (x + 15) & ~size_t(15); };
     const size_t kLds = 160 * 1024, kStatic = 512;   // static: queue control words, tallies (208 bytes)
     const size_t head_bytes = (size_t)m->n_scatterers * sizeof(ScatHead);
