@@ -395,6 +395,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   // batch's sums go to the block's LDS tallies once, from lane 0.  (Counters that ran on in registers
   // for the whole launch were ten registers that every phase had to carry -- or spill -- around its
   // peak; per-batch counters summed by a wave butterfly were ~40 vector instructions a batch.)
+  // (rare ones -- invalid histories -- go one by one; the rest as ONE LDS instruction per batch, below)
   auto tally_n = [&](int slot, unsigned long long n) {
     if (lane == 0 && n) atomicAdd(&s_tally[slot], n);
   };
@@ -422,10 +423,19 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
     }
   };
   // A history ended (lanes with `died`): loss counters, report line, final record.
+  // A batch's counts go to the block's tallies as ONE LDS instruction where the batch ends (lane j adds
+  // to tally j), in the layered and the spherical kernel; the tetra kernel, with no vector register to
+  // spare for that, adds them one by one where they arise (the vector form there: +0.8 %).
+  constexpr bool kVectorTally = KIND != CELL_TET;
+  uint32_t n_lost = 0, n_timeout = 0;   // (per batch, like the event counts: reset where a batch starts)
   auto finish = [&](bool died, int fate, int reason, const Phonon& p, uint64_t hid, uint32_t catches) {
     if (!any_lane(died)) return;
-    tally(died && fate == FATE_LOST, 0);
-    tally(died && fate == FATE_TIMEOUT, 1);
+    if constexpr (kVectorTally) {
+      n_lost += count(died && fate == FATE_LOST), n_timeout += count(died && fate == FATE_TIMEOUT);
+    } else {
+      tally(died && fate == FATE_LOST, 0);
+      tally(died && fate == FATE_TIMEOUT, 1);
+    }
     if (any_lane(died && fate == FATE_INVALID)) {   // rare
       tally(died && fate == FATE_INVALID, 2);
 #pragma unroll
@@ -502,27 +512,26 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
     {
       // ---- choose a queue: a full batch of a minor phase first (they all feed MOVE), then a
       //      refill, then MOVE; with no full batch anywhere, the fullest queue ----
+      // (lane j looks at queue j: one compare for all of them, then scalar tests of the lane mask)
       const uint32_t snap = lane < 8 ? lds_ld(&ctl.word[lane]) : 0u;
       const uint32_t drained = (uint32_t)__builtin_amdgcn_readlane((int)snap, kDrainedWord);
       if (drained && a.carry_out) break;   // no ids left: the pool is parked as it is for the next launch
-      uint32_t w[Q_NUM], c[Q_NUM];
-#pragma unroll
-      for (int j = 0; j < Q_NUM; j++) w[j] = (uint32_t)__builtin_amdgcn_readlane((int)snap, j), c[j] = w[j] & 0xFFFFu;
+      const uint32_t cnt = snap & 0xFFFFu;
+      const bool minor = lane == (unsigned)Q_RT || lane == (unsigned)Q_COLLECT || lane == (unsigned)Q_SCATTER;
+      uint32_t full = (uint32_t)ballot(cnt >= (minor ? kMinorFull : 64u)) & ((1u << Q_NUM) - 1u);
       if (drained) {
-        if (c[Q_FREE] == S) break;   // every slot is free and nothing is left to hand out
-        c[Q_FREE] = 0u;              // (free slots are of no use any more)
+        if ((uint32_t)__builtin_amdgcn_readlane((int)cnt, Q_FREE) == S) break;   // every slot is free and nothing is left to hand out
+        full &= ~(1u << Q_FREE);                                                  // (free slots are of no use any more)
       }
-      q = -1;
-      if (c[Q_RT] >= kMinorFull) q = Q_RT;
-      else if (c[Q_COLLECT] >= kMinorFull) q = Q_COLLECT;
-      else if (c[Q_SCATTER] >= kMinorFull) q = Q_SCATTER;
-      else if (c[Q_FREE] >= 64u) q = Q_FREE;
-      else if (c[Q_MOVE] >= 64u) q = Q_MOVE;
-      else {
+      q = (full & (1u << Q_RT)) ? Q_RT : (full & (1u << Q_COLLECT)) ? Q_COLLECT : (full & (1u << Q_SCATTER)) ? Q_SCATTER
+          : (full & (1u << Q_FREE)) ? Q_FREE : (full & (1u << Q_MOVE)) ? Q_MOVE : -1;
+      if (q < 0) {   // no full batch anywhere: the fullest queue
         uint32_t best = 0u;
 #pragma unroll
-        for (int j = 0; j < Q_NUM; j++)
-          if (c[j] > best) best = c[j], q = j;
+        for (int j = 0; j < Q_NUM; j++) {
+          const uint32_t cj = (drained && j == Q_FREE) ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)cnt, j);
+          if (cj > best) best = cj, q = j;
+        }
       }
       if (q < 0) {   // everything in flight is in other waves' hands
 #ifdef R3D_PHASE_TIMING
@@ -532,9 +541,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         __builtin_amdgcn_s_sleep(8);
         continue;
       }
-      uint32_t wq = 0;
-#pragma unroll
-      for (int j = 0; j < Q_NUM; j++) wq = (q == j) ? w[j] : wq;
+      const uint32_t wq = (uint32_t)__builtin_amdgcn_readlane((int)snap, q);
       R3D_PRIO_HIGH();
       k = q_pop(ctl, ring(q), rmask, rlog, q, lane, wq, id);
 #ifdef R3D_PRIO_NARROW
@@ -551,7 +558,9 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
     const unsigned long long t_begin = __builtin_readcyclecounter();
 #endif
     int dest = Q_FREE;   // where each active lane's slot goes after this phase
-    uint32_t n_iter = 0, n_transfer = 0, n_reflect = 0;   // the batch's event counts (wave-uniform)
+    // the batch's event counts (wave-uniform; scalar registers), added to the block's tallies together below
+    uint32_t n_iter = 0, n_transfer = 0, n_reflect = 0, n_generated = 0, n_collect = 0, n_catch = 0;
+    n_lost = 0, n_timeout = 0;
 
 #ifndef R3D_PRIO_NARROW
     if (q == Q_FREE) R3D_PRIO_LOW();
@@ -578,7 +587,8 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         dest = Q_MOVE;
       }
       report(fresh, 0, p, hid);   // GEN
-      tally_n(kEv + R3D_EV_GENERATED, take);
+      if constexpr (kVectorTally) n_generated = take;
+      else tally_n(kEv + R3D_EV_GENERATED, take);
     } else if (q == Q_MOVE) {
       // ---- termination checks, boundary search, free-path draw, advance (phonons.cpp:549-623),
       //      and what the face reached asks for when that is little: a plain hand-over, a Snell
@@ -684,11 +694,13 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       k1 = k0;
 #endif
       report(act, 3, p, hid);   // COL: the incident state
-      tally_n(kEv + R3D_EV_COLLECT, k);
+      if constexpr (kVectorTally) n_collect = k;
+      else tally_n(kEv + R3D_EV_COLLECT, k);
       if (any_lane(k1 > k0)) {
         const uint32_t hits = pool_collect_pairs<KIND, TRACE>(a, T, p, vel, k0, k1, LDS_SEIS ? lds_gitems : nullptr,
                                                               lane, catches, bc);
-        tally_n(kEv + R3D_EV_CATCH, hits);
+        if constexpr (kVectorTally) n_catch = hits;
+        else tally_n(kEv + R3D_EV_CATCH, hits);
       }
       bool died = false;
       if (act) {
@@ -764,10 +776,35 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       }
       if (q == Q_RT) n_transfer += count(st.transfer != 0u), n_reflect += count(st.reflect != 0u);
     }
-    if (q == Q_SCATTER) tally_n(kEv + R3D_EV_SCATTER, k);
-    tally_n(kEv + R3D_EV_ITERATIONS, n_iter), tally_n(kEv + R3D_EV_TRANSFER, n_transfer);
-    tally_n(kEv + R3D_EV_REFLECT, n_reflect);
-    if (q == Q_RT) tally_n(kEv + R3D_EV_RTSOLVE, k);
+    if constexpr (!kVectorTally) {
+      if (q == Q_SCATTER) tally_n(kEv + R3D_EV_SCATTER, k);
+      tally_n(kEv + R3D_EV_ITERATIONS, n_iter), tally_n(kEv + R3D_EV_TRANSFER, n_transfer);
+      tally_n(kEv + R3D_EV_REFLECT, n_reflect);
+      if (q == Q_RT) tally_n(kEv + R3D_EV_RTSOLVE, k);
+    } else {
+      // lane j holds what the batch adds to tally j (include/r3d.h: lost, timeout, invalid + reasons, the
+      // eight event counters): one LDS add for all of them
+      static_assert(kEv + R3D_EV_NUM == R3D_N_SCALARS && R3D_N_SCALARS <= 64, "one lane per tally");
+      uint32_t tv = 0;
+#define R3D_PUT(slot, n)                                                         \
+  do {                                                                           \
+    uint32_t put_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n));          \
+    asm("" : "+s"(put_)); /* (a scalar REGISTER: a count known to be zero would fold into an operand the instruction does not take) */ \
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(tv) : "s"(put_), "n"(slot));         \
+  } while (0)
+      R3D_PUT(0, n_lost);
+      R3D_PUT(1, n_timeout);
+      R3D_PUT(kEv + R3D_EV_GENERATED, n_generated);
+      R3D_PUT(kEv + R3D_EV_ITERATIONS, n_iter);
+      R3D_PUT(kEv + R3D_EV_SCATTER, q == Q_SCATTER ? k : 0u);
+      R3D_PUT(kEv + R3D_EV_COLLECT, n_collect);
+      R3D_PUT(kEv + R3D_EV_CATCH, n_catch);
+      R3D_PUT(kEv + R3D_EV_REFLECT, n_reflect);
+      R3D_PUT(kEv + R3D_EV_TRANSFER, n_transfer);
+      R3D_PUT(kEv + R3D_EV_RTSOLVE, q == Q_RT ? k : 0u);
+#undef R3D_PUT
+      if (lane < (unsigned)R3D_N_SCALARS && tv) atomicAdd(&s_tally[lane], (unsigned long long)tv);
+    }
 #ifdef R3D_PHASE_TIMING
     const unsigned long long t_push = __builtin_readcyclecounter();
 #endif
