@@ -95,8 +95,10 @@ __device__ __forceinline__ uint32_t lap_of(uint32_t ticket, uint32_t log2cap) { 
 // many (wave-uniform); lane l < k gets its slot in `id`.
 __device__ __forceinline__ unsigned q_pop(PoolCtl& ctl, lds_u16* ring, uint32_t mask, uint32_t log2cap, int q,
                                           unsigned lane, uint32_t seen, unsigned& id) {
+  // (everything but the compare-and-swap itself is wave-uniform and written so: scalar instructions and
+  //  scalar branches, where the same loop under "lane 0 only" ran on the vector unit behind exec masks)
   unsigned k = 0, pos = 0;
-  if (lane == 0) {
+  {
     uint32_t w = seen;
     // (never fewer than the scheduler counted on: when another wave was quicker and left a
     //  remainder, taking that handful would make a batch of a few lanes -- look again instead)
@@ -104,7 +106,9 @@ __device__ __forceinline__ unsigned q_pop(PoolCtl& ctl, lds_u16* ring, uint32_t 
     while ((w & 0xFFFFu) >= need && (w & 0xFFFFu)) {
       const uint32_t c = w & 0xFFFFu, t = c < 64u ? c : 64u;
       const uint32_t next = ((w + (t << 16)) & 0xFFFF0000u) | (c - t);
-      const uint32_t was = atomicCAS(&ctl.word[q], w, next);
+      uint32_t was = 0;
+      if (lane == 0) was = atomicCAS(&ctl.word[q], w, next);
+      was = (uint32_t)__builtin_amdgcn_readfirstlane((int)was);
       if (was == w) {
         k = t, pos = w >> 16;
         break;
@@ -112,8 +116,6 @@ __device__ __forceinline__ unsigned q_pop(PoolCtl& ctl, lds_u16* ring, uint32_t 
       w = was;
     }
   }
-  k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
-  pos = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
   id = 0;
   if (lane < k) {
     volatile lds_u16* e = ring + ((pos + lane) & mask);
