@@ -171,6 +171,25 @@ __device__ __forceinline__ void q_push_all(PoolCtl& ctl, lds_u16* rings, uint32_
   if (lane < Q_NUM && kq) atomicAdd(&ctl.word[lane], kq);
 }
 
+// The same for a batch whose first k lanes ALL go to queue q (what a reflection / transmission or a
+// scattering batch does: on to MOVE): no lane masks, no ranks -- lane l takes ticket l of the k.
+__device__ __forceinline__ void q_push_one(PoolCtl& ctl, lds_u16* rings, uint32_t rcap, uint32_t log2cap, int q,
+                                           unsigned lane, unsigned k, unsigned id) {
+  uint32_t pos = 0;
+  if (lane == 0) pos = atomicAdd(&ctl.tail[q], k);
+  R3D_LDS_RELEASE();   // (the slots' state before their numbers)
+  pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+  if (lane < k) {
+    const uint32_t t = pos + lane;
+    volatile lds_u16* e = rings + (((uint32_t)q << log2cap) | (t & (rcap - 1u)));
+    while (*e != kRingEmpty) {
+    }
+    *e = (uint16_t)((lap_of(t, log2cap) << kSlotBits) | id);
+  }
+  R3D_LDS_RELEASE();
+  if (lane == 0) atomicAdd(&ctl.word[q], k);
+}
+
 // Seismometer collection for a batch of arrivals (one per lane with k1 > k0): the same tests and
 // bin updates as collect() in r3d_step.h (reference dataout.cpp:103-216, :545-568).  The
 // (arrival, candidate receiver) pairs of the whole batch are numbered through a prefix sum of
@@ -811,7 +830,8 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
     const unsigned long long t_push = __builtin_readcyclecounter();
 #endif
     R3D_PRIO_HIGH();
-    q_push_all(ctl, rings, rcap, rlog, lane, act, dest, id);
+    if (q == Q_RT || q == Q_SCATTER) q_push_one(ctl, rings, rcap, rlog, Q_MOVE, lane, k, id);   // (all on to MOVE)
+    else q_push_all(ctl, rings, rcap, rlog, lane, act, dest, id);
 #ifdef R3D_PRIO_NARROW
     R3D_PRIO_LOW();
 #endif
