@@ -201,7 +201,7 @@ R3D_HD double log_lean(double x) {
   __builtin_memcpy(&m, &mant, 8);
 #endif
   const double f = m - 1.0;
-  const double s_ = f / (2.0 + f);
+  const double s_ = f * frcp(2.0 + f);   // (2 + f lies in [1.7, 2.42])
   const double z = s_ * s_;
   double r = 1.479819860511658591e-01;
   r = __builtin_fma(r, z, 1.531383769920937332e-01);

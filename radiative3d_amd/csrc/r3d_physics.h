@@ -333,7 +333,8 @@ R3D_HD SphArc sph_arc(const CellSph& c, const double ec[3], const Phonon& p) {
   const double TwoGA = 2. * G * c.a;
   const double urad = 1. - (2. * TwoGA * G * c.c);
   double bottom = (urad > 1) ? (1. - fsqrt(urad)) * frcp(TwoGA) : 0;
-  A.radius = (c.zero_rad2 / bottom - bottom) / 2.0;
+  // (bottom == 0: the vertical ray, whose radius is infinite -- what the division gave)
+  A.radius = (bottom == 0) ? c.zero_rad2 * pos_inf() : 0.5 * (c.zero_rad2 * frcp(bottom) - bottom);
   A.rad2 = A.radius * A.radius;
   A.center = p.loc + ((A.radius * cosi) * w1 + (-A.radius * sini) * w3);
   A.u3 = down_at(ec, A.center);
@@ -480,7 +481,7 @@ R3D_HD void rt_weights(const Iface& f, double sini, int intype, double w[RT_NUM]
 #pragma unroll
   for (int i = 0; i < RT_NUM; i++) w[i] = 0;
   if (intype == 1) {  // GetCoefs_SH, rtcoef.cpp:207-278
-    const double s2 = (b2 / b1) * sini;
+    const double s2 = (b2 * frcp(b1)) * sini;   // (b1: the S velocity where an S ray is travelling -- a plain number)
     const Cx cj1 = sqrt_real(1.0 - sini * sini);
     const Cx cj2 = sqrt_real(1.0 - s2 * s2);
     const Cx a = (rho1 * b1) * cj1, b = (rho2 * b2) * cj2;
@@ -496,7 +497,8 @@ R3D_HD void rt_weights(const Iface& f, double sini, int intype, double w[RT_NUM]
     Cx ci1, ci2, cj1, cj2;           // vertical slownesses cos / v of the four outgoing rays
     double a, b, c, d, pp, psq, t_in;
     {
-      const double ia1 = 1.0 / a1, ia2 = 1.0 / a2, ib1 = 1.0 / b1, ib2 = 1.0 / b2;
+      // (P velocities are plain numbers -- a free surface's far side has 1e-12 --; an S velocity is 0 in a fluid, and its reciprocal's infinity is meant)
+      const double ia1 = frcp(a1), ia2 = frcp(a2), ib1 = 1.0 / b1, ib2 = 1.0 / b2;
       pp = sini * (in_p ? ia1 : ib1);  // horizontal slowness
       psq = pp * pp;
       const double sTP = a2 * pp, sTS = b2 * pp, sRS = b1 * pp, sRP = a1 * pp;   // the outgoing rays' sines
@@ -554,10 +556,10 @@ R3D_HD void rt_ray(const Iface& f, double sini, int intype, int choice, double& 
   const double v_p = out_t ? a2 : a1, v_s = out_t ? b2 : b1;
   const double v_out = out_p ? v_p : v_s;
   if (intype == 1) {   // (b2 / b1) sini as in rt_weights; the reflected SH ray keeps the incidence sine
-    sn = (choice == R_SH) ? sini : (b2 / b1) * sini;
+    sn = (choice == R_SH) ? sini : (b2 * frcp(b1)) * sini;
     cr = sqrt_real(1.0 - sn * sn).re;
   } else {
-    const double pp = sini * (1.0 / v_in);
+    const double pp = sini * frcp(v_in);
     sn = v_out * pp;
     cr = sqrt_real(1.0 - sn * sn).re;
   }
@@ -691,7 +693,7 @@ R3D_HD bool bend(Phonon& p, V3 fnorm, double veli, double velo) {
   // Normal incidence (w = 0) takes the reference's substitute axis (geom_r3.cpp:146-171).
   const double cn = dot(fnorm, p.dir);
   const V3 dt = p.dir - cn * fnorm;
-  const double ratio = velo / veli;
+  const double ratio = velo * frcp(veli);   // (the incident ray's own velocity: a plain number)
   const double so2 = (ratio * ratio) * mag2(dt);   // sin^2 of the outgoing angle
   const bool transfer = !(so2 >= 1.0);
   // (total reflection: the same tangential part, the normal part reversed)
@@ -755,9 +757,12 @@ R3D_HD uint64_t sample_cdf_guided(const double* __restrict__ cdf_, const GuideCe
   uint64_t k1 = g.k1;
   const uint64_t k2 = g.k2;
   const bool direct = k2 - k1 <= (uint64_t)kGuideVals;
-  uint32_t below = 0;   // how many of the cell's values lie below r (entries, or pivots)
+  // how many of the cell's values lie below r (entries, or pivots).  (A short bracket's cell is filled up
+  // with cdf[k2], and r <= cdf[k2] -- the answer lies in the bracket --: the filling never counts, so
+  // no lane asks how long its bracket is.)
+  uint32_t below = 0;
 #pragma unroll
-  for (int i = 0; i < kGuideVals; i++) below += ((direct ? k1 + i < k2 : true) && !(r <= g.c[i])) ? 1u : 0u;
+  for (int i = 0; i < kGuideVals; i++) below += !(r <= g.c[i]) ? 1u : 0u;
   if (direct) return k1 + below;
   // a long bracket: the pivots leave an eighth of it, [lo, hi]; its first eight entries at once
   uint64_t lo = below ? guide_pivot(k1, k2, (int)below - 1) + 1 : k1;
@@ -768,7 +773,7 @@ R3D_HD uint64_t sample_cdf_guided(const double* __restrict__ cdf_, const GuideCe
   for (int i = 0; i < kAtOnce; i++) c[i] = cdf[(lo + i < hi) ? lo + i : hi];
   uint32_t more = 0;
 #pragma unroll
-  for (int i = 0; i < kAtOnce; i++) more += (lo + i < hi && !(r <= c[i])) ? 1u : 0u;
+  for (int i = 0; i < kAtOnce; i++) more += !(r <= c[i]) ? 1u : 0u;   // (beyond hi: cdf[hi] again, never below r)
   lo += more;
   if (more == kAtOnce) {   // (brackets beyond 64 entries: bisect what is left)
     uint64_t top = hi;
