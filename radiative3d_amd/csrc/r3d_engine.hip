@@ -126,6 +126,7 @@ struct r3d_engine {
   };
   std::vector<ScatStats> scat_stats;
   std::vector<ScatPtrs> scat_ptrs;   // device addresses of every scatterer's tables
+  std::vector<const double*> d_spol; // ... and of its polarisation ANGLES (the kernel reads their cosine / sine pairs)
   uint64_t n_toa = 0;
   const double* d_toa = nullptr;     // the take-off set, (theta, phi) pairs
   const double* d_src[3] = {nullptr, nullptr, nullptr};
@@ -168,6 +169,16 @@ const GuideCell* make_guide(r3d_engine* e, const double* d_cdf, uint64_t n, uint
   if (*err == hipSuccess)
     if (hipError_t r = build_guide_on_device(d_cdf, n, bits, d_guide, nullptr); r != hipSuccess) *err = r;
   return d_guide;
+}
+
+// The (cosine, sine) pairs of a scatterer's polarisation angles (r3d_tables.h ScatPtrs::spol_cs), made in HBM.
+const double* make_spol_cs(r3d_engine* e, const double* d_spol, uint64_t n, hipError_t* err) {
+  auto g = std::make_unique<DevBuf>();
+  if (hipError_t r = g->alloc_zero(2 * n * sizeof(double)); r != hipSuccess) *err = r;
+  double* d_cs = reinterpret_cast<double*>(e->keep(std::move(g))->p);
+  if (*err == hipSuccess)
+    if (hipError_t r = build_spol_cs_on_device(d_spol, n, d_cs, nullptr); r != hipSuccess) *err = r;
+  return d_cs;
 }
 
 // The traversal kernels live in one translation unit per cell kind (r3d_kernels_kind.hip, compiled
@@ -270,6 +281,7 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   }
   e->n_toa = m->n_toa;
   e->scat_stats.resize(m->n_scatterers);
+  e->d_spol.assign(m->n_scatterers, nullptr);
   // ---- the take-off set: uploaded, or generated here (r3d_tables_build.hip) ----
   const double* d_toa = nullptr;   // (theta, phi) pairs
   {
@@ -295,7 +307,8 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
         pm.scat_ptrs[s].guide[k] = make_guide(e.get(), pm.scat_ptrs[s].cdf[k], m->n_toa, a.guide_bits, &err);
         st.total[k] = S.cdf[k][m->n_toa - 1];
       }
-      pm.scat_ptrs[s].spol = upload_doubles(e.get(), S.spol, m->n_toa, &err);
+      e->d_spol[s] = upload_doubles(e.get(), S.spol, m->n_toa, &err);
+      pm.scat_ptrs[s].spol_cs = make_spol_cs(e.get(), e->d_spol[s], m->n_toa, &err);
       st.mfp[0] = S.mfp[0], st.mfp[1] = S.mfp[1], st.dipole[0] = st.dipole[1] = nan;
       continue;
     }
@@ -322,7 +335,8 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
       pm.scat_ptrs[s].guide[k] = make_guide(e.get(), d_cdf[k], m->n_toa, a.guide_bits, &err);
       pm.scat_head[s].total[k] = st.total[k];
     }
-    pm.scat_ptrs[s].spol = d_spol;
+    e->d_spol[s] = d_spol;
+    pm.scat_ptrs[s].spol_cs = make_spol_cs(e.get(), d_spol, m->n_toa, &err);
     // Mean free paths, conversion table and dipole moments from the totals, as the host
     // builder derives them (scatterers.cpp:172-220, :244-259)
     const double* tot = st.total;
@@ -710,7 +724,7 @@ int r3d_engine_download_scatterer(r3d_engine* e, int s, double* cdf[4], double* 
   const size_t bytes = e->n_toa * sizeof(double);
   for (int k = 0; k < 4; k++)
     if (cdf && cdf[k]) R3D_HIP_OK(hipMemcpy(cdf[k], e->scat_ptrs[s].cdf[k], bytes, hipMemcpyDeviceToHost));
-  if (spol) R3D_HIP_OK(hipMemcpy(spol, e->scat_ptrs[s].spol, bytes, hipMemcpyDeviceToHost));
+  if (spol) R3D_HIP_OK(hipMemcpy(spol, e->d_spol[s], bytes, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -29,6 +29,7 @@ struct PackedModel {
   std::vector<uint32_t> grid_start, grid_items;
   std::vector<std::vector<GuideCell>> src_guide;    // [3]   (host emulation only: the engine builds its own in HBM)
   std::vector<std::vector<GuideCell>> scat_guide;   // [n_scat * 4]
+  std::vector<std::vector<double>> spol_cs;         // [n_scat] (cosine, sine) pairs (host emulation only, likewise)
   KArgs args;                        // pointers refer to the vectors above / the model
   size_t cell_bytes() const {
     return cyl.size() * sizeof(CellCyl) + tet.size() * sizeof(CellTet) + sph.size() * sizeof(CellSph);
@@ -334,6 +335,7 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm, bool for_engine
   // ---- scatterers ----
   a.guide_bits = guide_bits_for(m.n_toa);
   pm.scat_guide.assign((size_t)m.n_scatterers * 4, {});
+  pm.spol_cs.assign((size_t)m.n_scatterers, {});
   pm.src_guide.assign(3, {});
   pm.scat_head.resize(m.n_scatterers);
   pm.scat_ptrs.resize(m.n_scatterers);
@@ -345,7 +347,7 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm, bool for_engine
     }
     if (!S.cdf[0]) {   // build-on-device form: the engine fills head, tables and guides
       for (int k = 0; k < 4; k++) pm.scat_ptrs[s].cdf[k] = nullptr, pm.scat_ptrs[s].guide[k] = nullptr;
-      pm.scat_ptrs[s].spol = nullptr;
+      pm.scat_ptrs[s].spol_cs = nullptr;
       continue;
     }
     for (int k = 0; k < 4; k++) {
@@ -357,7 +359,13 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm, bool for_engine
         pm.scat_ptrs[s].guide[k] = pm.scat_guide[s * 4 + k].data();
       }
     }
-    pm.scat_ptrs[s].spol = S.spol;
+    pm.scat_ptrs[s].spol_cs = nullptr;
+    if (!for_engine) {   // (the engine makes the pairs in HBM too)
+      std::vector<double>& cs = pm.spol_cs[s];
+      cs.resize(2 * m.n_toa);
+      for (uint64_t k = 0; k < m.n_toa; k++) cs[2 * k] = std::cos(S.spol[k]), cs[2 * k + 1] = std::sin(S.spol[k]);
+      pm.scat_ptrs[s].spol_cs = cs.data();
+    }
   }
   a.scat_head = pm.scat_head.data();
   a.scat_ptrs = pm.scat_ptrs.data();

@@ -366,13 +366,14 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
       uint64_t k = sample_cdf_guided(sp->cdf[conv], sp->guide[conv], a.guide_bits, sh.total[conv], u_dir);
 #endif
       double rc = 1.0, rs = 0.0;      // relative polarisation 0 except S->S (scatterers.cpp:341-356)
-      if (conv == 3) {
+      if (conv == 3) {   // (the angle's cosine and sine as the table holds them: r3d_tables.h ScatPtrs)
 #if defined(__HIP_DEVICE_COMPILE__)
         typedef __attribute__((address_space(1))) const double gdouble;   // (HBM: a global, not a FLAT, load)
-        rotation(((gdouble*)sp->spol)[k], &rs, &rc);   // (an angle in (-pi, pi]: the small-argument kernels serve it)
+        const gdouble* cs = (gdouble*)sp->spol_cs + 2 * k;
 #else
-        rotation(sp->spol[k], &rs, &rc);
+        const double* cs = sp->spol_cs + 2 * k;
 #endif
+        rc = cs[0], rs = cs[1];
       }
       scatter_transform(p, v3(a.toa_xyz + 3 * k), rc, rs, (conv & 1) ? RAY_S : RAY_P);
     }

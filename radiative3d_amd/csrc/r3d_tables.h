@@ -118,7 +118,9 @@ struct ScatHead {     // small per-scatterer record, staged in LDS
 };
 struct ScatPtrs {     // HBM-resident tables of one scatterer
   const double* cdf[4];
-  const double* spol;
+  // S -> S polarisation of each deflection as (cosine, sine) pairs: what the transform takes, one 16-byte
+  // fetch in place of an angle and its sine / cosine polynomials at every S -> S scattering
+  const double* spol_cs;
   const GuideCell* guide[4]; // search guides of the four CDFs (see sample_cdf_guided)
 };
 

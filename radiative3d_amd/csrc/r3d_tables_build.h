@@ -30,6 +30,9 @@ hipError_t build_toa_xyz_on_device(const double* d_toa, uint64_t n, double min_t
 hipError_t build_source_tables(const double moment[6], const double* d_toa, uint64_t n, double* d_cdf[3],
                                double totals[3], hipStream_t stream);
 
+// (cos, sin) pairs of the n polarisation angles d_spol (asynchronous).
+hipError_t build_spol_cs_on_device(const double* d_spol, uint64_t n, double* d_cs, hipStream_t stream);
+
 // The 2^bits guide cells of a cumulative table (r3d_tables.h GuideCell; asynchronous).
 hipError_t build_guide_on_device(const double* d_cdf, uint64_t n, uint32_t bits, GuideCell* d_guide,
                                  hipStream_t stream);

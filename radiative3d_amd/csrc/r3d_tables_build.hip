@@ -347,6 +347,19 @@ hipError_t build_scatterer_tables(const double het[6], double psdf_numer, const 
   return err;
 }
 
+__global__ __launch_bounds__(kThreads) void spol_cs_kernel(const double* __restrict__ spol, uint64_t n,
+                                                           double* __restrict__ cs) {
+  const uint64_t k = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (k >= n) return;
+  double s, c;
+  sincos(spol[k], &s, &c);
+  cs[2 * k] = c, cs[2 * k + 1] = s;
+}
+hipError_t build_spol_cs_on_device(const double* d_spol, uint64_t n, double* d_cs, hipStream_t stream) {
+  spol_cs_kernel<<<(uint32_t)((n + kThreads - 1) / kThreads), kThreads, 0, stream>>>(d_spol, n, d_cs);
+  return hipGetLastError();
+}
+
 hipError_t build_guide_on_device(const double* d_cdf, uint64_t n, uint32_t bits, GuideCell* d_guide,
                                  hipStream_t stream) {
   const uint64_t G = 1ull << bits;
