@@ -361,11 +361,11 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
   a.scat_ptrs = upload_vec(e.get(), pm.scat_ptrs, &err);
   {   // unit vectors of the take-off directions: evaluated in HBM from the (theta, phi) pairs
     auto b = std::make_unique<DevBuf>();
-    if (hipError_t r = b->alloc_zero(m->n_toa * 3 * sizeof(double)); r != hipSuccess) err = r;
+    if (hipError_t r = b->alloc_zero(m->n_toa * 4 * sizeof(double)); r != hipSuccess) err = r;
     if (err == hipSuccess)
       err = build_toa_xyz_on_device(d_toa, m->n_toa, m->params.min_theta, m->params.max_theta,
                                     reinterpret_cast<double*>(b->p), nullptr);
-    a.toa_xyz = reinterpret_cast<const double*>(e->keep(std::move(b))->p);
+    a.toa_dir = reinterpret_cast<const double*>(e->keep(std::move(b))->p);
   }
   {   // the source's cumulative radiation patterns: copied in, or evaluated here; guides made here
     double* d_src[3] = {nullptr, nullptr, nullptr};

@@ -373,20 +373,19 @@ inline void pack_model(const r3d_model_desc& m, PackedModel& pm, bool for_engine
 
   // ---- take-off directions as unit vectors; theta nudged away from the poles
   //      as Phonon::nudge_if_singular does (phonons.hpp:335-344) ----
-  if (!for_engine) pm.toa_xyz.resize(m.n_toa * 3);
+  if (!for_engine) pm.toa_xyz.resize(m.n_toa * 4);
   for (uint64_t k = 0; k < m.n_toa && !for_engine; k++) {
     double th = m.toa[2 * k], ph = m.toa[2 * k + 1];
     if (th < par.min_theta) th = par.min_theta;
     if (th > par.max_theta) th = par.max_theta;
-    pm.toa_xyz[3 * k] = std::sin(th) * std::cos(ph);
-    pm.toa_xyz[3 * k + 1] = std::sin(th) * std::sin(ph);
-    pm.toa_xyz[3 * k + 2] = std::cos(th);
+    pm.toa_xyz[4 * k] = std::cos(th), pm.toa_xyz[4 * k + 1] = std::cos(ph);
+    pm.toa_xyz[4 * k + 2] = std::sin(ph), pm.toa_xyz[4 * k + 3] = std::sin(th);
   }
-  a.toa_xyz = pm.toa_xyz.data();
+  a.toa_dir = pm.toa_xyz.data();
   a.n_toa = m.n_toa;
-  a.nodeflect_dir[0] = std::sin(par.min_theta);
-  a.nodeflect_dir[1] = 0.0;
-  a.nodeflect_dir[2] = std::cos(par.min_theta);
+  a.nodeflect_dir[0] = std::cos(par.min_theta);
+  a.nodeflect_dir[1] = 1.0, a.nodeflect_dir[2] = 0.0;
+  a.nodeflect_dir[3] = std::sin(par.min_theta);
 
   // ---- source ----
   for (int k = 0; k < 3; k++) {

@@ -796,12 +796,15 @@ R3D_HD int sample_small(const double* cdf, int n, double u) {
 // (reference Phonon::Transform, phonons.cpp:116-170; OrthoAxes,
 // geom_r3.cpp:212-286).  rel is the unit deflection vector, (rc, rs) the cosine
 // and sine of the relative polarisation angle.
-R3D_HD void scatter_transform(Phonon& p, V3 rel, double rc, double rs, int new_type) {
+// The deflection comes as {cos theta, cos phi, sin phi, sin theta} (r3d_tables.h KArgs::toa_dir): the
+// vector and its theta^, phi^ axes without a square root.
+R3D_HD void scatter_transform(Phonon& p, const double* dirn, double rc, double rs, int new_type) {
   V3 e1, e2;
   sph_basis(p.dir, e1, e2);
   const V3 s1 = p.pc * e1 + p.ps * e2, s2 = (-p.ps) * e1 + p.pc * e2, e3 = p.dir;
-  V3 b1, b2;
-  sph_basis(rel, b1, b2);
+  const double ct = dirn[0], cp = dirn[1], sp = dirn[2], st = dirn[3];
+  const V3 rel = v3(st * cp, st * sp, ct);
+  const V3 b1 = v3(ct * cp, ct * sp, -st), b2 = v3(-sp, cp, 0.0);
   const V3 bs1 = rc * b1 + rs * b2;              // S1 axis of the deflection frame
   V3 nd = rel.x * s1 + rel.y * s2 + rel.z * e3;  // AA.Express(BB.E3)
   V3 ns1 = bs1.x * s1 + bs1.y * s2 + bs1.z * e3;

@@ -64,9 +64,12 @@ R3D_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
   out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
 }
 
+// (m + 1) 2^-53 with m = (hi >> 5) 2^26 + (lo >> 6), formed from its two halves: each converts exactly,
+// and their scaled sum -- a multiple of 2^-53 in (0, 1] -- is exact too, so this IS (double)(m + 1) * 2^-53
+// (oracle/philox.h) without the 64-bit integer arithmetic and the 64-bit conversion.
 R3D_HD double u01_from_words(uint32_t hi, uint32_t lo) {
-  uint64_t m = ((uint64_t)(hi >> 5) << 26) | (uint64_t)(lo >> 6);
-  return (double)(m + 1) * (1.0 / 9007199254740992.0);
+  const double a = (double)(hi >> 5), b = (double)((lo >> 6) + 1u);
+  return __builtin_fma(a, 1.0 / 134217728.0, b * (1.0 / 9007199254740992.0));
 }
 
 R3D_HD void rng_init(Rng& g, uint64_t id) {

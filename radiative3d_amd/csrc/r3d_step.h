@@ -112,7 +112,10 @@ R3D_HD void spray(const KArgs& a, Phonon& p, Rng& rng) {
   p.t = p.path = p.recent = 0.0;
   p.lamp = 0.0;
   p.moves = 0;
-  p.dir = v3(a.toa_xyz + 3 * k);
+  {
+    const double* d = a.toa_dir + 4 * k;   // {cos theta, cos phi, sin phi, sin theta}
+    p.dir = v3(d[3] * d[1], d[3] * d[2], d[0]);
+  }
   // mPol = pi/2 for SH, else 0 (phonons.hpp:200); cos(pi/2) in fp64 is 6.1e-17, not 0
   p.pc = (rt3 == 1) ? 6.123233995736766e-17 : 1.0;
   p.ps = (rt3 == 1) ? 1.0 : 0.0;
@@ -352,7 +355,7 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
     // Scatterer::GetRandomScatteredRelativePhonon, scatterers.cpp:318-363
     st.scatter++;
     if (a.no_deflect) {
-      scatter_transform(p, v3(a.nodeflect_dir), 1.0, 0.0, p.type);
+      scatter_transform(p, a.nodeflect_dir, 1.0, 0.0, p.type);
     } else {
       const int scat = cell_scat(c);
       const ScatHead& sh = T.scat_head[scat];
@@ -375,7 +378,7 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
 #endif
         rc = cs[0], rs = cs[1];
       }
-      scatter_transform(p, v3(a.toa_xyz + 3 * k), rc, rs, (conv & 1) ? RAY_S : RAY_P);
+      scatter_transform(p, a.toa_dir + 4 * k, rc, rs, (conv & 1) ? RAY_S : RAY_P);
     }
     volume_count(a, p);   // SCT
     return FATE_ALIVE;

@@ -158,7 +158,10 @@ struct KArgs {
   const SeisHit* seis_hit;
   SeisGrid grid;
   uint64_t n_toa;
-  const double* toa_xyz;     // n_toa x 3, theta already nudged
+  // take-off directions as {cos theta, cos phi, sin phi, sin theta} (theta already nudged): two 16-byte loads give
+  // the unit vector (st cp, st sp, ct) AND its theta^ / phi^ axes (ct cp, ct sp, -st), (-sp, cp, 0) -- what a
+  // scattering would otherwise rebuild from the vector with a reciprocal square root
+  const double* toa_dir;     // n_toa x 4
   const double* src_cdf[3];
   const GuideCell* src_guide[3];
   double src_total[3];       // src_cdf[k][n_toa-1]
@@ -171,7 +174,7 @@ struct KArgs {
   // scalars
   double ttl, time_per_bin, inv_time_per_bin, slow_concern;
   uint64_t loop_concern;
-  double nodeflect_dir[3];   // unit vector at theta = min_theta, phi = 0
+  double nodeflect_dir[4];   // the same four numbers at theta = min_theta, phi = 0
   double cyl_radius2;        // cylinder models: wall radius squared
   double earth_center[3];
   // work

@@ -242,9 +242,8 @@ __global__ __launch_bounds__(kThreads) void toa_xyz_kernel(const double* __restr
   const double ph = toa[2 * k + 1];
   if (th < min_theta) th = min_theta;
   if (th > max_theta) th = max_theta;
-  xyz[3 * k] = sin(th) * cos(ph);
-  xyz[3 * k + 1] = sin(th) * sin(ph);
-  xyz[3 * k + 2] = cos(th);
+  // {cos theta, cos phi, sin phi, sin theta} (r3d_tables.h KArgs::toa_dir)
+  xyz[4 * k] = cos(th), xyz[4 * k + 1] = cos(ph), xyz[4 * k + 2] = sin(ph), xyz[4 * k + 3] = sin(th);
 }
 // ---- source radiation patterns --------------------------------------------------------------
 // P, SH and SV energy radiated into each take-off direction by a moment tensor given in the local
