@@ -309,17 +309,12 @@ struct SphArc {
   double s0, c0;   // sine / cosine of the current location's angle from the arc bottom
   bool straight;   // a == 0: straight rays
 };
-R3D_HD V3 down_at(const double ec[3], V3 loc) {  // ECS.GetDown, ecs.cpp:147-167
-  return -unit_else(loc - v3(ec), v3(0, 1, 0));
+R3D_HD V3 down_at(V3 ec, V3 loc) {  // ECS.GetDown, ecs.cpp:147-167
+  return -unit_else(loc - ec, v3(0, 1, 0));
 }
-R3D_HD SphArc sph_arc(const CellSph& c, const double ec[3], const Phonon& p) {
+R3D_HD SphArc sph_arc(const CellSph& c, V3 ec, const Phonon& p) {
   SphArc A;
   A.straight = (c.a == 0);
-  if (A.straight) {
-    A.radius = pos_inf(), A.rad2 = pos_inf(), A.S2 = 0, A.inv_TwoSQ = 0, A.CotZetaBy2 = 0;
-    A.timeCoef = 0, A.s0 = 0, A.c0 = 1, A.center = v3(0, 0, 0), A.u1 = p.dir, A.u3 = v3(0, 0, 0);
-    return A;
-  }
   V3 w3 = down_at(ec, p.loc);
   V3 w2 = unit_else(cross(w3, p.dir), v3(0, 0, 0));
   V3 w1 = cross(w2, w3);
@@ -357,6 +352,13 @@ R3D_HD SphArc sph_arc(const CellSph& c, const double ec[3], const Phonon& p) {
   const double ih = frsqrt(h2);
   A.s0 = (h2 == 0) ? 0.0 : y * ih;   // atan2(0, 0) = 0
   A.c0 = (h2 == 0) ? 1.0 : x * ih;
+  // (a shell of uniform velocity: straight rays.  Set here, over whatever the formulas above made of
+  //  a == 0, rather than returned early: with two ways out the compiler kept part of the result in
+  //  scratch memory, a store and a load through the vector-memory path in every move)
+  if (A.straight) {
+    A.radius = pos_inf(), A.rad2 = pos_inf(), A.S2 = 0, A.inv_TwoSQ = 0, A.CotZetaBy2 = 0;
+    A.timeCoef = 0, A.s0 = 0, A.c0 = 1, A.center = v3(0, 0, 0), A.u1 = p.dir, A.u3 = v3(0, 0, 0);
+  }
   return A;
 }
 // reference SphereShell::GetPathToBoundary, media.cpp:668-757 (search part), with

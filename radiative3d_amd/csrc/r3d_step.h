@@ -265,7 +265,7 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
     e.face = texit.face;
     e.len = tet_exit_length(tarc, texit);
   } else {
-    sarc = sph_arc(c, a.earth_center, p);
+    sarc = sph_arc(c, v3(a.earth_center[0], a.earth_center[1], a.earth_center[2]), p);
     sexit = sph_exit(c, sarc, p);
     e.face = sexit.face, e.len = sexit.len;
   }
