@@ -417,12 +417,19 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
     uint32_t acc_bits = m->n_seismometers > 0 ? 8u : 0u;   // 256 accumulators = 13 KB ...
     if (const char* s = getenv("R3D_ACC_BITS")) acc_bits = (uint32_t)atoi(s);   // developer tuning
     if (acc_bits && acc_bits < 5) acc_bits = 0;
+    const size_t pool_bytes = (size_t)kSlotStride * kSlotBytes, ring_bytes = (size_t)Q_NUM * kSlotStride * sizeof(uint16_t);
+    // (a layered or spherical model whose cell records do not fit beside 256 accumulators but do beside
+    //  128 gets 128: the hot first-arrival bins are a few dozen, and records from LDS are worth more)
+    if (acc_bits == 8 && !getenv("R3D_ACC_BITS") && m->cell_kind != R3D_CELL_TETRA) {
+      const size_t room8 = kLds - kStatic - pool_bytes - ring_bytes - 64 - (kAccEntryBytes << 8);
+      const size_t room7 = kLds - kStatic - pool_bytes - ring_bytes - 64 - (kAccEntryBytes << 7);
+      if (cell_bytes + scat_bytes > room8 && cell_bytes + scat_bytes <= room7) acc_bits = 7;
+    }
     const size_t acc_bytes = acc_bits ? (kAccEntryBytes << acc_bits) : 0;
     // The pool's field arrays have kSlotStride entries each (r3d_pool.h: a constant distance between a
     // slot's fields), 128 KB in all, and the rings one entry per slot: what is staged beside them is
     // what the remaining ~20 KB hold -- the bin accumulators first, then the scatterer heads, then
     // the cell records.
-    const size_t pool_bytes = (size_t)kSlotStride * kSlotBytes, ring_bytes = (size_t)Q_NUM * kSlotStride * sizeof(uint16_t);
     const size_t room = kLds - kStatic - pool_bytes - ring_bytes - 64 - acc_bytes;   // (64: alignment of up to four blocks)
     const bool scat_fit = scat_bytes <= room && force_res < RES_NONE;
     const bool cells_fit = scat_fit && cell_bytes + scat_bytes <= room && force_res < RES_TABLES &&
