@@ -393,6 +393,8 @@ double   r3d_kernel_ms(r3d_engine* e, uint64_t launch);
  * they compare with the oracle.                                               */
 int      r3d_engine_variant(const r3d_engine* e);
 uint32_t r3d_engine_pool_slots(const r3d_engine* e);
+/* Entries of a workgroup's table of bin accumulators in LDS (0: none -- a model without receivers).  */
+uint32_t r3d_engine_accumulators(const r3d_engine* e);
 
 /* Number of scalar counters r3d_run_device expects.                         */
 #define R3D_N_SCALARS (3 + R3D_INV_NUM + R3D_EV_NUM)

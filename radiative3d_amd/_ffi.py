@@ -252,6 +252,8 @@ def hip_lib(reproducible=None):
                                        C.POINTER(C.c_int), C.c_int, C.POINTER(Result)]
         L.r3d_engine_variant.restype = C.c_int
         L.r3d_engine_variant.argtypes = [C.c_void_p]
+        L.r3d_engine_accumulators.restype = C.c_uint32
+        L.r3d_engine_accumulators.argtypes = [C.c_void_p]
         L.r3d_engine_pool_slots.restype = C.c_uint32
         L.r3d_engine_pool_slots.argtypes = [C.c_void_p]
         L.r3d_last_error.restype = C.c_char_p

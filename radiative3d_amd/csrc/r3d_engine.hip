@@ -406,7 +406,11 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
     // rings, the bin accumulators, and beside them what fits of the small tables: the scatterer
     // heads, then the cell records (two per cell: one per ray type).
     auto align16 = [](size_t x) { return (x + 15) & ~size_t(15); };
-    const size_t kLds = 160 * 1024, kStatic = 512;   // static: queue control words, tallies (208 bytes)
+    size_t kStatic = 512;   // static: queue control words, tallies (208 bytes)
+    // R3D_LDS_RESERVE=bytes (developer and test switch): LDS the carve-up must leave alone, as if the
+    // model's tables were that much larger -- how the tests reach the paths for models with more cells
+    if (const char* s = getenv("R3D_LDS_RESERVE")) kStatic += (size_t)atoi(s) / 16 * 16;
+    const size_t kLds = 160 * 1024;
     const size_t head_bytes = (size_t)m->n_scatterers * sizeof(ScatHead);
     const size_t scat_bytes = head_bytes + (size_t)m->n_scatterers * sizeof(ScatPtrs);   // heads + table addresses
     // R3D_FORCE_RES=1 / 2 (developer and test switch): run the kernel variant that keeps the cell
@@ -418,19 +422,23 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
     if (const char* s = getenv("R3D_ACC_BITS")) acc_bits = (uint32_t)atoi(s);   // developer tuning
     if (acc_bits && acc_bits < 5) acc_bits = 0;
     const size_t pool_bytes = (size_t)kSlotStride * kSlotBytes, ring_bytes = (size_t)Q_NUM * kSlotStride * sizeof(uint16_t);
+    // what the pool, its rings and `acc` bytes of accumulators leave for tables (64: alignment of up to four blocks)
+    auto room_beside = [&](size_t acc) {
+      const size_t fixed = kStatic + pool_bytes + ring_bytes + 64 + acc;
+      return fixed < kLds ? kLds - fixed : size_t(0);
+    };
     // (a layered or spherical model whose cell records do not fit beside 256 accumulators but do beside
     //  128 gets 128: the hot first-arrival bins are a few dozen, and records from LDS are worth more)
     if (acc_bits == 8 && !getenv("R3D_ACC_BITS") && m->cell_kind != R3D_CELL_TETRA) {
-      const size_t room8 = kLds - kStatic - pool_bytes - ring_bytes - 64 - (kAccEntryBytes << 8);
-      const size_t room7 = kLds - kStatic - pool_bytes - ring_bytes - 64 - (kAccEntryBytes << 7);
-      if (cell_bytes + scat_bytes > room8 && cell_bytes + scat_bytes <= room7) acc_bits = 7;
+      if (cell_bytes + scat_bytes > room_beside(kAccEntryBytes << 8) && cell_bytes + scat_bytes <= room_beside(kAccEntryBytes << 7))
+        acc_bits = 7;
     }
     const size_t acc_bytes = acc_bits ? (kAccEntryBytes << acc_bits) : 0;
     // The pool's field arrays have kSlotStride entries each (r3d_pool.h: a constant distance between a
     // slot's fields), 128 KB in all, and the rings one entry per slot: what is staged beside them is
     // what the remaining ~20 KB hold -- the bin accumulators first, then the scatterer heads, then
     // the cell records.
-    const size_t room = kLds - kStatic - pool_bytes - ring_bytes - 64 - acc_bytes;   // (64: alignment of up to four blocks)
+    const size_t room = room_beside(acc_bytes);
     const bool scat_fit = scat_bytes <= room && force_res < RES_NONE;
     const bool cells_fit = scat_fit && cell_bytes + scat_bytes <= room && force_res < RES_TABLES &&
                            m->cell_kind != R3D_CELL_TETRA;
@@ -856,6 +864,7 @@ uint64_t r3d_launch_count(const r3d_engine* e) { return e ? e->launches : 0; }
 
 int r3d_engine_variant(const r3d_engine* e) { return e ? e->kind * 4 + e->res : -1; }
 uint32_t r3d_engine_pool_slots(const r3d_engine* e) { return e ? e->args.pool_slots : 0; }
+uint32_t r3d_engine_accumulators(const r3d_engine* e) { return e && e->args.acc_bits ? 1u << e->args.acc_bits : 0u; }
 
 double r3d_kernel_ms(r3d_engine* e, uint64_t launch) {
   if (!e || launch == 0 || launch > e->launches || e->launches - launch >= r3d_engine::kCounters) return -1.0;

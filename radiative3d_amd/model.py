@@ -417,6 +417,11 @@ class Engine:
     def pool_slots(self):
         return int(self._lib.r3d_engine_pool_slots(self._e))
 
+    @property
+    def accumulators(self):
+        """entries of a workgroup's LDS table of bin accumulators"""
+        return int(self._lib.r3d_engine_accumulators(self._e))
+
     def last_kernel_ms(self):
         return float(self._lib.r3d_last_kernel_ms(self._e))
 

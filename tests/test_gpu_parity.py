@@ -670,3 +670,23 @@ def test_bench_cpu_baseline_and_envelope_under_a_launcher():
                          "--toa-degree", "5"], launched=True, port=free_port())
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port"
     assert line["envelope"]["gpu_side"].startswith("device-built tables, each batch sharded over 1 rank")
+
+
+def test_a_model_with_more_layers_keeps_its_cells_in_lds_beside_a_smaller_accumulator_table(monkeypatch):
+    """The LDS carve-up for layered / spherical models whose cell records do not fit beside 256 bin accumulators
+    (r3d_engine.hip): 128 accumulators, cells still staged (variant residency 0).  Reached on LopNor by reserving
+    LDS as if its tables were 2.5 KB larger; the bins must not notice."""
+    m = Model(lopnor(3))
+    base = Engine(m)
+    assert base.variant == (0, 0) and base.accumulators == 256
+    monkeypatch.setenv("R3D_LDS_RESERVE", "2500")
+    e = Engine(m)
+    monkeypatch.delenv("R3D_LDS_RESERVE")
+    assert e.variant == (0, 0) and e.accumulators == 128
+    check_production_against_oracle(e, 20000)
+    # and further down: with 7000 bytes gone neither the cell records nor the scatterer heads fit -- both from L2
+    monkeypatch.setenv("R3D_LDS_RESERVE", "7000")
+    e2 = Engine(m)
+    monkeypatch.delenv("R3D_LDS_RESERVE")
+    assert e2.variant == (0, 2) and e2.accumulators == 256
+    check_production_against_oracle(e2, 5000)
