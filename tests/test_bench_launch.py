@@ -66,7 +66,8 @@ def test_a_rendezvous_port_taken_in_between_is_retried_on_a_fresh_one(monkeypatc
             "    s = socket.socket()\n"
             "    try:\n"
             "        s.bind(('127.0.0.1', int(os.environ['MASTER_PORT'])))\n"
-            "    except OSError:\n"
+            "    except OSError as exc:\n"
+            "        print(exc, file=sys.stderr)\n"   # 'Address already in use', as torch's TCPStore reports it
             "        sys.exit(1)\n")
     try:
         assert launch.spawn_ranks(2, [sys.executable, "-c", prog]) == 0
@@ -74,6 +75,37 @@ def test_a_rendezvous_port_taken_in_between_is_retried_on_a_fresh_one(monkeypatc
         assert launch.spawn_ranks(2, [sys.executable, "-c", prog], port=busy) != 0     # a named port is not replaced
     finally:
         taken.close()
+
+
+def test_an_early_crash_of_rank_0_is_not_taken_for_a_port_collision(monkeypatch):
+    """Only rank 0 failing to BIND is retried.  A crash of rank 0 after it bound the port (its sockets
+    then sit in TIME_WAIT), a crash that says nothing about the address, and a failure of another rank
+    first are returned as they are, after ONE attempt."""
+    ports = []
+    real_free_port = launch.free_port
+
+    def counting_free_port():
+        ports.append(real_free_port())
+        return ports[-1]
+
+    monkeypatch.setattr(launch, "free_port", counting_free_port)
+    crash_after_bind = ("import os, socket, sys\n"
+                        "if os.environ['RANK'] == '0':\n"
+                        "    s = socket.socket(); s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)\n"
+                        "    s.bind(('127.0.0.1', int(os.environ['MASTER_PORT']))); s.listen(1)\n"
+                        "    c = socket.create_connection(('127.0.0.1', int(os.environ['MASTER_PORT'])))\n"
+                        "    a, _ = s.accept(); a.close(); c.close(); s.close()\n"   # leaves TIME_WAIT behind
+                        "    print('engine create failed: Address already in use (not really)', file=sys.stderr)\n"
+                        "    sys.exit(3)\n")
+    assert launch.spawn_ranks(2, [sys.executable, "-c", crash_after_bind]) == 3
+    assert len(ports) == 1                       # the port is free again (nobody listens): no second start
+    silent = "import os, sys\nsys.exit(5 if os.environ['RANK'] == '0' else 0)\n"
+    assert launch.spawn_ranks(2, [sys.executable, "-c", silent]) == 5 and len(ports) == 2
+    other_rank = ("import os, sys, time\n"
+                  "if os.environ['RANK'] == '1':\n"
+                  "    print('Address already in use', file=sys.stderr); sys.exit(9)\n"
+                  "time.sleep(30)\n")
+    assert launch.spawn_ranks(2, [sys.executable, "-c", other_rank]) != 0 and len(ports) == 3
 
 
 def test_under_launcher_detection():
