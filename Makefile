@@ -12,9 +12,9 @@
 CXX      ?= g++
 HIPCC    ?= /opt/rocm/bin/hipcc
 CXXFLAGS ?= -std=c++17 -O2 -fPIC -Wall -Wno-unused-function -Wno-unknown-pragmas
-# -disable-machine-licm: the kernel is one long loop; hoisting every libm polynomial constant
-# out of it costs ~60 registers, which were then spilled and reloaded (with a full wait each)
-# inside atan2 on every iteration.  Without the hoist: 199 VGPRs, no spills, -15 % kernel time.
+# -disable-machine-licm: the kernel is one long loop; hoisting every polynomial constant out of it
+# costs ~60 registers (measured with machine-LICM on: 256 registers and 100+ spilled, DESIGN.md
+# section 6); without the hoist the three kernels hold 162-167 and fit three waves per SIMD.
 # -amdgpu-atomic-optimizer-strategy=None: the kernels' atomics on a uniform address are issued by ONE
 # lane already (a batch's tallies, the id counter); the optimiser still wraps each in its generic
 # reduction (lane election, a scalar loop over the active lanes): 1-2.5 % of the kernel time.
@@ -106,15 +106,24 @@ clean:
 	rm -f $(LIBDIR)/*.so oracle/*.so main
 	rm -rf $(OBJDIR)
 
-# Developer variants of the engine (timing-only / diagnostic builds, never shipped as libr3d_hip.so):
+# Developer variants of the engine (timing-only / diagnostic builds, never shipped as libr3d_hip.so;
+# the only builds that say -DR3D_DEV_BUILD, without which the R3D_ABLATE_* / R3D_PHASE_TIMING switches
+# are a compile error -- csrc/r3d_tables.h):
 #   make variant NAME=PHASE DEFS="-DR3D_PHASE_TIMING"   ->  radiative3d_amd/lib/variant_PHASE.so
-# run with R3D_HIP_LIB=radiative3d_amd/lib/variant_PHASE.so (tools/time_chain.py, tools/pool_stats.py)
+# run through the tools with R3D_HIP_LIB=radiative3d_amd/lib/variant_PHASE.so (tools/time_chain.py,
+# tools/pool_stats.py pass it to Engine(lib=...); the library itself reads no environment).
+# Every object is compiled afresh and each compile's status is checked: a failed one cannot leave
+# an older object to be linked in its place.
+VOBJ = $(OBJDIR)/v$(NAME)
+VDEFS = -DR3D_DEV_BUILD $(DEFS)
 variant:
 	@mkdir -p $(OBJDIR)
-	$(HIPCC) $(HIPFLAGS) $(DEFS) -c -o $(OBJDIR)/v$(NAME)_engine.o $(CSRC)/r3d_engine.hip & \
-	$(HIPCC) $(HIPFLAGS) $(DEFS) -c -o $(OBJDIR)/v$(NAME)_tables.o $(CSRC)/r3d_tables_build.hip & \
-	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_CYL) $(DEFS) $(DEFS_CYL) -DR3D_KIND=0 -c -o $(OBJDIR)/v$(NAME)_cyl.o $(CSRC)/r3d_kernels_kind.hip & \
-	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_TET) $(DEFS) $(DEFS_TET) -DR3D_KIND=1 -c -o $(OBJDIR)/v$(NAME)_tet.o $(CSRC)/r3d_kernels_kind.hip & \
-	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_SPH) $(DEFS) $(DEFS_SPH) -DR3D_KIND=2 -c -o $(OBJDIR)/v$(NAME)_sph.o $(CSRC)/r3d_kernels_kind.hip & wait
-	$(HIPCC) --offload-arch=gfx950 -shared -pthread -o $(LIBDIR)/variant_$(NAME).so $(OBJDIR)/v$(NAME)_engine.o \
-	    $(OBJDIR)/v$(NAME)_tables.o $(OBJDIR)/v$(NAME)_cyl.o $(OBJDIR)/v$(NAME)_tet.o $(OBJDIR)/v$(NAME)_sph.o
+	rm -f $(VOBJ)_engine.o $(VOBJ)_tables.o $(VOBJ)_cyl.o $(VOBJ)_tet.o $(VOBJ)_sph.o $(LIBDIR)/variant_$(NAME).so
+	$(HIPCC) $(HIPFLAGS) $(VDEFS) -c -o $(VOBJ)_engine.o $(CSRC)/r3d_engine.hip & p1=$$!; \
+	$(HIPCC) $(HIPFLAGS) $(VDEFS) -c -o $(VOBJ)_tables.o $(CSRC)/r3d_tables_build.hip & p2=$$!; \
+	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_CYL) $(VDEFS) $(DEFS_CYL) -DR3D_KIND=0 -c -o $(VOBJ)_cyl.o $(CSRC)/r3d_kernels_kind.hip & p3=$$!; \
+	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_TET) $(VDEFS) $(DEFS_TET) -DR3D_KIND=1 -c -o $(VOBJ)_tet.o $(CSRC)/r3d_kernels_kind.hip & p4=$$!; \
+	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_SPH) $(VDEFS) $(DEFS_SPH) -DR3D_KIND=2 -c -o $(VOBJ)_sph.o $(CSRC)/r3d_kernels_kind.hip & p5=$$!; \
+	rc=0; for p in $$p1 $$p2 $$p3 $$p4 $$p5; do wait $$p || rc=1; done; exit $$rc
+	$(HIPCC) --offload-arch=gfx950 -shared -pthread -o $(LIBDIR)/variant_$(NAME).so $(VOBJ)_engine.o \
+	    $(VOBJ)_tables.o $(VOBJ)_cyl.o $(VOBJ)_tet.o $(VOBJ)_sph.o

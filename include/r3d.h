@@ -221,6 +221,21 @@ typedef struct r3d_engine r3d_engine;   /* opaque: tables resident in HBM   */
  * layout.  Returns NULL on error (see r3d_last_error).  Thread-compatible:
  * one engine per thread.                                                   */
 r3d_engine* r3d_engine_create(const r3d_model_desc* model, int device);
+/* The same with the kernel's LDS carve-up in the caller's hands -- for tests that must reach a
+ * given compiled kernel variant on a small model, and for tuning runs.  r3d_engine_create is this
+ * call with opts == NULL: every field automatic.  The library reads no environment variable.   */
+typedef struct r3d_engine_opts {
+  uint32_t size;             /* sizeof(r3d_engine_opts): a mismatch is refused                  */
+  int32_t  residency;        /* -1 automatic; else run at least this far down the list of table
+                                residencies: 0 cell records + scatterer heads staged in LDS,
+                                1 the heads only, 2 neither (r3d_engine_variant)                */
+  uint32_t pool_slots;       /* history slots of a workgroup's pool: 0 = 1024 (all of them);
+                                rounded down to a multiple of 64, at least the workgroup size   */
+  int32_t  accumulator_bits; /* -1 automatic; 0 no bin accumulators in LDS; 5..8: 2^bits entries */
+  uint32_t lds_reserve;      /* bytes of LDS the carve-up leaves alone, as if the model's tables
+                                were that much larger                                            */
+} r3d_engine_opts;
+r3d_engine* r3d_engine_create_ex(const r3d_model_desc* model, int device, const r3d_engine_opts* opts);
 void        r3d_engine_destroy(r3d_engine* e);
 /* Checked form of destroy: waits for the engine's launches, and REFUSES (returns
  * nonzero, engine left intact) while histories carried over by r3d_run_device_carry

@@ -176,21 +176,26 @@ def host_lib():
     return _host
 
 
-def hip_lib(reproducible=None):
+class EngineOpts(C.Structure):
+    """include/r3d.h r3d_engine_opts"""
+    _fields_ = [("size", C.c_uint32), ("residency", C.c_int32), ("pool_slots", C.c_uint32),
+                ("accumulator_bits", C.c_int32), ("lds_reserve", C.c_uint32)]
+
+
+def hip_lib(reproducible=False, path=None):
     """libr3d_hip.so: the HIP engine.  Fails loudly when it was not built.
 
-    reproducible (default: the environment's R3D_REPRODUCIBLE=1): libr3d_hip_repro.so, the same
-    engine built with -DR3D_REPRODUCIBLE -- no wave-voted series choices (csrc/r3d_math.h
-    all_lanes), so a history's result is bit-defined by (model, seed, id)."""
-    if reproducible is None:
-        reproducible = os.environ.get("R3D_REPRODUCIBLE", "0") not in ("", "0")
-    key = bool(reproducible)
+    reproducible: libr3d_hip_repro.so, the same engine built with -DR3D_REPRODUCIBLE -- no
+    wave-voted series choices (csrc/r3d_math.h all_lanes), so a history's result is bit-defined by
+    (model, seed, id).  path: another build of the engine (a `make variant` library, tools/); nothing
+    here or in the library reads the environment."""
+    key = os.path.abspath(path) if path else bool(reproducible)
     if key not in _hip:
-        # R3D_HIP_LIB: developer override used by tools/ to time experimental builds
-        L = _load(os.environ.get("R3D_HIP_LIB") or
-                  os.path.join(LIBDIR, "libr3d_hip_repro.so" if key else "libr3d_hip.so"))
+        L = _load(path or os.path.join(LIBDIR, "libr3d_hip_repro.so" if reproducible else "libr3d_hip.so"))
         L.r3d_engine_create.restype = C.c_void_p
         L.r3d_engine_create.argtypes = [C.POINTER(ModelDesc), C.c_int]
+        L.r3d_engine_create_ex.restype = C.c_void_p
+        L.r3d_engine_create_ex.argtypes = [C.POINTER(ModelDesc), C.c_int, C.POINTER(EngineOpts)]
         L.r3d_engine_destroy.argtypes = [C.c_void_p]
         L.r3d_energy_len.restype = C.c_size_t
         L.r3d_energy_len.argtypes = [C.c_void_p]

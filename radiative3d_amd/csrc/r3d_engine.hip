@@ -246,9 +246,29 @@ extern "C" {
 const char* r3d_last_error(void) { return g_error.c_str(); }
 const char* r3d_version(void) { return "radiative3d_amd engine r1 (gfx950, fp64)"; }
 
-r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
+r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) { return r3d_engine_create_ex(m, device, nullptr); }
+
+r3d_engine* r3d_engine_create_ex(const r3d_model_desc* m, int device, const r3d_engine_opts* opts) {
   r3d_engine* const fail_value = nullptr;
   if (!check_model(m)) return nullptr;
+  // The carve-up's knobs (include/r3d.h r3d_engine_opts): defaults unless the caller -- a test that must
+  // reach a given kernel variant on a small model, a tuning run -- names them.  Nothing here reads the
+  // environment.
+  r3d_engine_opts o;
+  o.size = sizeof o, o.residency = -1, o.pool_slots = 0, o.accumulator_bits = -1, o.lds_reserve = 0;
+  if (opts) {
+    if (opts->size != sizeof(r3d_engine_opts))
+      return g_error = "r3d_engine_opts.size does not match this library's sizeof(r3d_engine_opts)", nullptr;
+    o = *opts;
+    if (o.residency < -1 || o.residency > RES_NONE)
+      return g_error = "r3d_engine_opts.residency must be -1 (automatic), 0, 1 or 2", nullptr;
+    if (o.accumulator_bits < -1 || o.accumulator_bits > 8 || (o.accumulator_bits > 0 && o.accumulator_bits < 5))
+      return g_error = "r3d_engine_opts.accumulator_bits must be -1 (automatic), 0 (none) or 5..8", nullptr;
+    if (o.pool_slots > kSlotStride)
+      return g_error = "r3d_engine_opts.pool_slots exceeds the pool's 1024 slots", nullptr;
+    if (o.lds_reserve > 160u * 1024u)
+      return g_error = "r3d_engine_opts.lds_reserve exceeds the 160 KB of a CU", nullptr;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
     g_error = "no HIP device available: the engine has no CPU path";
@@ -406,21 +426,25 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
     // rings, the bin accumulators, and beside them what fits of the small tables: the scatterer
     // heads, then the cell records (two per cell: one per ray type).
     auto align16 = [](size_t x) { return (x + 15) & ~size_t(15); };
-    size_t kStatic = 512;   // static: queue control words, tallies (208 bytes)
-    // R3D_LDS_RESERVE=bytes (developer and test switch): LDS the carve-up must leave alone, as if the
-    // model's tables were that much larger -- how the tests reach the paths for models with more cells
-    if (const char* s = getenv("R3D_LDS_RESERVE")) kStatic += (size_t)atoi(s) / 16 * 16;
+    // static LDS of the kernel: queue control words and tallies, 208 bytes; the diagnostic builds'
+    // per-phase timers (R3D_PHASE_TIMING, make variant) add 320
+#ifdef R3D_PHASE_TIMING
+    size_t kStatic = 1024;
+#else
+    size_t kStatic = 512;
+#endif
+    // opts.lds_reserve: LDS the carve-up must leave alone, as if the model's tables were that much
+    // larger -- how the tests reach the paths for models with more cells
+    kStatic += (size_t)o.lds_reserve / 16 * 16;
     const size_t kLds = 160 * 1024;
     const size_t head_bytes = (size_t)m->n_scatterers * sizeof(ScatHead);
     const size_t scat_bytes = head_bytes + (size_t)m->n_scatterers * sizeof(ScatPtrs);   // heads + table addresses
-    // R3D_FORCE_RES=1 / 2 (developer and test switch): run the kernel variant that keeps the cell
-    // records (1) or also the scatterer heads (2) in HBM although they would fit in LDS, so that
-    // every compiled variant can be held against the oracle on any model
-    int force_res = 0;
-    if (const char* s = getenv("R3D_FORCE_RES")) force_res = atoi(s);
+    // opts.residency = 1 / 2: run the kernel variant that keeps the cell records (1) or also the
+    // scatterer heads (2) in HBM although they would fit in LDS, so that every compiled variant can
+    // be held against the oracle on any model
+    const int force_res = o.residency < 0 ? 0 : o.residency;
     uint32_t acc_bits = m->n_seismometers > 0 ? 8u : 0u;   // 256 accumulators = 13 KB ...
-    if (const char* s = getenv("R3D_ACC_BITS")) acc_bits = (uint32_t)atoi(s);   // developer tuning
-    if (acc_bits && acc_bits < 5) acc_bits = 0;
+    if (o.accumulator_bits >= 0) acc_bits = (uint32_t)o.accumulator_bits;
     const size_t pool_bytes = (size_t)kSlotStride * kSlotBytes, ring_bytes = (size_t)Q_NUM * kSlotStride * sizeof(uint16_t);
     // what the pool, its rings and `acc` bytes of accumulators leave for tables (64: alignment of up to four blocks)
     auto room_beside = [&](size_t acc) {
@@ -429,7 +453,7 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
     };
     // (a layered or spherical model whose cell records do not fit beside 256 accumulators but do beside
     //  128 gets 128: the hot first-arrival bins are a few dozen, and records from LDS are worth more)
-    if (acc_bits == 8 && !getenv("R3D_ACC_BITS") && m->cell_kind != R3D_CELL_TETRA) {
+    if (acc_bits == 8 && o.accumulator_bits < 0 && m->cell_kind != R3D_CELL_TETRA) {
       if (cell_bytes + scat_bytes > room_beside(kAccEntryBytes << 8) && cell_bytes + scat_bytes <= room_beside(kAccEntryBytes << 7))
         acc_bits = 7;
     }
@@ -454,8 +478,8 @@ r3d_engine* r3d_engine_create(const r3d_model_desc* m, int device) {
     a.lds_acc_off = (uint32_t)off, a.acc_bits = acc_bits;
     if (acc_bits) off = align16(off + acc_bytes);
     uint32_t slots = kSlotStride, cap = kSlotStride;
-    if (const char* s = getenv("R3D_POOL_SLOTS")) {   // developer tuning: fewer slots in circulation
-      uint32_t want = (uint32_t)atoi(s) / 64 * 64;   // at least a slot per lane of the workgroup
+    if (o.pool_slots) {   // fewer slots in circulation (tests of a crowded pool, tuning)
+      uint32_t want = o.pool_slots / 64 * 64;   // at least a slot per lane of the workgroup
       if (want < (uint32_t)kPoolBlock) want = (uint32_t)kPoolBlock;
       if (want < slots) {
         slots = want, cap = 64;

@@ -76,7 +76,6 @@ inline void build_seis_grid(const r3d_model_desc& m, SeisGrid& g, std::vector<ui
   std::vector<double> sorted = rad;
   std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
   double h = std::max(0.25 * sorted[n / 2], 1e-6);
-  if (const char* e = getenv("R3D_SEIS_GRID_FACTOR")) h = std::max(atof(e) * sorted[n / 2], 1e-6);   // developer tuning
   int d[3];
   auto dims_for = [&](double hh) {
     double cells = 1;
@@ -151,9 +150,7 @@ inline void build_guide_cells(const double* cdf, uint64_t n, uint32_t bits, std:
 }
 inline uint32_t guide_bits_for(uint64_t n_toa) {
   uint32_t bits = 4;
-  int per = 2, cap = 20;   // ~2^per entries per bracket, at most 2^cap guide entries
-  if (const char* e = getenv("R3D_GUIDE_PER")) per = atoi(e);   // developer tuning
-  if (const char* e = getenv("R3D_GUIDE_CAP")) cap = atoi(e);
+  const int per = 2, cap = 20;   // ~2^per entries per bracket, at most 2^cap guide entries
   while ((int)bits < cap && (1ull << (bits + per)) < n_toa) bits++;
   return bits;
 }

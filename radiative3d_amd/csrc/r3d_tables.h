@@ -17,6 +17,16 @@
 
 #include <stdint.h>
 
+// Timing-only developer switches: R3D_ABLATE_* cut a part of the work out of the kernel (one of them,
+// R3D_ABLATE_RT, changes the physics) and R3D_PHASE_TIMING adds per-phase cycle counters.  They exist
+// in `make variant` builds, which say -DR3D_DEV_BUILD; the shipped libraries (`make all`) never define
+// it, and with this guard no build without it can contain any of them (tests/test_abi.py holds the
+// Makefile and this list against the sources).
+#if !defined(R3D_DEV_BUILD) && (defined(R3D_ABLATE_CATCH) || defined(R3D_ABLATE_COLLECT) || defined(R3D_ABLATE_RT) || \
+                                defined(R3D_ABLATE_SPRAY_SEARCH) || defined(R3D_ABLATE_SCATTER) || defined(R3D_PHASE_TIMING))
+#error "R3D_ABLATE_* / R3D_PHASE_TIMING are developer-build switches: build with -DR3D_DEV_BUILD (make variant)"
+#endif
+
 namespace r3d {
 
 // face flag byte (same bit values as include/r3d.h)

@@ -238,13 +238,23 @@ def volume_desc(origin, cell_size, dims, n_frames, frame_dt):
 class Engine:
     """The model resident in HBM + the HIP traversal kernels (libr3d_hip.so)."""
 
-    def __init__(self, model, device=0, reproducible=None):
-        """reproducible: None = as the environment says (R3D_REPRODUCIBLE=1), True / False = the
-        build without / with wave-voted series choices (see _ffi.hip_lib)."""
-        self._lib = _ffi.hip_lib(reproducible)
+    def __init__(self, model, device=0, reproducible=False, lib=None, residency=None, pool_slots=None,
+                 accumulator_bits=None, lds_reserve=None):
+        """reproducible: the build without wave-voted series choices (see _ffi.hip_lib); lib: the path
+        of another build of the engine (tools/).  residency, pool_slots, accumulator_bits, lds_reserve:
+        the kernel's LDS carve-up in the caller's hands (include/r3d.h r3d_engine_opts) -- how the
+        tests reach every compiled kernel variant on small models; None = automatic, and with all
+        four None the engine is made by plain r3d_engine_create."""
+        self._lib = _ffi.hip_lib(reproducible, lib)
         self.model = model
         self._volume_keepalive = None
-        self._e = self._lib.r3d_engine_create(model.desc_p, device)
+        if residency is None and pool_slots is None and accumulator_bits is None and lds_reserve is None:
+            self._e = self._lib.r3d_engine_create(model.desc_p, device)
+        else:
+            o = _ffi.EngineOpts(C.sizeof(_ffi.EngineOpts), -1 if residency is None else residency,
+                                pool_slots or 0, -1 if accumulator_bits is None else accumulator_bits,
+                                lds_reserve or 0)
+            self._e = self._lib.r3d_engine_create_ex(model.desc_p, device, C.byref(o))
         if not self._e:
             raise RuntimeError("r3d_engine_create failed: " + self._lib.r3d_last_error().decode())
         if model.device_tables:   # mean free paths / dipoles are the engine's output

@@ -99,3 +99,51 @@ def test_headers_are_strict_c99_and_the_c_example_links(tmp_path):
                          + ["--num-phonons=1000"], capture_output=True, text=True)
     if out.returncode != 0:
         assert "no HIP device" in out.stderr or "no CPU path" in out.stderr, out.stderr
+
+
+def test_the_shipped_engine_reads_no_environment_and_holds_no_developer_switch():
+    """The library a maintainer links takes its knobs through r3d_engine_create_ex (include/r3d.h
+    r3d_engine_opts), never from the environment; the timing-only R3D_ABLATE_* / R3D_PHASE_TIMING blocks
+    exist only under -DR3D_DEV_BUILD, which `make all` never says."""
+    csrc = os.path.join(_ffi.REPO, "radiative3d_amd", "csrc")
+    switches = set()
+    for f in sorted(os.listdir(csrc)):
+        text = open(os.path.join(csrc, f)).read()
+        code = re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", text, flags=re.S))
+        assert "getenv" not in code, f
+        switches |= set(re.findall(r"#\s*if\w*\s+!?(?:defined\()?(R3D_ABLATE_\w+|R3D_PHASE_TIMING)", code))
+    # every switch used anywhere is named in the one guard of r3d_tables.h
+    guard = re.search(r"#if !defined\(R3D_DEV_BUILD\) && \((.*?)\)\n#error", open(os.path.join(csrc, "r3d_tables.h")).read(), re.S)
+    assert guard, "the R3D_DEV_BUILD guard is gone from r3d_tables.h"
+    assert switches and switches <= set(re.findall(r"defined\((\w+)\)", guard.group(1))), switches
+    # `make all` never defines it: only the variant target's VDEFS does
+    mk = open(os.path.join(_ffi.REPO, "Makefile")).read()
+    assert [l for l in mk.splitlines() if "R3D_DEV_BUILD" in l and not l.startswith("#")] == ["VDEFS = -DR3D_DEV_BUILD $(DEFS)"]
+    # and the built libraries carry no R3D_* names but the header's own constants (which error messages quote)
+    header = open(os.path.join(INCLUDE, "r3d.h")).read()
+    for so in ("libr3d_hip.so", "libr3d_hip_repro.so"):
+        blob = open(os.path.join(_ffi.LIBDIR, so), "rb").read()
+        names = {n.decode() for n in set(re.findall(rb"R3D_[A-Z_]{3,}", blob))}
+        assert not {n for n in names if not re.search(r"\b" + n + r"\b", header)}, (so, names)
+    for py in ("_ffi.py", "model.py", "parallel.py", "launch.py"):
+        assert "environ.get(\"R3D_" not in open(os.path.join(_ffi.REPO, "radiative3d_amd", py)).read(), py
+
+
+def test_engine_opts_mirror_matches_c_layout(tmp_path):
+    prog = r'''
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "r3d.h"
+    int main(void) {
+      printf("%zu %zu %zu %zu %zu %zu\n", sizeof(r3d_engine_opts), offsetof(r3d_engine_opts, residency),
+             offsetof(r3d_engine_opts, pool_slots), offsetof(r3d_engine_opts, accumulator_bits),
+             offsetof(r3d_engine_opts, lds_reserve), offsetof(r3d_engine_opts, size));
+      return 0;
+    }'''
+    src = tmp_path / "s.c"
+    src.write_text(prog)
+    subprocess.check_call(["gcc", "-std=c99", "-I", INCLUDE, "-o", str(tmp_path / "s"), str(src)])
+    got = [int(x) for x in subprocess.check_output([str(tmp_path / "s")]).split()]
+    E = _ffi.EngineOpts
+    assert got == [C.sizeof(E), E.residency.offset, E.pool_slots.offset, E.accumulator_bits.offset,
+                   E.lds_reserve.offset, E.size.offset]

@@ -6,8 +6,8 @@ import numpy as np
 import pytest
 
 import emul_ffi as E
-from conftest import finals_differ
 from oracle import oracle_ffi as O
+from oracle.check import assert_aggregates_equal, assert_aggregates_equal_without, forked_ids
 from radiative3d_amd import Model
 from tests.configs import halfspace
 
@@ -15,14 +15,40 @@ from tests.configs import halfspace
 def compare(model, n, first_id=0, seed=0x5EED, allow=0):
     ro, fo = O.run(model, n, first_id, seed, trace=True)
     re, fe = E.run(model, n, first_id, seed, trace=True)
-    bad = sum(finals_differ(a, b) for a, b in zip(fe, fo))
-    assert bad <= allow, f"{bad} of {n} histories differ"
-    assert (ro.n_lost, ro.n_timeout, ro.n_invalid) == (re.n_lost, re.n_timeout, re.n_invalid)
-    if bad == 0:
-        assert ro.events == re.events
-        assert (ro.counts == re.counts).all()
-        assert np.allclose(ro.energy, re.energy, rtol=1e-9, atol=1e-13)
+    forked = forked_ids(fe, fo, first_id)
+    assert len(forked) <= allow, f"{len(forked)} of {n} histories differ: ids {forked[:20]}"
+    # (the aggregates on every path: forked histories are taken out of both sides, oracle/check.py)
+    assert_aggregates_equal_without(re, ro, forked, lambda k, i: E.run(model, k, i, seed),
+                                    lambda k, i: O.run(model, k, i, seed))
     return ro, re
+
+
+def test_the_checker_still_compares_aggregates_when_a_history_forks(models):
+    """oracle/check.py: a forked history is taken out of both sides and everything else is still held
+    bin for bin -- a run with a fork AND a wrong bin elsewhere fails; a run with only the fork passes."""
+    import copy
+    model, n, seed = models("crustpinch"), 600, 0x5EED
+    want, wf = O.run(model, n, 0, seed, trace=True)
+    victim = next(i for i, f in enumerate(wf) if f.n_catch > 0)      # a history that was caught somewhere
+    stand_in = O.run(model, 1, 10**6, seed)                           # what the "engine" made of it instead
+    own = O.run(model, 1, victim, seed)
+    got = copy.deepcopy(want)
+    got.energy += stand_in.energy - own.energy
+    got.counts += stand_in.counts
+    got.counts -= own.counts
+    for k in got.events:
+        got.events[k] += stand_in.events[k] - own.events[k]
+    got.n_lost += stand_in.n_lost - own.n_lost
+    got.n_timeout += stand_in.n_timeout - own.n_timeout
+    with pytest.raises(AssertionError):
+        assert_aggregates_equal(got, want)                            # the fork shows in the totals ...
+    run_engine = lambda k, i: stand_in if i == victim else O.run(model, k, i, seed)   # noqa: E731
+    run_oracle = lambda k, i: O.run(model, k, i, seed)                                  # noqa: E731
+    assert_aggregates_equal_without(got, want, [victim], run_engine, run_oracle)       # ... and is accounted for
+    s, b = np.argwhere(want.counts.sum(-1) > 0)[-1]
+    got.counts[s, b, 0] += 1                                           # a wrong bin that no fork explains
+    with pytest.raises(AssertionError):
+        assert_aggregates_equal_without(got, want, [victim], run_engine, run_oracle)
 
 
 @pytest.mark.parametrize("name,n", [("halfspace", 20000), ("crustpinch", 4000), ("lopnor", 4000),

@@ -8,6 +8,7 @@ import torch
 
 from conftest import finals_differ
 from oracle import oracle_ffi as O
+from oracle.check import assert_aggregates_equal, assert_aggregates_equal_without, forked_ids
 from radiative3d_amd import Engine, Model, _ffi
 from radiative3d_amd.parallel import DeviceResult, shard_range
 from tests.configs import crustpinch, halfspace, lopnor, sphere_deep
@@ -27,35 +28,28 @@ def engines(models):
     return get
 
 
-def check_against_oracle(engine, n, first_id=0, seed=0x5EED, allow_frac=0.0005):
+def check_against_oracle(engine, n, first_id=0, seed=0x5EED, allow_frac=0.0):
+    """History by history against the oracle, then the aggregates.  allow_frac: share of histories
+    that may fork (device libm vs glibc in the last ulp under a branch decision; none has been
+    seen, and only the TOA-degree-9 samples ask for any): their ids are printed, and the aggregates
+    are compared all the same, with those histories' own contributions taken out of both sides
+    (oracle/check.py) -- no path passes without an aggregate comparison."""
     model = engine.model
     rg, fg = engine.run(n, first_id, seed, trace=True)
     ro, fo = O.run(model, n, first_id, seed, trace=True)
-    bad = sum(finals_differ(a, b) for a, b in zip(fg, fo))
-    # device libm vs glibc differ in the last ulp; a history whose branch
-    # decision sits on such a bit may legitimately fork.  None has been seen.
-    assert bad <= int(allow_frac * n), f"{bad} of {n} histories differ from the oracle"
+    forked = forked_ids(fg, fo, first_id)
+    if forked:
+        print(f"forked histories (engine vs oracle): ids {forked}")
+    assert len(forked) <= int(allow_frac * n), f"{len(forked)} of {n} histories differ from the oracle: ids {forked[:20]}"
     assert rg.n_lost + rg.n_timeout + rg.n_invalid == n
-    if bad == 0:
-        assert (rg.n_lost, rg.n_timeout, rg.n_invalid) == (ro.n_lost, ro.n_timeout, ro.n_invalid)
-        assert rg.events == ro.events
-        assert (rg.counts == ro.counts).all()                       # integer work: bit-exact
-        assert np.allclose(rg.energy, ro.energy, rtol=1e-9, atol=1e-13)  # fp64: 1e-9 relative
+    assert_aggregates_equal_without(rg, ro, forked, lambda k, i: engine.run(k, i, seed),
+                                    lambda k, i: O.run(model, k, i, seed), "diagnostic kernel")
     return rg, ro
 
 
 def assert_result_equals_oracle(got, want, what):
-    """Aggregate comparison for runs without per-history records: every integer output bit-exact
-    (counts per seismometer, bin and type; lost / timeout / invalid; the 8 event counters), the
-    invalid reasons as the per-history suite holds them (their sum: which of "negative time" /
-    "stuck" / "slow" a trapped phonon is filed under sits on the sign of rounding noise),
-    energies to 1e-9 relative (device libm vs glibc)."""
-    assert (got.n_lost, got.n_timeout, got.n_invalid) == (want.n_lost, want.n_timeout, want.n_invalid), what
-    assert got.events == want.events, what
-    assert int(got.invalid_reasons.sum()) == int(want.invalid_reasons.sum()) == got.n_invalid, what
-    assert (got.invalid_reasons[[0, 1, 2, 6]] == want.invalid_reasons[[0, 1, 2, 6]]).all(), what
-    assert (got.counts == want.counts).all(), what
-    assert np.allclose(got.energy, want.energy, rtol=1e-9, atol=1e-13), what
+    """Aggregate comparison for runs without per-history records (oracle/check.py)."""
+    assert_aggregates_equal(got, want, what)
 
 
 def check_production_against_oracle(engine, n, first_id=0, seed=0x5EED, pieces=4):
@@ -82,7 +76,7 @@ def check_production_against_oracle(engine, n, first_id=0, seed=0x5EED, pieces=4
 
 
 # (cell kind, table residency) of every compiled traversal kernel and a model that runs it; residency 1 / 2
-# on models whose tables would fit in LDS is forced with R3D_FORCE_RES.  tests/test_kernel_coverage.py (CPU)
+# on models whose tables would fit in LDS is asked for through r3d_engine_create_ex (Engine(residency=...)).  tests/test_kernel_coverage.py (CPU)
 # holds this list against the symbols in libr3d_hip.so.
 KERNEL_CASES = [(0, 0, "lopnor", 6000), (0, 1, "lopnor", 6000), (0, 2, "halfspace", 20000),
                 (1, 1, "crustpinch", 8000), (1, 2, "upthrust", 8000),
@@ -93,8 +87,7 @@ KERNEL_CASES = [(0, 0, "lopnor", 6000), (0, 1, "lopnor", 6000), (0, 2, "halfspac
 def test_every_compiled_kernel_matches_oracle(models, monkeypatch, kind, res, name, n):
     """pool_kernel<kind, res, TRACE>, pool_kernel<kind, res, production> and pool_drain_kernel<kind, res>
     each against the oracle; the engine says which variant it launches."""
-    monkeypatch.setenv("R3D_FORCE_RES", str(res))
-    e = Engine(models(name))
+    e = Engine(models(name), residency=res)
     assert e.variant == (kind, res)
     check_against_oracle(e, n, first_id=17)                   # the diagnostic kernel (final records)
     check_production_against_oracle(e, n, first_id=17)        # the production kernel and the drain kernel
@@ -110,15 +103,11 @@ def test_production_kernel_matches_oracle(engines, name, n):
 def test_production_kernel_small_pool_and_many_receivers(models, monkeypatch):
     """The production kernels under the queue stress of test_small_pool_many_short_launches (the
     smallest pool, no bin accumulators) and with 4500 receivers (every catch through the hash)."""
-    monkeypatch.setenv("R3D_POOL_SLOTS", "64")
-    monkeypatch.setenv("R3D_ACC_BITS", "0")
     for name, n in (("crustpinch", 20000), ("lopnor", 20000), ("sphere_deep", 2000)):
-        e = Engine(models(name))
-        assert e.pool_slots == 768
+        e = Engine(models(name), pool_slots=64, accumulator_bits=0)   # (64: clamped up to the workgroup size)
+        assert e.pool_slots == 768 and e.accumulators == 0
         check_production_against_oracle(e, n, first_id=3, pieces=7)
         e.close()
-    monkeypatch.delenv("R3D_POOL_SLOTS")
-    monkeypatch.delenv("R3D_ACC_BITS")
     args = [a for a in halfspace(4) if not a.startswith("--seis-p2p")] + [
         "--seis-p2p=0,0,0,183.85,183.85,0,2.737,0.105,10.0,1500",
         "--seis-p2p=0,0,0,260,0,0,2.737,0.105,10.0,1500",
@@ -248,7 +237,7 @@ def test_full_size_crustpinch_properties():
     assert abs(z.mean()) < 0.4 and 0.9 < z.std() < 1.5
     assert a.energy.sum() == pytest.approx(b.energy.sum(), rel=0.02)
     # small-sample oracle comparison on the big tables too: diagnostic and production kernels
-    check_against_oracle(e, 3000, first_id=123456789)
+    check_against_oracle(e, 3000, first_id=123456789, allow_frac=0.0005)
     check_production_against_oracle(e, 3000, first_id=123456789)
 
 
@@ -297,7 +286,7 @@ def test_full_size_lopnor_properties():
     a, b = independent_halves_agree(e, n, 3000)
     assert a.n_invalid == 0 and a.energy.sum() == pytest.approx(b.energy.sum(), rel=0.03)
     reference_event_mix(e, "lopnor", a, n)
-    check_against_oracle(e, 3000, first_id=987654321)
+    check_against_oracle(e, 3000, first_id=987654321, allow_frac=0.0005)
     check_production_against_oracle(e, 3000, first_id=987654321)
     e.close()
 
@@ -314,7 +303,7 @@ def test_full_size_sphere_deep_source_properties():
     a, b = independent_halves_agree(e, n, 3000)
     assert a.n_timeout == n and a.n_invalid == 0
     assert a.events["scatter"] / n > 50 and a.events["rtsolve"] / n > 20
-    check_against_oracle(e, 1500, first_id=24680)
+    check_against_oracle(e, 1500, first_id=24680, allow_frac=0.0005)
     check_production_against_oracle(e, 1500, first_id=24680)
     e.close()
     from tests.configs import sphere
@@ -517,10 +506,8 @@ def test_small_pool_many_short_launches(models, monkeypatch):
     accumulators, and a carry chain of many launches far smaller than the pool (most workgroups
     find the id counter exhausted at once and park an almost empty pool) -- against the oracle
     and against one self-contained run."""
-    monkeypatch.setenv("R3D_POOL_SLOTS", "64")      # clamped up to the workgroup size
-    monkeypatch.setenv("R3D_ACC_BITS", "0")
     for name, n in (("crustpinch", 20000), ("lopnor", 20000), ("sphere_deep", 2000)):
-        e = Engine(models(name))
+        e = Engine(models(name), pool_slots=64, accumulator_bits=0)      # (64: clamped up to the workgroup size)
         check_against_oracle(e, n, first_id=3)
         want = e.run(n, first_id=10**6, seed=21)
         total, step = DeviceResult(e.model, "cuda:0"), DeviceResult(e.model, "cuda:0")
@@ -593,11 +580,8 @@ def test_reproducible_build_defines_every_history_to_the_bit(models, monkeypatch
 
     for name, n in (("crustpinch", 30000), ("lopnor", 20000), ("sphere_deep", 3000)):
         m = models(name)
-        monkeypatch.delenv("R3D_POOL_SLOTS", raising=False)
         big = Engine(m, reproducible=True)
-        monkeypatch.setenv("R3D_POOL_SLOTS", "768")
-        small = Engine(m, reproducible=True)
-        monkeypatch.delenv("R3D_POOL_SLOTS")
+        small = Engine(m, reproducible=True, pool_slots=768)
         assert big.pool_slots > small.pool_slots == 768
         ra, fa = big.run(n, first_id=5, seed=3, trace=True)
         rb, fb = small.run(n, first_id=5, seed=3, trace=True)
@@ -632,8 +616,7 @@ def _bench_child(extra_args, launched, port=None):
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items()
-           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "R3D_FORCE_RES",
-                        "R3D_POOL_SLOTS", "R3D_ACC_BITS")}
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
     if launched:
         env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -679,14 +662,10 @@ def test_a_model_with_more_layers_keeps_its_cells_in_lds_beside_a_smaller_accumu
     m = Model(lopnor(3))
     base = Engine(m)
     assert base.variant == (0, 0) and base.accumulators == 256
-    monkeypatch.setenv("R3D_LDS_RESERVE", "2500")
-    e = Engine(m)
-    monkeypatch.delenv("R3D_LDS_RESERVE")
+    e = Engine(m, lds_reserve=2500)
     assert e.variant == (0, 0) and e.accumulators == 128
     check_production_against_oracle(e, 20000)
     # and further down: with 7000 bytes gone neither the cell records nor the scatterer heads fit -- both from L2
-    monkeypatch.setenv("R3D_LDS_RESERVE", "7000")
-    e2 = Engine(m)
-    monkeypatch.delenv("R3D_LDS_RESERVE")
+    e2 = Engine(m, lds_reserve=7000)
     assert e2.variant == (0, 2) and e2.accumulators == 256
     check_production_against_oracle(e2, 5000)

@@ -7,7 +7,7 @@ import numpy as np
 from radiative3d_amd import Model, Engine
 from radiative3d_amd.configs import crustpinch
 from bench import envelope_agreement, batch_moments
-m = Model(crustpinch(9) + ["--device-tables"]); e = Engine(m)
+m = Model(crustpinch(9) + ["--device-tables"]); e = Engine(m, lib=os.environ.get("R3D_HIP_LIB"))
 def batches(k, per, base):
     es, cs = [], []
     for b in range(k):

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from radiative3d_amd import Model, Engine
 from radiative3d_amd.configs import CONFIGS
 name, deg = sys.argv[1], int(sys.argv[2])
-m = Model(CONFIGS[name](deg) + ["--device-tables"]); e = Engine(m)
+m = Model(CONFIGS[name](deg) + ["--device-tables"]); e = Engine(m, lib=os.environ.get("R3D_HIP_LIB"))
 e.run(1_000_000)
 rows = []
 for n in (100_000, 1_000_000, 2_000_000, 5_000_000, 10_000_000, 20_000_000, 50_000_000, 100_000_000):

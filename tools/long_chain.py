@@ -7,7 +7,7 @@ from radiative3d_amd import Model, Engine
 from radiative3d_amd.parallel import DeviceResult
 from radiative3d_amd.configs import CONFIGS
 name, deg, n, k = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-m = Model(CONFIGS[name](deg) + ["--device-tables"]); e = Engine(m)
+m = Model(CONFIGS[name](deg) + ["--device-tables"]); e = Engine(m, lib=os.environ.get("R3D_HIP_LIB"))
 total, buf = DeviceResult(m, "cuda:0"), DeviceResult(m, "cuda:0")
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(k):

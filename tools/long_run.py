@@ -5,7 +5,7 @@ from radiative3d_amd import Model, Engine
 from radiative3d_amd.configs import CONFIGS
 name, deg, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 10_000_000
-m = Model(CONFIGS[name](deg)); e = Engine(m); res = m.new_result()
+m = Model(CONFIGS[name](deg)); e = Engine(m, lib=os.environ.get("R3D_HIP_LIB")); res = m.new_result()
 t0 = time.time(); done = 0; kms = 0.0
 while done < n:
     c = min(chunk, n - done)

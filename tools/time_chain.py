@@ -8,7 +8,7 @@ from radiative3d_amd.parallel import DeviceResult
 from radiative3d_amd.configs import CONFIGS
 name, deg, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 k = int(sys.argv[4]) if len(sys.argv) > 4 else 6
-m = Model(CONFIGS[name](deg) + ["--device-tables"]); e = Engine(m)
+m = Model(CONFIGS[name](deg) + ["--device-tables"]); e = Engine(m, lib=os.environ.get("R3D_HIP_LIB"))
 buf = DeviceResult(m, "cuda:0")
 ms = []
 for i in range(k + 1):

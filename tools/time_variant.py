@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from radiative3d_amd import Model, Engine
 from radiative3d_amd.configs import CONFIGS
 name, deg, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-m = Model(CONFIGS[name](deg)); e = Engine(m)
+m = Model(CONFIGS[name](deg)); e = Engine(m, lib=os.environ.get("R3D_HIP_LIB"))
 e.run(n // 10)
 best = 1e9
 for rep in range(3):

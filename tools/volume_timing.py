@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from radiative3d_amd import Model, Engine
 from radiative3d_amd.configs import crustpinch
-m = Model(crustpinch(9) + ["--device-tables"]); e = Engine(m)
+m = Model(crustpinch(9) + ["--device-tables"]); e = Engine(m, lib=os.environ.get("R3D_HIP_LIB"))
 n = 10_000_000
 e.run(n // 10)
 e.run(n); t0 = e.last_kernel_ms()
