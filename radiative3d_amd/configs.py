@@ -27,17 +27,26 @@ def crustpinch(deg=9):
             "--seis-p2p=0,90,0,950,90,0,1.0,2.0,40.0,160").split()
 
 
-def lopnor(deg=9):
+def lopnor(deg=9, event="expl"):
+    """do-lopnor.sh:26-104; event: the script's own switch (:31) -- "expl", the generic explosion
+    2 km below Lop Nor (BASELINE config 3), or "eq", the Xinjiang earthquake 32 km down (what the
+    script ships with)."""
+    source = {"expl": "--source=EXPL --source-loc=425.54,-169.53,-1.02",
+              "eq": "--source=SDR,125,40,90,0.0 --source-loc=425.54,-169.53,-31.02"}[event]
     return ("--grid-compiled=1 --flatten --range=1200 "
             "--model-args=0.8,0.01,0.5,0.2,50,0.8,0.01,0.5,0.3,1000,0.8,0.01,0.7,0.5,300 "
-            "--source=EXPL --source-loc=425.54,-169.53,-1.02 --frequency=2.0 --timetolive=600 "
+            f"{source} --frequency=2.0 --timetolive=600 "
             f"--binsize=2.00 --toa-degree={deg} "
             "--seis-p2p=425.54,-169.53,0.98,-390.04,-167.18,1.457,1.0,2.0,40.0,160 "
             "--seis-p2p=425.54,-169.53,0.98,-102.27,430.84,0.60,1.0,2.0,40.0,160").split()
 
 
 def sphere(deg=9, source_depth=-10):
+    """do-spherical.sh:27-74.  (The script passes the crust-pinch run's five scattering groups as
+    --model-args; the whole-Earth model ignores them, do-spherical.sh:46, user_SphereEarth_inc.cpp:22-27.)"""
     return ("--grid-compiled=16 --source=SDR,22.5,90,0 "
+            "--model-args=0.8,0.01,0.20,0.2,200,0.8,0.01,0.20,0.3,1500,0.8,0.01,0.20,0.3,1500,"
+            "0.8,0.01,0.20,0.4,1500,0.8,0.01,0.20,0.5,900 "
             f"--source-loc=0,0,{source_depth} --frequency=2.0 --timetolive=8000 "
             f"--binsize=20.0 --toa-degree={deg} "
             "--seis-p2p=0,67.5,0,12000,67.5,0,20.0,20.0,400.0,160 "
@@ -54,9 +63,9 @@ def crustpinch_vids(deg=9):
     """do-crustpinch-vids.sh:22-72: the crust-pinch model as a scatter-event video run -- pinned
     mean free paths, scattering without deflection (scatter events become dense check-points,
     ~10 SCT + REF events per history), 350 s, coarse bins, three 16-receiver lines.  With a
-    dense event grid attached this is BASELINE config 5."""
-    return ("--grid-compiled=5 "
-            "--model-args=0.8,0.01,0.20,0.2,200,0.8,0.01,0.20,0.3,1500,0.8,0.01,0.20,0.3,1500,"
+    dense event grid attached this is BASELINE config 5.  (The script names no model: an unspecified
+    grid source is selection 0, which user.cpp:63-67 turns into 5, the crust pinch.)"""
+    return ("--model-args=0.8,0.01,0.20,0.2,200,0.8,0.01,0.20,0.3,1500,0.8,0.01,0.20,0.3,1500,"
             "0.8,0.01,0.20,0.4,1500,0.8,0.01,0.20,0.5,900,2.0,30.0,5.0,.3666667,.4736842,1,1 "
             "--source=SDR,22.5,90,0 --source-loc=0,0,-10 --frequency=2.0 --timetolive=350 "
             f"--binsize=10.0 --toa-degree={deg} --overridemfp=25,50 --nodeflect "
