@@ -36,10 +36,10 @@ HOST_SRC := $(HOSTDIR)/ecs.cpp $(HOSTDIR)/grid.cpp $(HOSTDIR)/model.cpp \
             $(HOSTDIR)/models_builtin.cpp $(HOSTDIR)/cmdline.cpp $(HOSTDIR)/dataout.cpp \
             $(HOSTDIR)/capi.cpp
 HOST_HDR := $(wildcard $(HOSTDIR)/*.hpp) include/r3d.h include/r3d_host.h
-ENGINE_SRC := $(CSRC)/r3d_engine.hip $(CSRC)/r3d_tables_build.hip $(CSRC)/r3d_kernels_kind.hip
+ENGINE_SRC := $(CSRC)/r3d_engine.hip $(CSRC)/r3d_tables_build.hip $(CSRC)/r3d_kernels_kind.hip $(CSRC)/r3d_volume.hip
 ENGINE_HDR := $(wildcard $(CSRC)/*.h) include/r3d.h
 OBJDIR   := build/obj
-# engine_objects(tag, extra flags): the five objects of one engine build
+# engine_objects(tag, extra flags): the six objects of one engine build
 define engine_objects
 $(OBJDIR)/$(1)_engine.o: $(CSRC)/r3d_engine.hip $(ENGINE_HDR)
 	@mkdir -p $(OBJDIR)
@@ -47,6 +47,9 @@ $(OBJDIR)/$(1)_engine.o: $(CSRC)/r3d_engine.hip $(ENGINE_HDR)
 $(OBJDIR)/$(1)_tables.o: $(CSRC)/r3d_tables_build.hip $(ENGINE_HDR)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(2) -c -o $$@ $(CSRC)/r3d_tables_build.hip
+$(OBJDIR)/$(1)_volume.o: $(CSRC)/r3d_volume.hip $(ENGINE_HDR)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(2) -c -o $$@ $(CSRC)/r3d_volume.hip
 $(OBJDIR)/$(1)_cyl.o: $(CSRC)/r3d_kernels_kind.hip $(ENGINE_HDR)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_CYL) $(2) -DR3D_KIND=0 -c -o $$@ $(CSRC)/r3d_kernels_kind.hip
@@ -57,7 +60,7 @@ $(OBJDIR)/$(1)_sph.o: $(CSRC)/r3d_kernels_kind.hip $(ENGINE_HDR)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_SPH) $(2) -DR3D_KIND=2 -c -o $$@ $(CSRC)/r3d_kernels_kind.hip
 endef
-engine_objs = $(OBJDIR)/$(1)_engine.o $(OBJDIR)/$(1)_tables.o $(OBJDIR)/$(1)_cyl.o $(OBJDIR)/$(1)_tet.o $(OBJDIR)/$(1)_sph.o
+engine_objs = $(OBJDIR)/$(1)_engine.o $(OBJDIR)/$(1)_tables.o $(OBJDIR)/$(1)_volume.o $(OBJDIR)/$(1)_cyl.o $(OBJDIR)/$(1)_tet.o $(OBJDIR)/$(1)_sph.o
 $(eval $(call engine_objects,main,))
 $(eval $(call engine_objects,repro,-DR3D_REPRODUCIBLE -ffp-contract=off))
 
@@ -118,12 +121,13 @@ VOBJ = $(OBJDIR)/v$(NAME)
 VDEFS = -DR3D_DEV_BUILD $(DEFS)
 variant:
 	@mkdir -p $(OBJDIR)
-	rm -f $(VOBJ)_engine.o $(VOBJ)_tables.o $(VOBJ)_cyl.o $(VOBJ)_tet.o $(VOBJ)_sph.o $(LIBDIR)/variant_$(NAME).so
+	rm -f $(VOBJ)_engine.o $(VOBJ)_tables.o $(VOBJ)_volume.o $(VOBJ)_cyl.o $(VOBJ)_tet.o $(VOBJ)_sph.o $(LIBDIR)/variant_$(NAME).so
 	$(HIPCC) $(HIPFLAGS) $(VDEFS) -c -o $(VOBJ)_engine.o $(CSRC)/r3d_engine.hip & p1=$$!; \
 	$(HIPCC) $(HIPFLAGS) $(VDEFS) -c -o $(VOBJ)_tables.o $(CSRC)/r3d_tables_build.hip & p2=$$!; \
+	$(HIPCC) $(HIPFLAGS) $(VDEFS) -c -o $(VOBJ)_volume.o $(CSRC)/r3d_volume.hip & p6=$$!; \
 	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_CYL) $(VDEFS) $(DEFS_CYL) -DR3D_KIND=0 -c -o $(VOBJ)_cyl.o $(CSRC)/r3d_kernels_kind.hip & p3=$$!; \
 	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_TET) $(VDEFS) $(DEFS_TET) -DR3D_KIND=1 -c -o $(VOBJ)_tet.o $(CSRC)/r3d_kernels_kind.hip & p4=$$!; \
 	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_SPH) $(VDEFS) $(DEFS_SPH) -DR3D_KIND=2 -c -o $(VOBJ)_sph.o $(CSRC)/r3d_kernels_kind.hip & p5=$$!; \
-	rc=0; for p in $$p1 $$p2 $$p3 $$p4 $$p5; do wait $$p || rc=1; done; exit $$rc
+	rc=0; for p in $$p1 $$p2 $$p3 $$p4 $$p5 $$p6; do wait $$p || rc=1; done; exit $$rc
 	$(HIPCC) --offload-arch=gfx950 -shared -pthread -o $(LIBDIR)/variant_$(NAME).so $(VOBJ)_engine.o \
-	    $(VOBJ)_tables.o $(VOBJ)_cyl.o $(VOBJ)_tet.o $(VOBJ)_sph.o
+	    $(VOBJ)_tables.o $(VOBJ)_volume.o $(VOBJ)_cyl.o $(VOBJ)_tet.o $(VOBJ)_sph.o

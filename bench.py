@@ -208,6 +208,10 @@ def parse_args(argv=None):
     ap.add_argument("--reduce-per-step", action="store_true",
                     help="all-reduce every step's bins (default: every launch adds into the rank's own block "
                          "and the blocks are summed over ranks once, after the flush)")
+    ap.add_argument("--volume-reduce", default="auto", choices=["auto", "sparse", "dense", "allreduce"],
+                    help="config 5's event grid over ranks: by frame as (index, count) pairs point to point "
+                         "(sparse), by frame with one reduce per owner (dense), whichever fits (auto), or the "
+                         "whole grid on every rank (allreduce: round 3's form)")
     ap.add_argument("--timed-only", action="store_true",
                     help="stop after the timed region: no single-launch, device-table, CPU-baseline or envelope "
                          "legs (profiling passes: every dispatch is then a step or flush launch of the chain)")
@@ -328,11 +332,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def reduce_volume():
+        if args.volume_reduce == "allreduce":
+            volume.allreduce_()
+        else:   # rank r ends with the job's counts for its frames ("keep sharded by frame")
+            volume.reduce_scatter_frames_(mode=args.volume_reduce)
+
     for i in range(args.warmup):
         step(i)
     flush()
     if not args.reduce_per_step:
         result.allreduce_()
+    if volume is not None and args.warmup:   # (connections and the pair buffer are set up outside the timed region)
+        reduce_volume()
     sync()
     result.zero_()
     if volume is not None:
@@ -351,11 +363,12 @@ def main():
     if volume is not None:   # the job's event grid: summed over ranks once, at the end
         torch.cuda.synchronize()          # (so that the reduction is timed on its own)
         t_vol0 = time.perf_counter()
-        volume.allreduce_()
+        reduce_volume()
     sync()
     t1 = time.perf_counter()
     elapsed = t1 - t0
     volume_reduce_s = (t1 - t_vol0) if volume is not None else None
+    events_binned = volume.job_total() if volume is not None else None   # (a collective: every rank calls it)
     step_ms = [ms for ms in (engine.kernel_ms(k) for k in step_launches) if ms >= 0]   # (the 64 most recent)
     flush_ms = [ms for ms in (engine.kernel_ms(k) for k in flush_launches) if ms >= 0]
     per_rank = None
@@ -371,6 +384,13 @@ def main():
         dist.all_gather(everyone, mine)
         per_rank = [dict(zip(("step_ms_min", "step_ms_max", "step_ms_mean", "flush_ms"),
                              (round(float(v), 4) for v in row))) for row in everyone]
+        if volume is not None:   # every rank's own time in the grid's reduction, and what it put on the wire
+            mine = torch.tensor([volume_reduce_s, float(volume.timing.get("bytes_sent") or 0)],
+                                dtype=torch.float64, device=device)
+            everyone = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(everyone, mine)
+            for row, v in zip(per_rank, everyone):
+                row["volume_reduce_s"], row["volume_bytes_sent"] = round(float(v[0]), 5), int(v[1])
     note(f"timed {args.steps} steps in {elapsed:.3f} s")
 
     line = None
@@ -449,10 +469,14 @@ def main():
         }
         if volume is not None:
             line["volume"] = {"shape": list(volume.shape), "bytes": volume.counters.numel() * 4,
-                              "events_binned": volume.total(),
+                              "events_binned": events_binned,
                               "reduce_over_ranks_s": volume_reduce_s, "saturated_cells": volume.saturated,
-                              "reduced_as": None if volume.widened is None else
-                                            ("int64, saturating" if volume.widened else "int32 in place")}
+                              "reduction": args.volume_reduce,
+                              "frames_held_by_rank_0": None if volume.owned is None else list(volume.owned),
+                              "reduced_as": volume.timing.get("mode") if args.volume_reduce != "allreduce" else
+                                            (None if volume.widened is None else
+                                             ("int64, saturating" if volume.widened else "int32 in place")),
+                              "phases_rank_0": {k: v for k, v in volume.timing.items() if k != "mode"}}
 
         if args.timed_only:
             line["cpu_baseline"] = None

@@ -353,6 +353,27 @@ void*  r3d_volume_device_ptr(r3d_engine* e);
  * r3d_run_device does for the bins).  v == NULL detaches.                    */
 int    r3d_engine_set_volume_buffer(r3d_engine* e, const r3d_volume_desc* v, uint32_t* d_counters);
 
+/* ---- the grid between ranks ---------------------------------------------------
+ * Replicas add (vis/seisplot/combine.m:26-33), and a rank's grid is sparse: ~10 events per
+ * history touch < 5 % of config 5's 2.5e9 cells.  These two calls are what a multi-GPU job needs
+ * to add the grids of its ranks WITHOUT moving 10 GB per rank: every rank compacts, per owner of
+ * a range of frames, the non-zero counters of that range into (index, count) pairs; the pairs
+ * travel point to point (RCCL send / recv); the owner adds what it receives into its own range
+ * (radiative3d_amd/parallel.py DeviceVolume.reduce_scatter_frames_).  Asynchronous on `stream`
+ * (a hipStream_t; NULL = the default stream); d_* are device pointers on `device`.
+ *
+ * r3d_volume_compact: appends the non-zero counters of d_counters[begin, end) to d_pairs as pairs
+ * of uint32 {index, count} -- index counted from d_counters, so end <= 2^32 -- starting at slot
+ * *d_n, and adds their number to *d_n (a device counter the caller zeroes; it may pass `capacity`
+ * pairs: what does not fit is counted, not written).
+ * r3d_volume_scatter_add: d_counters[index] += count for n pairs, index < len, saturating at
+ * 2^32 - 1.  d_flags[0] counts the cells that reached the ceiling, d_flags[1] pairs whose index was
+ * out of range (not written); the caller zeroes both.                              */
+int r3d_volume_compact(int device, const uint32_t* d_counters, uint64_t begin, uint64_t end, uint32_t* d_pairs,
+                       uint64_t capacity, uint64_t* d_n, void* stream);
+int r3d_volume_scatter_add(int device, uint32_t* d_counters, uint64_t len, const uint32_t* d_pairs, uint64_t n,
+                           uint64_t* d_flags, void* stream);
+
 /* ---- optional per-event report stream --------------------------------------
  * The reference's `--reports[=KEYWORDS]` (main.cpp:223-258) writes one text line
  * per event with the phonon's state at that moment (dataout.cpp:484-520): GEN

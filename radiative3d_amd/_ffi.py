@@ -261,6 +261,12 @@ def hip_lib(reproducible=False, path=None):
         L.r3d_engine_accumulators.argtypes = [C.c_void_p]
         L.r3d_engine_pool_slots.restype = C.c_uint32
         L.r3d_engine_pool_slots.argtypes = [C.c_void_p]
+        L.r3d_volume_compact.restype = C.c_int
+        L.r3d_volume_compact.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
+                                         C.c_void_p, C.c_void_p]
+        L.r3d_volume_scatter_add.restype = C.c_int
+        L.r3d_volume_scatter_add.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                             C.c_void_p]
         L.r3d_last_error.restype = C.c_char_p
         L.r3d_version.restype = C.c_char_p
         _hip[key] = L

@@ -7,7 +7,8 @@ counters are summed once at the end -- the same semantics as the reference's
 process-level replicas + `combine` (scripts/do-parallel.sh:23-29,
 vis/seisplot/combine.m:26-33).  The reduction is one all-reduce(SUM) per
 buffer through torch.distributed (backend "nccl" = RCCL over xGMI on the GPU
-node, "gloo" in CPU tests).
+node, "gloo" in CPU tests).  The event grid of BASELINE config 5 (10 GB per rank) is reduced BY FRAME
+and sparsely instead (DeviceVolume.reduce_scatter_frames_).
 """
 import torch
 import torch.distributed as dist
@@ -93,23 +94,40 @@ class DeviceVolume:
     event (dataout.cpp:570-577) and the Octave scripts bin them per frame
     (vis/scattervid/scattervid_above.m:111); replicas are combined by adding
     (vis/seisplot/combine.m:26-33).  Here every rank's engine increments its own grid
-    (r3d_engine_set_volume_buffer) and `allreduce_` / `reduce_` add the grids once at the end
-    of the job.  The counters are uint32 (a 10 GB grid at the 300 x 64 x 256 x 256 size of
-    BASELINE config 5), and a sum over ranks of 1e8..1e9 histories could pass 2^32 in a hot
-    cell.  The reduction first asks (one scalar MAX over ranks) whether any cell CAN reach 2^31:
-    if not -- the usual case -- the int32 storage is all-reduced as it is, 4 bytes per cell on
-    the wire; else it runs chunk by chunk in int64 and SATURATES at 2^32 - 1 instead of
-    wrapping; `saturated` counts the cells that hit the ceiling, `widened` says which path ran.
+    (r3d_engine_set_volume_buffer) and the grids are added ONCE, at the end of the job:
+
+    reduce_scatter_frames_()   the job's reduction ("keep sharded by frame"): rank r
+        ends up with the job's counts for ITS range of frames, [r F / N, (r + 1) F / N) of both wave
+        types -- a video frame is rendered from one frame's cells, so nobody needs all of them.
+        Sparse form (the usual case: ~10 events per history touch < 5 % of config 5's 2.5e9 cells):
+        every rank compacts, per owner, the non-zero counters of the owner's frames into 8-byte
+        (index, count) pairs (r3d_volume_compact), the pairs travel point to point -- every
+        xGMI link of the node's full mesh at once --, the owner adds what it receives
+        (r3d_volume_scatter_add, saturating at 2^32 - 1).  Dense form (a grid too full for its
+        pair buffer): one reduce(SUM) per owner and wave type on the int32 storage itself,
+        (N - 1) / N of the grid per rank on the wire; widened to int64 and saturating when a
+        cell's sum could reach 2^31.
+    allgather_frames_()        afterwards and outside any timed region, for a caller that does want
+        the whole grid everywhere: every owner broadcasts its frames.
+    allreduce_() / reduce_()   the whole grid on every rank / on one rank in one go (round 3's
+        form: 2 (N - 1) / N x 10 GB per rank on the wire; kept for small grids and as the
+        reference point of the tests).
+
+    `owned` says which frames of this rank's buffer hold JOB totals after a reduction: None = all
+    of them (or none was run: the rank's own counts), (lo, hi) after reduce_scatter_frames_, () on
+    the ranks a reduce_ left with scratch.  Reads outside `owned` raise.
     (torch has no arithmetic on uint32, so the storage is int32 holding the same bits.)"""
 
     def __init__(self, engine, origin, cell_size, dims, n_frames, frame_dt, device):
         self.shape = (2, int(n_frames), int(dims[2]), int(dims[1]), int(dims[0]))
-        n = 1
-        for d in self.shape:
-            n *= d
+        self.n_frames = int(n_frames)
+        self.frame_cells = int(dims[2]) * int(dims[1]) * int(dims[0])
+        n = 2 * self.n_frames * self.frame_cells
         self.counters = torch.zeros(n, dtype=torch.int32, device=device)
         self.saturated = 0
         self.widened = None
+        self.owned = None
+        self.timing = {}
         self.engine = engine
         if engine is not None:   # (the engine keeps a reference to the tensor: model.Engine.set_volume_buffer)
             engine.set_volume_buffer(origin, cell_size, dims, n_frames, frame_dt, self.counters)
@@ -123,7 +141,23 @@ class DeviceVolume:
     def zero_(self):
         self.counters.zero_()
         self.saturated = 0
+        self.owned = None
+        self.widened = None
 
+    # ---- who owns what ---------------------------------------------------------------------------
+    def frame_range(self, rank, world):
+        """Frames [lo, hi) whose job totals rank `rank` of `world` holds after reduce_scatter_frames_."""
+        return shard_range(self.n_frames, rank, world)
+
+    def _segments(self, lo, hi):
+        """The two contiguous runs of counters (one per wave type) that hold frames [lo, hi)."""
+        fc = self.frame_cells
+        return [((t * self.n_frames + lo) * fc, (t * self.n_frames + hi) * fc) for t in (0, 1) if hi > lo]
+
+    def _group(self):
+        return dist.is_available() and dist.is_initialized()
+
+    # ---- dense reductions --------------------------------------------------------------------------
     def _headroom(self, world):
         """True when no cell's sum over `world` ranks can reach 2^31: the counters can then be added
         as they are stored (int32), with no widening.  One scalar all-reduce (MAX) decides it for
@@ -133,47 +167,223 @@ class DeviceVolume:
         dist.all_reduce(worst, op=dist.ReduceOp.MAX)
         return int(worst.item()) * world < (1 << 31)
 
-    def _reduce_chunks(self, collective, chunk_elems, keep):
-        """Add the grids over ranks.  Usual case (every rank's largest counter x ranks < 2^31):
-        the collective runs on the int32 storage itself, in place, 4 bytes per cell on the wire.
-        Otherwise: widen, add, saturate, store back -- chunk by chunk so that the int64 scratch
-        stays small next to a multi-GB grid (8 bytes per cell on the wire)."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return self
-        if self._headroom(dist.get_world_size()):
-            self.widened = False
-            for lo in range(0, self.counters.numel(), chunk_elems):
-                collective(self.counters[lo:lo + chunk_elems])
-            return self
-        self.widened = True
-        sat = 0
-        for lo in range(0, self.counters.numel(), chunk_elems):
-            part = self.counters[lo:lo + chunk_elems]
+    def _reduce_run(self, collective, b, e, chunk_elems, keep, headroom):
+        """Add counters[b:e] over ranks with `collective`.  Usual case (every rank's largest counter
+        x ranks < 2^31): on the int32 storage itself, in place, 4 bytes per cell on the wire.
+        Otherwise: widen, add, saturate, store back -- chunk by chunk so that the int64 scratch stays
+        small next to a multi-GB grid (8 bytes per cell on the wire)."""
+        for lo in range(b, e, chunk_elems):
+            part = self.counters[lo:min(lo + chunk_elems, e)]
+            if headroom:
+                collective(part)
+                continue
             wide = _as_unsigned(part)
             collective(wide)
             if keep:
-                sat += int((wide > U32_MAX).sum().item())
+                self.saturated += int((wide > U32_MAX).sum().item())
                 part.copy_(_to_storage(wide.clamp_(max=U32_MAX)))
-        self.saturated += sat
+
+    def _reduce_whole(self, collective, chunk_elems, keep):
+        if not self._group():
+            return self
+        # (also at world size 1: a job of one rank takes the same path through the collective library)
+        headroom = self._headroom(dist.get_world_size())
+        self.widened = not headroom
+        self._reduce_run(collective, 0, self.counters.numel(), chunk_elems if headroom else min(chunk_elems, 1 << 26),
+                         keep, headroom)
         return self
 
     def allreduce_(self, chunk_elems=1 << 28):
         """Every rank ends with the job's grid (one all-reduce(SUM) per chunk of 1 GiB)."""
-        return self._reduce_chunks(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), chunk_elems, True)
+        self._reduce_whole(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), chunk_elems, True)
+        self.owned = None
+        return self
 
     def reduce_(self, dst=0, chunk_elems=1 << 28):
-        """Rank `dst` ends with the job's grid; the other ranks' buffers are then undefined
-        (a reduce may use them as scratch)."""
-        return self._reduce_chunks(lambda t: dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM), chunk_elems,
-                                   dist.is_initialized() and dist.get_rank() == dst)
+        """Rank `dst` ends with the job's grid; the other ranks' buffers are scratch afterwards (a
+        reduce may use them so) and refuse to be read."""
+        if not self._group():
+            return self
+        mine = dist.get_rank() == dst
+        self._reduce_whole(lambda t: dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM), chunk_elems, mine)
+        self.owned = None if mine else ()
+        return self
+
+    # ---- the job's reduction: by frame ------------------------------------------------------------
+    def reduce_scatter_frames_(self, mode="auto", pair_capacity=None, chunk_elems=1 << 28):
+        """Rank r ends with the job's counts for its frame_range(r, N) (both wave types); the rest of
+        its buffer is stale.  mode: "sparse" (pairs, point to point), "dense" (one reduce per owner
+        and wave type), "auto" = sparse unless some rank's pairs do not fit `pair_capacity`
+        (default: a sixteenth of the cells, i.e. half the grid's bytes) -- decided for all ranks
+        alike from the exchanged counts.  `timing` records the phases."""
+        if mode not in ("auto", "sparse", "dense"):
+            raise ValueError(mode)
+        if not self._group():
+            return self
+        rank, world = dist.get_rank(), dist.get_world_size()
+        self.timing = {"mode": None}
+        t0 = self._clock()
+        if mode != "dense" and self.counters.numel() < (1 << 32):
+            cap = int(pair_capacity if pair_capacity is not None else max(1024, self.counters.numel() // 16))
+            if self._reduce_scatter_sparse(rank, world, cap, t0) or mode == "sparse":
+                return self
+        headroom = self._headroom(world)
+        self.widened = not headroom
+        for owner in range(world):
+            for b, e in self._segments(*self.frame_range(owner, world)):
+                self._reduce_run(lambda t: dist.reduce(t, dst=owner, op=dist.ReduceOp.SUM), b, e,
+                                 chunk_elems if headroom else min(chunk_elems, 1 << 26), rank == owner, headroom)
+        self.owned = self.frame_range(rank, world)
+        self.timing.update(mode="dense int64, saturating" if self.widened else "dense int32",
+                           total_s=self._clock() - t0,
+                           bytes_sent=(self.counters.numel() - sum(e - b for b, e in self._segments(*self.owned)))
+                           * (8 if self.widened else 4))
+        return self
+
+    def _clock(self):
+        import time
+        if self.counters.is_cuda:
+            torch.cuda.synchronize(self.counters.device)
+        return time.perf_counter()
+
+    def _compact(self, b, e, pairs, n_dev, cap):
+        """Append the non-zero counters of [b, e) to `pairs` (int32 [cap, 2]) at *n_dev."""
+        if self.counters.is_cuda:
+            from . import _ffi
+            lib = _ffi.hip_lib()
+            if lib.r3d_volume_compact(self.counters.device.index, self.counters.data_ptr(), b, e, pairs.data_ptr(), cap,
+                                      n_dev.data_ptr(), torch.cuda.current_stream(self.counters.device).cuda_stream):
+                raise RuntimeError("r3d_volume_compact failed: " + lib.r3d_last_error().decode())
+            return
+        # host tensors (the gloo tests of the exchange): the same result with torch operations
+        seg = self.counters[b:e]
+        idx = seg.nonzero().flatten()
+        at = int(n_dev.item())
+        fit = max(0, min(idx.numel(), cap - at))
+        pairs[at:at + fit, 0] = _to_storage(idx[:fit] + b)
+        pairs[at:at + fit, 1] = seg[idx[:fit]]
+        n_dev += idx.numel()
+
+    def _scatter_add(self, pairs):
+        """counters[index] += count for the received pairs, saturating."""
+        if pairs.shape[0] == 0:
+            return
+        if self.counters.is_cuda:
+            from . import _ffi
+            lib = _ffi.hip_lib()
+            flags = torch.zeros(2, dtype=torch.int64, device=self.counters.device)
+            if lib.r3d_volume_scatter_add(self.counters.device.index, self.counters.data_ptr(), self.counters.numel(),
+                                          pairs.data_ptr(), pairs.shape[0], flags.data_ptr(),
+                                          torch.cuda.current_stream(self.counters.device).cuda_stream):
+                raise RuntimeError("r3d_volume_scatter_add failed: " + lib.r3d_last_error().decode())
+            sat, stray = (int(v) for v in flags.tolist())
+            if stray:
+                raise RuntimeError(f"{stray} received pairs lie outside the grid")
+            self.saturated += sat
+            return
+        idx, val = _as_unsigned(pairs[:, 0]), _as_unsigned(pairs[:, 1])
+        b, e = int(idx.min().item()), int(idx.max().item()) + 1
+        wide = _as_unsigned(self.counters[b:e])
+        wide.index_add_(0, idx - b, val)
+        self.saturated += int((wide > U32_MAX).sum().item())
+        self.counters[b:e] = _to_storage(wide.clamp_(max=U32_MAX))
+
+    def _reduce_scatter_sparse(self, rank, world, cap, t0):
+        """The sparse form; returns False (nothing changed) when some rank's pairs do not fit."""
+        dev = self.counters.device
+        pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        n_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        ends = []   # ends[o] = pairs written (or merely counted) once owner o's frames are compacted
+        for owner in range(world):
+            if owner != rank:   # (this rank's own frames stay where they are)
+                for b, e in self._segments(*self.frame_range(owner, world)):
+                    self._compact(b, e, pairs, n_dev, cap)
+            ends.append(int(n_dev.item()))
+        t1 = self._clock()
+        counts = torch.tensor([ends[o] - (ends[o - 1] if o else 0) for o in range(world)], dtype=torch.int64, device=dev)
+        matrix = [torch.zeros_like(counts) for _ in range(world)]
+        dist.all_gather(matrix, counts)                       # matrix[src][dst] = pairs src has for dst
+        matrix = torch.stack(matrix).cpu()
+        if int(matrix.sum(1).max().item()) > cap:             # (every rank sees the same matrix: one decision)
+            self.timing["sparse_refused"] = f"{int(matrix.sum(1).max().item())} pairs on some rank, capacity {cap}"
+            return False
+        incoming = [int(matrix[src][rank].item()) for src in range(world)]
+        recv = torch.empty((sum(incoming), 2), dtype=torch.int32, device=dev)
+        ops, at = [], 0
+        for peer in range(world):
+            if peer == rank:
+                continue
+            lo, hi = (ends[peer - 1] if peer else 0), ends[peer]
+            if hi > lo:
+                ops.append(dist.P2POp(dist.isend, pairs[lo:hi], peer))
+            if incoming[peer]:
+                ops.append(dist.P2POp(dist.irecv, recv[at:at + incoming[peer]], peer))
+                at += incoming[peer]
+        if ops:
+            for work in dist.batch_isend_irecv(ops):
+                work.wait()
+        t2 = self._clock()
+        self._scatter_add(recv)
+        self.owned = self.frame_range(rank, world)
+        t3 = self._clock()
+        self.widened = None
+        self.timing.update(mode="sparse pairs", compact_s=t1 - t0, exchange_s=t2 - t1, add_s=t3 - t2, total_s=t3 - t0,
+                           pairs_sent=ends[-1], pairs_received=sum(incoming), bytes_sent=8 * ends[-1])
+        return True
+
+    def allgather_frames_(self, chunk_elems=1 << 28):
+        """After reduce_scatter_frames_: every owner broadcasts its frames, every rank ends with the
+        job's whole grid (for callers that want it everywhere; not part of the job's reduction)."""
+        if not self._group() or self.owned is None:
+            return self
+        world = dist.get_world_size()
+        for owner in range(world):
+            for b, e in self._segments(*self.frame_range(owner, world)):
+                for lo in range(b, e, chunk_elems):
+                    dist.broadcast(self.counters[lo:min(lo + chunk_elems, e)], src=owner)
+        self.owned = None
+        return self
+
+    # ---- reading -----------------------------------------------------------------------------------
+    def _valid_runs(self):
+        if self.owned is None:
+            return [(0, self.counters.numel())]
+        if self.owned == ():
+            raise RuntimeError("this rank's grid was scratch of a reduce_ to another rank: it holds nothing to read")
+        return self._segments(*self.owned)
 
     def total(self, chunk_elems=1 << 26):
-        """Sum of all counters (events binned), computed chunk by chunk."""
+        """Sum of the counters this rank holds job totals for (all of them unless a reduction by frame
+        has run), computed chunk by chunk."""
         t = 0
-        for lo in range(0, self.counters.numel(), chunk_elems):
-            t += int(_as_unsigned(self.counters[lo:lo + chunk_elems]).sum().item())
+        for b, e in self._valid_runs():
+            for lo in range(b, e, chunk_elems):
+                t += int(_as_unsigned(self.counters[lo:min(lo + chunk_elems, e)]).sum().item())
         return t
 
-    def to_numpy(self):
+    def job_total(self):
+        """Events binned by the whole job: total() summed over the owners after reduce_scatter_frames_."""
+        t = self.total()
+        if self._group() and self.owned is not None:
+            v = torch.tensor([t], dtype=torch.int64, device=self.counters.device)
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+            t = int(v.item())
+        return t
+
+    def frames_numpy(self):
+        """(lo, hi, counts[2][hi - lo][z][y][x]) of the frames this rank holds job totals for."""
         import numpy as np
+        if self.owned == ():
+            self._valid_runs()
+        lo, hi = (0, self.n_frames) if self.owned is None else self.owned
+        full = self.counters.view(self.shape)[:, lo:hi]
+        return lo, hi, full.cpu().numpy().view(np.uint32)
+
+    def to_numpy(self):
+        """The whole grid; refuses while only a range of frames holds job totals."""
+        import numpy as np
+        if self.owned is not None:
+            self._valid_runs() if self.owned == () else None
+            raise RuntimeError(f"only frames {self.owned} of this rank's grid hold job totals "
+                               "(reduce_scatter_frames_): read frames_numpy(), or allgather_frames_() first")
         return self.counters.cpu().numpy().view(np.uint32).reshape(self.shape)

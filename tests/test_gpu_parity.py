@@ -636,14 +636,19 @@ def _bench_child(extra_args, launched, port=None):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("config", ["crustpinch", "crustpinch_volume"])
-def test_bench_under_a_launcher_runs_rccl_and_equals_the_direct_run(config):
-    """The launched path of bench.py at world size 1: RCCL initialised, DeviceResult.allreduce_ (and for
-    config 5 DeviceVolume under the group), barrier, destroy -- same totals as the direct run.
-    (Reference semantics: scripts/do-parallel.sh:23-29, vis/seisplot/combine.m:26-33.)"""
+@pytest.mark.parametrize("config,volume_reduce", [("crustpinch", None), ("crustpinch_volume", "dense"),
+                                                  ("crustpinch_volume", "sparse"), ("crustpinch_volume", "allreduce")])
+def test_bench_under_a_launcher_runs_rccl_and_equals_the_direct_run(config, volume_reduce):
+    """The launched path of bench.py at world size 1: RCCL initialised, DeviceResult.allreduce_, barrier,
+    destroy -- same totals as the direct run.  For config 5 the 10 GB event grid goes through the group
+    in each of its forms: by frame with one RCCL reduce per owner and wave type ("dense": the MAX pre-pass
+    and the chunked SUM on the int32 storage -- a job of one rank takes the same path through the
+    library), by frame as compacted pairs ("sparse": r3d_volume_compact on the full grid), and all-reduced.
+    (Reference semantics: scripts/do-parallel.sh:23-29, vis/seisplot/combine.m:26-33,
+    vis/scattervid/scattervid_above.m:111.)"""
     from radiative3d_amd.launch import free_port
     args = ["--config", config, "--steps", "2", "--warmup", "1", "--histories", "200000", "--toa-degree", "5",
-            "--no-cpu-baseline"]
+            "--no-cpu-baseline"] + (["--volume-reduce", volume_reduce] if volume_reduce else [])
     direct = _bench_child(args, launched=False)
     rccl = _bench_child(args, launched=True, port=free_port())
     assert direct["n_gpus"] == rccl["n_gpus"] == 1
@@ -652,7 +657,16 @@ def test_bench_under_a_launcher_runs_rccl_and_equals_the_direct_run(config):
     assert rccl["roofline"]["events_per_history"] == direct["roofline"]["events_per_history"]
     assert rccl["value"] > 0 and len(rccl["collective"]["per_rank_kernel_ms"]) == 1
     if config == "crustpinch_volume":
-        assert rccl["volume"]["events_binned"] == direct["volume"]["events_binned"] > 0
+        v = rccl["volume"]
+        assert v["events_binned"] == direct["volume"]["events_binned"] > 0
+        assert v["reduced_as"] == {"dense": "dense int32", "sparse": "sparse pairs", "allreduce": "int32 in place"}[volume_reduce]
+        assert direct["volume"]["reduced_as"] is None            # (no process group: nothing to reduce over)
+        assert v["reduce_over_ranks_s"] > 0 and v["saturated_cells"] == 0
+        assert rccl["collective"]["per_rank_kernel_ms"][0]["volume_reduce_s"] > 0
+        if volume_reduce != "allreduce":
+            assert v["frames_held_by_rank_0"] == [0, 300]        # world 1: rank 0 owns every frame
+        if volume_reduce == "dense":
+            assert v["phases_rank_0"]["bytes_sent"] == 0          # (N - 1) / N of the grid = nothing at N = 1
 
 
 def test_bench_cpu_baseline_and_envelope_under_a_launcher():

@@ -5,6 +5,7 @@ test-only host build of the kernel code (there is no product CPU path)."""
 import os
 import socket
 
+import pytest
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -168,3 +169,83 @@ def test_two_ranks_volume_grid_sums_to_the_single_process_histogram(tmp_path):
     _, want = E.run_with_volume(model, n, volume_desc(**GRID))
     assert got.dtype == np.uint32 and got.shape == want.shape
     assert int(want.sum()) > 10000 and (got == want).all()
+
+
+# ---- the job's reduction of the grid: by frame (SURVEY.md 8(e) "keep sharded by frame") -------------
+def _frames_worker(rank, world, port, n, out_dir):
+    """reduce_scatter_frames_ in its three forms against the all-reduced grid, on real engine output
+    (the host emulation's grid of this rank's id shard).  World sizes 2 and 3: 35 frames do not divide by 3."""
+    from radiative3d_amd.model import volume_desc
+    from radiative3d_amd.parallel import DeviceVolume
+    from tests.configs import crustpinch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = Model(crustpinch(3) + VIDEO)
+    lo, hi = shard_range(n, rank, world)
+    _, vol = E.run_with_volume(model, hi - lo, volume_desc(**GRID), first_id=lo)
+    own = torch.from_numpy(vol.reshape(-1).view(np.int32)).clone()
+
+    def fresh():
+        d = DeviceVolume(None, device="cpu", **GRID)
+        d.counters.copy_(own)
+        return d
+
+    whole = fresh().allreduce_()                       # the reference point: every cell's job total
+    want = whole.to_numpy()
+    f_lo, f_hi = whole.frame_range(rank, world)
+    assert sum(whole.frame_range(r, world)[1] - whole.frame_range(r, world)[0] for r in range(world)) == 35
+    for mode, kwargs in (("sparse", {}), ("dense", dict(chunk_elems=100_003)), ("auto", {}),
+                         ("auto", dict(pair_capacity=16))):   # (16 pairs cannot hold a rank's cells: auto goes dense)
+        d = fresh().reduce_scatter_frames_(mode=mode, **kwargs)
+        assert d.owned == (f_lo, f_hi)
+        a, b, mine = d.frames_numpy()
+        assert (a, b) == (f_lo, f_hi) and (mine == want[:, f_lo:f_hi]).all(), (mode, kwargs)
+        said = d.timing["mode"]
+        assert said == ("dense int32" if mode == "dense" or kwargs.get("pair_capacity") else "sparse pairs"), said
+        if said == "sparse pairs":       # what travelled: this rank's non-zero cells in the OTHER ranks' frames
+            others = own.view(d.shape).clone()
+            others[:, f_lo:f_hi] = 0
+            assert d.timing["pairs_sent"] == int((others != 0).sum()) and d.timing["bytes_sent"] == 8 * d.timing["pairs_sent"]
+        else:
+            assert d.timing["bytes_sent"] == 4 * (d.counters.numel() - 2 * (f_hi - f_lo) * d.frame_cells)
+        assert d.total() == int(want[:, f_lo:f_hi].sum()) and d.job_total() == int(want.sum())
+        with pytest.raises(RuntimeError, match="only frames"):
+            d.to_numpy()                               # the other frames are stale: not readable as a whole grid
+        d.allgather_frames_()
+        assert d.owned is None and (d.to_numpy() == want).all()
+    # a reduce_ leaves the other ranks with scratch that refuses to be read
+    r = fresh().reduce_(dst=world - 1)
+    if rank == world - 1:
+        assert (r.to_numpy() == want).all()
+    else:
+        with pytest.raises(RuntimeError, match="scratch"):
+            r.total()
+    # saturation and the 2^31 switch-over, by frame: one frame per rank at world 2, cells chosen per owner
+    tiny = dict(origin=(0, 0, 0), cell_size=(1, 1, 1), dims=(2, 1, 1), n_frames=world, frame_dt=1.0)
+    for mode in ("sparse", "dense"):
+        t = DeviceVolume(None, device="cpu", **tiny)
+        vals = np.zeros((2, world, 2), dtype=np.uint32)
+        vals[0, :, 0] = 0xFFFFFFFB          # every rank holds 2^32 - 5 in one cell of every frame: sums saturate
+        vals[0, :, 1] = 1 << 30             # and 2^30 in another: the sum of two is 2^31, beyond int32
+        vals[1, :, 0] = 7 + rank
+        t.counters.copy_(torch.from_numpy(vals.reshape(-1).view(np.int32)))
+        t.reduce_scatter_frames_(mode=mode)
+        a, b, got = t.frames_numpy()
+        assert b - a == 1
+        assert got[0, 0].reshape(-1).tolist() == [0xFFFFFFFF, min(world << 30, 0xFFFFFFFF)], (mode, got)
+        assert got[1, 0].reshape(-1).tolist() == [7 * world + sum(range(world)), 0]
+        assert t.saturated == 1 and (t.widened is True if mode == "dense" else t.widened is None)
+    if rank == 0:
+        np.save(os.path.join(out_dir, f"frames_{world}.npy"), want)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_grid_reduced_by_frame_equals_the_all_reduced_grid(tmp_path, world):
+    from radiative3d_amd.model import volume_desc
+    from tests.configs import crustpinch
+    n = 2400
+    mp.spawn(_frames_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(str(tmp_path / f"frames_{world}.npy"))
+    _, want = E.run_with_volume(Model(crustpinch(3) + VIDEO), n, volume_desc(**GRID))
+    assert int(want.sum()) > 5000 and (got == want).all()

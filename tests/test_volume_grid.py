@@ -71,3 +71,68 @@ def test_dense_volume_grid_at_scale(models):
     assert r.n_lost + r.n_timeout + r.n_invalid == n
     total = int(vol.sum(dtype=np.uint64))
     assert 0.8 * (r.events["scatter"] + r.events["reflect"]) < total <= r.events["scatter"] + r.events["reflect"]
+
+
+@pytest.mark.gpu
+def test_pairs_of_a_grid_and_their_add_rebuild_the_grid(models):
+    """r3d_volume_compact / r3d_volume_scatter_add (the grid between ranks, include/r3d.h) on an engine-
+    filled grid, against the counters themselves: the pairs are exactly the non-zero cells (ragged
+    ranges, ranges that do not start on a 16-byte boundary, a buffer too small), and adding them into
+    an empty grid -- twice -- gives the grid and its double; the ceiling holds."""
+    import ctypes as C
+
+    import torch
+    from radiative3d_amd import Engine, _ffi
+    from radiative3d_amd.parallel import DeviceVolume
+    m = models("crustpinch", 4, VIDEO)
+    e = Engine(m)
+    vol = DeviceVolume(e, device="cuda:0", **GRID)
+    e.run(30000)
+    torch.cuda.synchronize()
+    lib = _ffi.hip_lib()
+    grid = vol.counters
+    host = grid.cpu().numpy().view(np.uint32)
+    n_cells = host.size
+    cap = n_cells // 2
+    pairs = torch.empty((cap, 2), dtype=torch.int32, device="cuda:0")
+    n_dev = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+
+    def compact(b, e_, capacity=cap):
+        n_dev.zero_()
+        assert lib.r3d_volume_compact(0, grid.data_ptr(), b, e_, pairs.data_ptr(), capacity, n_dev.data_ptr(), None) == 0, \
+            lib.r3d_last_error()
+        torch.cuda.synchronize()
+        n = int(n_dev.item())
+        p = pairs[:min(n, capacity)].cpu().numpy().view(np.uint32)
+        return n, p[np.argsort(p[:, 0])]
+
+    for b, e_ in ((0, n_cells), (4096 * 3 + 1, n_cells - 7), (5, 9), (12, 12), (n_cells - 4099, n_cells)):
+        n, p = compact(b, e_)
+        want = np.flatnonzero(host[b:e_]) + b
+        assert n == want.size and (p[:, 0] == want).all() and (p[:, 1] == host[want]).all(), (b, e_)
+    assert np.count_nonzero(host) > 50000
+    n_small, p_small = compact(0, n_cells, capacity=1000)            # too small a buffer: counted, not written past it
+    assert n_small == np.count_nonzero(host) and p_small.shape[0] == 1000 and (host[p_small[:, 0]] == p_small[:, 1]).all()
+    n, _ = compact(0, n_cells)
+    rebuilt = torch.zeros_like(grid)
+    flags = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+    for _ in range(2):
+        assert lib.r3d_volume_scatter_add(0, rebuilt.data_ptr(), n_cells, pairs.data_ptr(), n, flags.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert (rebuilt.cpu().numpy().view(np.uint32) == 2 * host).all() and flags.tolist() == [0, 0]
+    # the ceiling: 2^32 - 3 in a cell, then the pairs on top -> pinned, counted once; an index beyond the grid is refused
+    hot = int(np.flatnonzero(host)[0])
+    rebuilt.zero_()
+    rebuilt[hot] = -3
+    bad = torch.tensor([[n_cells, 1]], dtype=torch.int32, device="cuda:0")
+    assert lib.r3d_volume_scatter_add(0, rebuilt.data_ptr(), n_cells, pairs.data_ptr(), n, flags.data_ptr(), None) == 0
+    assert lib.r3d_volume_scatter_add(0, rebuilt.data_ptr(), n_cells, bad.data_ptr(), 1, flags.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    got = rebuilt.cpu().numpy().view(np.uint32)
+    want = host.copy()
+    want[hot] = 0xFFFFFFFF if host[hot] >= 3 else host[hot] + 0xFFFFFFFD
+    assert (got == want).all() and flags.tolist() == [1 if host[hot] >= 3 else 0, 1]
+    assert lib.r3d_volume_compact(0, grid.data_ptr(), 8, 4, pairs.data_ptr(), cap, n_dev.data_ptr(), None) != 0
+    vol.detach()
+    e.close()
+    del C
