@@ -39,6 +39,12 @@ MAX_CLOCK_GHZ = 2.4
 PROFILE_ROUND = "r03"
 
 
+# BASELINE.json `configs`, as stated: the histories of ONE job of each configuration (configs 3-5 are
+# jobs of a whole node: their histories are divided over the ranks -- strong scaling)
+JOB_HISTORIES = {"halfspace": 100_000, "crustpinch": 10_000_000, "lopnor": 100_000_000, "sphere": 100_000_000,
+                 "crustpinch_volume": 100_000_000}
+
+
 def workloads():
     from radiative3d_amd import configs as C
     return {
@@ -208,6 +214,9 @@ def parse_args(argv=None):
     ap.add_argument("--reduce-per-step", action="store_true",
                     help="all-reduce every step's bins (default: every launch adds into the rank's own block "
                          "and the blocks are summed over ranks once, after the flush)")
+    ap.add_argument("--no-job", action="store_true",
+                    help="skip the literal BASELINE job (one self-contained run of the configuration's stated "
+                         "size, timed from its first launch to the reduced bins; printed as `job`)")
     ap.add_argument("--volume-reduce", default="auto", choices=["auto", "sparse", "dense", "allreduce"],
                     help="config 5's event grid over ranks: by frame as (index, count) pairs point to point "
                          "(sparse), by frame with one reduce per owner (dense), whichever fits (auto), or the "
@@ -369,6 +378,17 @@ def main():
     elapsed = t1 - t0
     volume_reduce_s = (t1 - t_vol0) if volume is not None else None
     events_binned = volume.job_total() if volume is not None else None   # (a collective: every rank calls it)
+    volume_line = None
+    if volume is not None:   # (as the timed region left it: the job leg below reduces the grid again)
+        volume_line = {"shape": list(volume.shape), "bytes": volume.counters.numel() * 4,
+                          "events_binned": events_binned,
+                          "reduce_over_ranks_s": volume_reduce_s, "saturated_cells": volume.saturated,
+                          "reduction": args.volume_reduce,
+                          "frames_held_by_rank_0": None if volume.owned is None else list(volume.owned),
+                          "reduced_as": volume.timing.get("mode") if args.volume_reduce != "allreduce" else
+                                        (None if volume.widened is None else
+                                         ("int64, saturating" if volume.widened else "int32 in place")),
+                          "phases_rank_0": {k: v for k, v in volume.timing.items() if k != "mode"}}
     step_ms = [ms for ms in (engine.kernel_ms(k) for k in step_launches) if ms >= 0]   # (the 64 most recent)
     flush_ms = [ms for ms in (engine.kernel_ms(k) for k in flush_launches) if ms >= 0]
     per_rank = None
@@ -393,9 +413,47 @@ def main():
                 row["volume_reduce_s"], row["volume_bytes_sent"] = round(float(v[0]), 5), int(v[1])
     note(f"timed {args.steps} steps in {elapsed:.3f} s")
 
+    # ---- the literal BASELINE job (model.cpp:602-633 is the job): the configuration's stated number of
+    # histories, divided over the ranks, as ONE self-contained launch per rank that drains its own
+    # stragglers, then the reduction of the bins (and of config 5's grid) -- timed from the first launch
+    # to the reduced result, tables resident.  Strong scaling: the job's size does not grow with N.
+    res_timed = result.to_result() if rank == 0 else None   # (the timed region's totals: the job leg reuses the block)
+    job = None
+    if not args.timed_only and not args.no_job:
+        n_job = JOB_HISTORIES[args.config]
+        lo, hi = shard_range(n_job, rank, world)
+        times = []
+        for rep in range(4):   # (the first is a warm-up: it sizes the allocator's pools for this launch size)
+            result.zero_()
+            if volume is not None:
+                volume.zero_()
+            sync()
+            tj = time.perf_counter()
+            engine.run_device(hi - lo, (7 << 40) + rep * n_job + lo, seed, *result.pointers(), stream=stream.cuda_stream)
+            result.allreduce_()
+            if volume is not None:
+                torch.cuda.synchronize()
+                reduce_volume()
+            sync()
+            dt = time.perf_counter() - tj
+            if launched:
+                t = torch.tensor([dt], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            if rep:
+                times.append((dt, engine.last_kernel_ms()))
+        times.sort()
+        dt, kernel_ms = times[len(times) // 2]
+        job = {"histories": n_job, "histories_per_gpu": hi - lo, "ms": 1e3 * dt, "value": n_job / dt,
+               "unit": "histories/s", "scaling": "strong", "kernel_ms_rank_0": kernel_ms,
+               "note": "median of 3: one self-contained launch per rank (drains its own stragglers) + the "
+                       "reduction of the bins" + (" and of the event grid" if volume is not None else "") +
+                       ", first launch to reduced result, max over ranks"}
+        note(f"job of {n_job} histories: {1e3 * dt:.2f} ms")
+
     line = None
     if rank == 0:
-        res = result.to_result()
+        res = res_timed
         total = res.events["generated"]            # histories summed over ranks and passes
         assert total == args.steps * n * world, (total, args.steps, n, world)
         assert res.n_lost + res.n_timeout + res.n_invalid == total
@@ -467,16 +525,10 @@ def main():
             "host": {"model_build_s": round(t_build, 2), "engine_create_s": round(t_upload, 2),
                      "tables": "device-built"},
         }
+        if job is not None:
+            line["job"] = job
         if volume is not None:
-            line["volume"] = {"shape": list(volume.shape), "bytes": volume.counters.numel() * 4,
-                              "events_binned": events_binned,
-                              "reduce_over_ranks_s": volume_reduce_s, "saturated_cells": volume.saturated,
-                              "reduction": args.volume_reduce,
-                              "frames_held_by_rank_0": None if volume.owned is None else list(volume.owned),
-                              "reduced_as": volume.timing.get("mode") if args.volume_reduce != "allreduce" else
-                                            (None if volume.widened is None else
-                                             ("int64, saturating" if volume.widened else "int32 in place")),
-                              "phases_rank_0": {k: v for k, v in volume.timing.items() if k != "mode"}}
+            line["volume"] = volume_line
 
         if args.timed_only:
             line["cpu_baseline"] = None

@@ -231,15 +231,32 @@ def test_full_size_crustpinch_properties():
     #  this common swing cancels and the mean is held as a per-bin bias would show in it.)
     b = e.run(n, first_id=n)
     z = bin_z(a, b, min_bins=5000)
-    print(f"crustpinch deg 9 independent halves: z mean {z.mean():+.4f} std {z.std():.3f} over {z.size} bins")
-    assert abs(z.mean()) < BIAS_BOUND and 0.9 < z.std() < 1.5, (z.mean(), z.std())
+    bound = bias_bound(e, n)
+    print(f"crustpinch deg 9 independent halves: z mean {z.mean():+.4f} (allowed +-{bound:.3f}) std {z.std():.3f} over {z.size} bins")
+    assert abs(z.mean()) < bound and 0.9 < z.std() < 1.5, (z.mean(), z.std())
     assert a.energy.sum() == pytest.approx(b.energy.sum(), rel=0.02)
     # small-sample oracle comparison on the big tables too: diagnostic and production kernels
     check_against_oracle(e, 3000, first_id=123456789, allow_frac=0.0005)
     check_production_against_oracle(e, 3000, first_id=123456789)
 
 
-BIAS_BOUND = 0.1
+def bias_bound(e, n, pairs=8):
+    """How far the mean of bin_z may sit from zero for two samples of the same code: bins are NOT
+    independent -- one long-reverberating history feeds many of them -- so the mean of z over
+    thousands of bins does not shrink like 1 / sqrt(bins) (LopNor: -0.11 over 8909 bins between two
+    1e7-history samples, eight of the independent-bin standard errors).  A relative swing delta of a
+    group of bins with c counts each shifts their z by delta sqrt(c / 2), and delta ~ 1 / sqrt(n),
+    c ~ n: the shift does not depend on the sample size.  So the spread of the statistic is MEASURED,
+    on `pairs` independent pairs of samples an eighth the size, and the full samples' mean is held to
+    four of those standard deviations (+ 0.02): a per-bin bias beyond the sample-to-sample variation
+    of the statistic itself fails."""
+    m = n // 8
+    means = []
+    for k in range(pairs):
+        a = e.run(m, first_id=(9 << 40) + 2 * k * m)
+        b = e.run(m, first_id=(9 << 40) + (2 * k + 1) * m)
+        means.append(bin_z(a, b, min_bins=200).mean())
+    return 4.0 * float(np.std(means, ddof=1)) + 0.02
 
 
 def bin_z(a, b, min_bins):
@@ -264,8 +281,9 @@ def independent_halves_agree(e, n, min_bins):
         assert int(r.counts.sum()) == r.events["catch"]
         assert np.allclose(r.energy[:, :, :3].sum(-1), r.energy[:, :, 3:].sum(-1), rtol=1e-10, atol=1e-300)
     z = bin_z(a, b, min_bins)
-    print(f"independent halves: z mean {z.mean():+.4f} std {z.std():.3f} over {z.size} bins")
-    assert abs(z.mean()) < BIAS_BOUND and 0.9 < z.std() < 1.6, (z.mean(), z.std())
+    bound = bias_bound(e, n)
+    print(f"independent halves: z mean {z.mean():+.4f} (allowed +-{bound:.3f}) std {z.std():.3f} over {z.size} bins")
+    assert abs(z.mean()) < bound and 0.9 < z.std() < 1.6, (z.mean(), z.std())
     return a, b
 
 
