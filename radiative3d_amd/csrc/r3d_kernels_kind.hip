@@ -1,7 +1,7 @@
 // r3d_kernels_kind.hip -- the traversal kernels of ONE cell kind (-DR3D_KIND=0 cylinder, 1 tetra,
 // 2 sphere shell; the Makefile compiles this file three times): pool_kernel<KIND, ...> diagnostic
-// and production variants and pool_drain_kernel<KIND, ...> for every table residency the kind can
-// run with, and the launch entry points r3d_engine.hip calls (r3d_kernels.h).
+// and chain-step variants, pool_job_kernel<KIND, ...> and pool_drain_kernel<KIND, ...> for every table
+// residency the kind can run with, and the launch entry points r3d_engine.hip calls (r3d_kernels.h).
 //
 // One unit per kind because the kinds want different instruction scheduling: the spherical-shell
 // and layered kernels run 3.4 % / 0.4 % faster under the compiler's max-ILP strategy, the tetra
@@ -42,8 +42,10 @@ hipError_t launch_kind(int res, bool trace, bool drain_only, unsigned grid, size
       hipLaunchKernelGGL((pool_drain_kernel<K, C, H>), dim3(grid), dim3(kPoolBlock), lds_bytes, s, a);
     else if (trace)
       hipLaunchKernelGGL((pool_kernel<K, C, H, true>), dim3(grid), dim3(kPoolBlock), lds_bytes, s, a);
-    else
+    else if (a.carry_out)   // a step launch of a chain: what is unfinished is parked for the next one
       hipLaunchKernelGGL((pool_kernel<K, C, H, false>), dim3(grid), dim3(kPoolBlock), lds_bytes, s, a);
+    else                    // a launch that drains its own stragglers
+      hipLaunchKernelGGL((pool_job_kernel<K, C, H>), dim3(grid), dim3(kPoolBlock), lds_bytes, s, a);
     return hipGetLastError();
   });
 }
@@ -55,6 +57,9 @@ hipError_t lds_attr_kind(int res, int lds_bytes) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (r != hipSuccess) return r;
     r = hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_drain_kernel<K, C, H>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (r != hipSuccess) return r;
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_job_kernel<K, C, H>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (r != hipSuccess) return r;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&pool_kernel<K, C, H, true>),

@@ -301,6 +301,21 @@ static __device__ unsigned long long g_pool_stats[5][8];   // rows 3 / 4: cycles
 constexpr int kPoolMoves = R3D_POOL_MOVES;
 constexpr int kPoolMovesThin = 32;   // (bounded, so that a drained launch with carry-over still parks promptly)
 constexpr unsigned kMoveAgainLanes = R3D_POOL_MOVE_AGAIN;
+// The drain of a launch that finishes its own stragglers (the ids are out, ever fewer histories are
+// alive): a wave that has served a THIN batch -- no more than kTailBatch slots -- KEEPS those slots
+// for as long as they all want the same next phase, and serves that phase itself: no hand-off, no
+// take, nobody to wait for.  What a drain waits for are the longest histories' serial chains, and
+// alone on the chip a history's queue round trips were 15 % (tetra) to 33 % (layered: every move of a
+// reverberating phonon ends in a reflection) of its chain (tools/lone_history_stats.py).  Kept lanes
+// that want DIFFERENT phases would be served one phase after the other, where the queues hand them to
+// different waves at once (whole batches kept whatever they want: LopNor's flush 11.1 -> 14.1 ms): a
+// batch that disagrees goes back to the queues, which also regroup the stragglers.  No more than
+// kPoolWaves - kTailServers waves keep lanes at a time, so that what waits in a queue is always served.
+#ifndef R3D_POOL_TAIL_BATCH
+#define R3D_POOL_TAIL_BATCH 16
+#endif
+constexpr uint32_t kTailBatch = R3D_POOL_TAIL_BATCH, kTailServers = 2;
+constexpr int kKeepersWord = 7;   // PoolCtl::word[kKeepersWord]: waves that keep lanes at the moment
 // Entries a minor phase's queue must hold before a wave goes for it.
 #ifndef R3D_POOL_MINOR_FULL
 #define R3D_POOL_MINOR_FULL 64
@@ -310,7 +325,9 @@ constexpr uint32_t kMinorFull = R3D_POOL_MINOR_FULL;
 // LDS_CELLS / LDS_SCAT: the cell records / the scatterer heads are staged in LDS (models with a few
 // dozen cells; all but models with thousands of scatterers).  The receiver tables are read through
 // L1 / L2 (a collection phase serves 64 arrivals at once, so their latency is paid per batch).
-template <int KIND, bool LDS_CELLS, bool LDS_SCAT, bool TRACE>
+// TAIL: the launch drains its own stragglers (no carry-over to a next launch), and its last stretch keeps
+// lanes (kTailBatch above); the step launches of a carry chain are compiled without that code.
+template <int KIND, bool LDS_CELLS, bool LDS_SCAT, bool TRACE, bool TAIL>
 __device__ __forceinline__ void pool_body(const KArgs& a) {
   using Cell = typename CellOf<KIND>::type;
   constexpr bool LDS_SEIS = false;
@@ -521,16 +538,28 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   // vector registers spilled, against 15-43 and 0-4 this way.
   typedef const __attribute__((address_space(4))) KArgs* KernArgs;
   KernArgs args = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();   // (KArgs is the kernels' only parameter)
+  // the drain (kTailBatch above): the lanes that keep their slot, and the phase they all want next
+  bool held = false;
+  bool ids_out = false;   // (wave-uniform) the id counter was seen exhausted
+  int dest = Q_FREE;
+  unsigned id = 0;
   for (;;) {
     asm volatile("" : "+s"(args));
     const KArgs& a = *(const KArgs*)args;   // (shadows the parameter: the same values, fetched afresh)
     int q;
-    unsigned id, k;
+    unsigned k;
     bool act;
 #ifdef R3D_PHASE_TIMING
     unsigned long long t_pop = __builtin_readcyclecounter();
 #endif
-    {
+    const unsigned long long held_m = TAIL ? ballot(held) : 0ull;
+    const bool was_held = held_m != 0ull;
+    if (was_held) {
+      // ---- kept lanes: they all want the same phase ----
+      q = __builtin_amdgcn_readlane(dest, __ffsll((long long)held_m) - 1);
+      act = held;
+      k = (unsigned)__popcll(held_m);
+    } else {
       // ---- choose a queue: a full batch of a minor phase first (they all feed MOVE), then a
       //      refill, then MOVE; with no full batch anywhere, the fullest queue ----
       // (lane j looks at queue j: one compare for all of them, then scalar tests of the lane mask)
@@ -563,6 +592,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         continue;
       }
       const uint32_t wq = (uint32_t)__builtin_amdgcn_readlane((int)snap, q);
+      ids_out = drained != 0u;
       R3D_PRIO_HIGH();
       k = q_pop(ctl, ring(q), rmask, rlog, q, lane, wq, id);
 #ifdef R3D_PRIO_NARROW
@@ -578,7 +608,9 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #ifdef R3D_PHASE_TIMING
     const unsigned long long t_begin = __builtin_readcyclecounter();
 #endif
-    int dest = Q_FREE;   // where each active lane's slot goes after this phase
+    // where each active lane's slot goes after this phase (kept lanes outside this batch: as it stands)
+    if constexpr (TAIL) dest = act ? Q_FREE : dest;
+    else dest = Q_FREE;
     // the batch's event counts (wave-uniform; scalar registers), added to the block's tallies together below
     uint32_t n_iter = 0, n_transfer = 0, n_reflect = 0, n_generated = 0, n_collect = 0, n_catch = 0;
     n_lost = 0, n_timeout = 0;
@@ -830,8 +862,39 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
     const unsigned long long t_push = __builtin_readcyclecounter();
 #endif
     R3D_PRIO_HIGH();
-    if (q == Q_RT || q == Q_SCATTER) q_push_one(ctl, rings, rcap, rlog, Q_MOVE, lane, k, id);   // (all on to MOVE)
+    bool keep_lanes = false;   // (wave-uniform) this batch's slots stay with the wave
+    if constexpr (TAIL) {
+      const bool alive = act && dest != Q_FREE;
+      const unsigned long long alive_m = ballot(alive);
+      if (kTailBatch != 0u && ids_out && !a.carry_out && k <= kTailBatch && alive_m) {
+        const int d0 = __builtin_amdgcn_readlane(dest, __ffsll((long long)alive_m) - 1);
+        keep_lanes = !any_lane(alive && dest != d0);   // they agree on what comes next
+      }
+      if (keep_lanes && !was_held) {   // one more wave that keeps lanes: only while enough others serve the queues
+        uint32_t n = 0;
+        if (lane == 0) n = atomicAdd(&ctl.word[kKeepersWord], 1u);
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)n) >= (uint32_t)kPoolWaves - kTailServers) {
+          if (lane == 0) atomicSub(&ctl.word[kKeepersWord], 1u);
+          keep_lanes = false;
+        }
+      } else if (was_held && !keep_lanes) {
+        if (lane == 0) atomicSub(&ctl.word[kKeepersWord], 1u);
+      }
+    }
+    if (TAIL && keep_lanes) {
+      // the slots' state is in LDS as for a hand-off and their next phase reads it back; only the slots of
+      // histories that ended go back (the workgroup's count of free slots is how everyone learns that the
+      // launch is over)
+      const bool ended = act && dest == Q_FREE;
+      if (any_lane(ended)) q_push_all(ctl, rings, rcap, rlog, lane, ended, Q_FREE, id);
+      held = act && dest != Q_FREE;
+      // (kept lanes sit in the wave's low lanes or anywhere: a phase only looks at `act`)
+    } else if (!was_held && (q == Q_RT || q == Q_SCATTER))
+      q_push_one(ctl, rings, rcap, rlog, Q_MOVE, lane, k, id);   // (all on to MOVE; a batch fresh from a queue sits in lanes 0 .. k-1)
     else q_push_all(ctl, rings, rcap, rlog, lane, act, dest, id);
+    if constexpr (TAIL) {
+      if (!keep_lanes) held = false;
+    }
 #ifdef R3D_PRIO_NARROW
     R3D_PRIO_LOW();
 #endif
@@ -879,15 +942,23 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   if (tid < R3D_N_SCALARS && s_tally[tid] != 0ull) atomicAdd(a_end.scalars + tid, s_tally[tid]);
 }
 
-// The traversal kernel, and the same body under a second name for the flush launch of a carry
-// chain (no new ids, only the histories carried over), so that profiles list the two apart.
+// The traversal kernel under four names, so that profiles list the roles apart:
+//   pool_kernel<..., false>  a step launch of a carry chain (parks what is unfinished: no tail)
+//   pool_job_kernel          a self-contained production launch (r3d_run, r3d_run_device, the last launch
+//                            of a chain when it brings ids of its own): drains its own stragglers
+//   pool_drain_kernel        the flush launch of a carry chain (no new ids, only the histories carried over)
+//   pool_kernel<..., true>   the diagnostic kernel (final records, report stream)
 template <int KIND, bool LDS_CELLS, bool LDS_SCAT, bool TRACE>
 __global__ __launch_bounds__(kPoolBlock) void pool_kernel(const KArgs a) {
-  pool_body<KIND, LDS_CELLS, LDS_SCAT, TRACE>(a);
+  pool_body<KIND, LDS_CELLS, LDS_SCAT, TRACE, TRACE>(a);
+}
+template <int KIND, bool LDS_CELLS, bool LDS_SCAT>
+__global__ __launch_bounds__(kPoolBlock) void pool_job_kernel(const KArgs a) {
+  pool_body<KIND, LDS_CELLS, LDS_SCAT, false, true>(a);
 }
 template <int KIND, bool LDS_CELLS, bool LDS_SCAT>
 __global__ __launch_bounds__(kPoolBlock) void pool_drain_kernel(const KArgs a) {
-  pool_body<KIND, LDS_CELLS, LDS_SCAT, false>(a);
+  pool_body<KIND, LDS_CELLS, LDS_SCAT, false, true>(a);
 }
 
 }  // namespace r3d

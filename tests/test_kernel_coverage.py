@@ -28,8 +28,9 @@ def test_every_compiled_traversal_kernel_has_a_parity_case(lib):
     compiled = K.traversal_variants(os.path.join(REPO, "radiative3d_amd", "lib", lib))
     assert compiled, "no traversal kernels found in " + lib
     cases = {(k, r) for k, r, _ in _kernel_cases()}
-    # each GPU case runs the diagnostic kernel, the production kernel and the drain kernel of its variant
-    covered = {(k, r, role) for (k, r) in cases for role in ("trace", "production", "drain")}
+    # each GPU case runs the diagnostic kernel (r3d_run_traced), the self-contained production kernel (r3d_run:
+    # pool_job_kernel), the chain-step kernel (r3d_run_device_carry) and the drain kernel (the chain's flush) of its variant
+    covered = {(k, r, role) for (k, r) in cases for role in ("trace", "job", "production", "drain")}
     assert compiled == covered, (sorted(compiled - covered), sorted(covered - compiled))
 
 

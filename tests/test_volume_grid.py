@@ -110,7 +110,7 @@ def test_pairs_of_a_grid_and_their_add_rebuild_the_grid(models):
         n, p = compact(b, e_)
         want = np.flatnonzero(host[b:e_]) + b
         assert n == want.size and (p[:, 0] == want).all() and (p[:, 1] == host[want]).all(), (b, e_)
-    assert np.count_nonzero(host) > 50000
+    assert np.count_nonzero(host) > 20000
     n_small, p_small = compact(0, n_cells, capacity=1000)            # too small a buffer: counted, not written past it
     assert n_small == np.count_nonzero(host) and p_small.shape[0] == 1000 and (host[p_small[:, 0]] == p_small[:, 1]).all()
     n, _ = compact(0, n_cells)

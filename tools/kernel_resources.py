@@ -56,8 +56,9 @@ def kernel_rows(lib=DEFAULT_LIB):
 
 def traversal_variants(lib=DEFAULT_LIB):
     """{(cell kind, table residency, role)} of the traversal kernels compiled into `lib`; role is
-    "trace" (pool_kernel<..., true>: final records / report stream), "production" (pool_kernel<..., false>)
-    or "drain" (pool_drain_kernel: a chain's flush).  Residency: 0 cells + scatterer heads in LDS,
+    "trace" (pool_kernel<..., true>: final records / report stream), "production" (pool_kernel<..., false>:
+    a step launch of a carry chain), "job" (pool_job_kernel: a self-contained production launch) or
+    "drain" (pool_drain_kernel: a chain's flush).  Residency: 0 cells + scatterer heads in LDS,
     1 heads only, 2 neither."""
     res_of = {("true", "true"): 0, ("false", "true"): 1, ("false", "false"): 2}
     found = set()
@@ -66,9 +67,9 @@ def traversal_variants(lib=DEFAULT_LIB):
         if m:
             found.add((int(m.group(1)), res_of[(m.group(2), m.group(3))], "trace" if m.group(4) == "true" else "production"))
             continue
-        m = re.match(r"void pool_drain_kernel<(\d), (true|false), (true|false)>", r["demangled"])
+        m = re.match(r"void pool_(drain|job)_kernel<(\d), (true|false), (true|false)>", r["demangled"])
         if m:
-            found.add((int(m.group(1)), res_of[(m.group(2), m.group(3))], "drain"))
+            found.add((int(m.group(2)), res_of[(m.group(3), m.group(4))], m.group(1)))
     return found
 
 

@@ -18,7 +18,12 @@ for i in range(k + 1):
         ms.append(e.last_kernel_ms())
 e.run_device(0, 0, 0x5EED, *buf.pointers(), carry="final"); torch.cuda.synchronize()
 flush = e.last_kernel_ms()
+lone = []
+for i in range(3):   # self-contained launches of the same size (each drains its own stragglers)
+    e.run_device(n, (1 << 40) + i * n, 0x5EED, *buf.pointers()); torch.cuda.synchronize()
+    lone.append(e.last_kernel_ms())
+lone.sort()
 ms.sort()
-print("%-28s %s deg %d n %d: chained launch %.2f ms median (min %.2f), flush %.2f ms -> %.3e hist/s" % (
-    os.path.basename(os.environ.get("R3D_HIP_LIB", "libr3d_hip.so")), name, deg, n, ms[len(ms) // 2], ms[0], flush,
+print("%-28s %s deg %d n %d: chained launch %.2f ms median (min %.2f), flush %.2f ms, self-contained launch %.2f ms -> %.3e hist/s" % (
+    os.path.basename(os.environ.get("R3D_HIP_LIB", "libr3d_hip.so")), name, deg, n, ms[len(ms) // 2], ms[0], flush, lone[1],
     n / ms[len(ms) // 2] * 1e3), flush=True)
