@@ -112,5 +112,10 @@ def upthrust(deg=4):
             "--seis-p2p=0,112.5,0,950,112.5,0,1.0,2.0,40.0,40").split()
 
 
-CONFIGS = {"halfspace": halfspace, "crustpinch": crustpinch, "crustpinch_vids": crustpinch_vids, "lopnor": lopnor, "sphere": sphere, "sphere_deep": sphere_deep,
+def halfspace_one(deg=9):
+    """BASELINE config 1 as it names it: the half-space run with one receiver."""
+    return halfspace(deg, one_receiver=True)
+
+
+CONFIGS = {"halfspace": halfspace, "halfspace_one": halfspace_one, "crustpinch": crustpinch, "crustpinch_vids": crustpinch_vids, "lopnor": lopnor, "sphere": sphere, "sphere_deep": sphere_deep,
            "toysphere_vids": toysphere_vids, "lopnor_vids": lopnor_vids, "upthrust": upthrust}

@@ -11,7 +11,7 @@
 // So each rank compacts, per owner of a frame range, the non-zero counters of that range; the
 // pairs travel point to point; the owner adds what it receives into its own range.
 //
-// Both kernels are HBM-bound streaming work: 16-byte loads, one atomic per 16 KB tile to claim
+// Both kernels are HBM-bound streaming work: 16-byte loads, one atomic per 32 KB tile to claim
 // output space, pairs written as 8-byte stores; the add is one 32-bit atomic per pair.
 #include <hip/hip_runtime.h>
 
@@ -26,11 +26,14 @@ extern thread_local std::string g_error;
 namespace {
 
 constexpr int kCompactBlock = 256;
-constexpr int kQuadsPerThread = 4;                                      // 4 x 16 B per thread
-constexpr uint64_t kTileCounters = (uint64_t)kCompactBlock * kQuadsPerThread * 4;   // 4096 counters = 16 KB per tile
+#ifndef R3D_COMPACT_QUADS
+#define R3D_COMPACT_QUADS 8
+#endif
+constexpr int kQuadsPerThread = R3D_COMPACT_QUADS;                       // 8 x 16 B per thread in flight
+constexpr uint64_t kTileCounters = (uint64_t)kCompactBlock * kQuadsPerThread * 4;   // 8192 counters = 32 KB per tile
 
 // Non-zero counters of [begin, end) as (global index, count) pairs, in no particular order.
-// One workgroup per 16 KB tile, grid-stride: every thread holds four 16-byte quads of the tile in
+// One workgroup per 32 KB tile, grid-stride: every thread holds eight 16-byte quads of the tile in
 // registers (quad q of thread t = quad q * 256 + t of the tile: coalesced), counts its non-zeros,
 // the workgroup's exclusive scan gives each thread its place, ONE atomic claims the tile's output
 // range.  Pairs beyond `capacity` are counted but not written (the caller sees *n > capacity and
@@ -39,8 +42,9 @@ __global__ __launch_bounds__(kCompactBlock) void volume_compact_kernel(const uin
                                                                         uint64_t begin, uint64_t end,
                                                                         uint2* __restrict__ pairs, uint64_t capacity,
                                                                         unsigned long long* __restrict__ n_out) {
-  __shared__ uint32_t s_wave[kCompactBlock / 64];
+  __shared__ uint32_t s_waves[2][kCompactBlock / 64];   // (two sets, used in turn: a tile's sums are still being read while the next tile's are written)
   __shared__ unsigned long long s_base;
+  unsigned turn = 0;
   const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint64_t n_tiles = (end - begin + kTileCounters - 1) / kTileCounters;
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -67,6 +71,8 @@ __global__ __launch_bounds__(kCompactBlock) void volume_compact_kernel(const uin
       const uint32_t y = __shfl_up(incl, off);
       if (lane >= (unsigned)off) incl += y;
     }
+    uint32_t* const s_wave = s_waves[turn];
+    turn ^= 1u;
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
     uint32_t before = 0, total = 0;
@@ -76,9 +82,10 @@ __global__ __launch_bounds__(kCompactBlock) void volume_compact_kernel(const uin
       before += (unsigned)w < wave ? c : 0u;
       total += c;
     }
-    if (tid == 0 && total) s_base = atomicAdd(n_out, (unsigned long long)total);
+    if (total == 0) continue;   // (a tile without a single event -- most of a 0.5 % full grid -- costs one barrier)
+    if (tid == 0) s_base = atomicAdd(n_out, (unsigned long long)total);
     __syncthreads();
-    if (total) {
+    {
       unsigned long long at_out = s_base + before + (incl - mine);
 #pragma unroll
       for (int k = 0; k < kQuadsPerThread; k++) {
@@ -92,7 +99,8 @@ __global__ __launch_bounds__(kCompactBlock) void volume_compact_kernel(const uin
           }
       }
     }
-    __syncthreads();   // (s_wave and s_base are written again by the next tile)
+    // (no barrier here: the next tile writes the OTHER set of sums, and s_base only behind its own first barrier,
+    //  which every thread reaches after it has read this tile's)
   }
 }
 
