@@ -30,16 +30,18 @@ labels = {"crustpinch": "crustpinch, 5 steps", "halfspace": "halfspace (one rece
 
 def row(b, label, bold=False):
     r, sl, cpu, env = b["roofline"], b.get("single_launch") or {}, b.get("cpu_baseline") or {}, b.get("envelope") or {}
+    job = b.get("job") or {}
     v = f"{b['value']:.2e}"
     v = f"**{v}**" if bold else v
     e = (f"{env['rms_sigma']:.2f} / {env['rms_sigma_gpu_vs_gpu_same_batches']:.2f}, {env['bins']} bins"
          if env.get("rms_sigma") else "-")
     return (f"| {label} | {v} | {r['kernel_ms_step_avg']:.2f} ms | {sum(r['kernel_ms_flush']):.2f} ms | "
-            f"{sl.get('kernel_ms', 0):.1f} ms = {sl.get('value', 0):.2e}/s | {cpu.get('value', 0):.2e}/s ({cpu.get('cores')} threads) | {e} |")
+            f"{sl.get('kernel_ms', 0):.1f} ms = {sl.get('value', 0):.2e}/s | {job.get('histories', 0):.0e} in {job.get('ms', 0):.1f} ms = {job.get('value', 0):.2e}/s | "
+            f"{cpu.get('value', 0):.2e}/s ({cpu.get('cores')} threads) | {e} |")
 
 
-meas = ["| config (`bench.py --config`) | histories/s | step launch | flush | one self-contained launch | CPU port (1e7-history sample where it fits 25 s) | envelope RMS (GPU vs CPU / GPU vs GPU) |",
-        "|---|---:|---:|---:|---:|---:|---:|",
+meas = ["| config (`bench.py --config`) | histories/s | step launch | flush | one self-contained launch of 1e7 | the BASELINE job as stated (one GPU) | CPU port (1e7-history sample where it fits 25 s) | envelope RMS (GPU vs CPU / GPU vs GPU) |",
+        "|---|---:|---:|---:|---:|---:|---:|---:|",
         row(line("crustpinch_steps20_warmup5"), "crustpinch (headline), 20 steps + 5 warm-up (the driver's command)", True)]
 for c in labels:
     meas.append(row(line(c), labels[c], c == "sphere"))
