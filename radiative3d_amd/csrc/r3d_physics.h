@@ -787,6 +787,20 @@ R3D_HD uint64_t sample_cdf_guided(const double* __restrict__ cdf_, const GuideCe
   }
   return lo;
 }
+// One word of the guide cell a draw will read (sample_cdf_guided): the fetch brings the cell's 64-byte
+// sector near without holding sixteen registers for it.  For callers that start several draws and want
+// their cells on the way before they look at the first (the pool's refill).
+R3D_HD uint32_t guide_touch(const GuideCell* __restrict__ guide_, uint32_t bits, double u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(1))) const GuideCell gcell;
+  gcell* guide = (gcell*)guide_;
+#else
+  const GuideCell* guide = guide_;
+#endif
+  uint32_t j = (uint32_t)(u * (double)(1u << bits));
+  if (j > (1u << bits) - 1u) j = (1u << bits) - 1u;
+  return guide[j].k1;
+}
 R3D_HD int sample_small(const double* cdf, int n, double u) {
   const double r = cdf[n - 1] * u;
   int k = n - 1;

@@ -316,6 +316,20 @@ constexpr unsigned kMoveAgainLanes = R3D_POOL_MOVE_AGAIN;
 #endif
 constexpr uint32_t kTailBatch = R3D_POOL_TAIL_BATCH, kTailServers = 2;
 constexpr int kKeepersWord = 7;   // PoolCtl::word[kKeepersWord]: waves that keep lanes at the moment
+// A refill starts kRefillBatches batches of histories at a time, their table fetches set going together (the
+// FREE phase below); the FREE queue counts as full for the scheduler at kRefillFull entries.
+#ifndef R3D_POOL_REFILL_PAIRS
+#define R3D_POOL_REFILL_PAIRS 1
+#endif
+constexpr bool kRefillPairs = R3D_POOL_REFILL_PAIRS != 0;
+#ifndef R3D_POOL_REFILL_BATCHES
+#define R3D_POOL_REFILL_BATCHES 2
+#endif
+constexpr int kRefillBatches = R3D_POOL_REFILL_BATCHES;
+#ifndef R3D_POOL_REFILL_FULL
+#define R3D_POOL_REFILL_FULL (R3D_POOL_REFILL_PAIRS ? 64 * R3D_POOL_REFILL_BATCHES : 64)
+#endif
+constexpr uint32_t kRefillFull = R3D_POOL_REFILL_FULL;
 // Entries a minor phase's queue must hold before a wave goes for it.
 #ifndef R3D_POOL_MINOR_FULL
 #define R3D_POOL_MINOR_FULL 64
@@ -331,6 +345,10 @@ template <int KIND, bool LDS_CELLS, bool LDS_SCAT, bool TRACE, bool TAIL>
 __device__ __forceinline__ void pool_body(const KArgs& a) {
   using Cell = typename CellOf<KIND>::type;
   constexpr bool LDS_SEIS = false;
+  // refills in pairs of batches (the FREE phase): not in the tetra kernel, whose boundary search leaves the
+  // register allocator no slack at all -- the pair's second queue take alone had it spill two registers in the
+  // move, and 64 slots waiting for their partners are a smaller pool (NSCP +3 % with it, half-space -10 %)
+  constexpr bool kPairs = kRefillPairs && KIND != CELL_TET;
   extern __shared__ __align__(16) unsigned char smem[];
   const unsigned tid = threadIdx.x, lane = tid & 63u;
 
@@ -568,7 +586,8 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       if (drained && a.carry_out) break;   // no ids left: the pool is parked as it is for the next launch
       const uint32_t cnt = snap & 0xFFFFu;
       const bool minor = lane == (unsigned)Q_RT || lane == (unsigned)Q_COLLECT || lane == (unsigned)Q_SCATTER;
-      uint32_t full = (uint32_t)ballot(cnt >= (minor ? kMinorFull : 64u)) & ((1u << Q_NUM) - 1u);
+      // (a refill waits for two batches of free slots: it starts them together, see the FREE phase)
+      uint32_t full = (uint32_t)ballot(cnt >= (minor ? kMinorFull : (kPairs && lane == (unsigned)Q_FREE) ? kRefillFull : 64u)) & ((1u << Q_NUM) - 1u);
       if (drained) {
         if ((uint32_t)__builtin_amdgcn_readlane((int)cnt, Q_FREE) == S) break;   // every slot is free and nothing is left to hand out
         full &= ~(1u << Q_FREE);                                                  // (free slots are of no use any more)
@@ -620,26 +639,77 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #endif
     if (q == Q_FREE) {
       // ---- fresh histories: ids from the global counter, source spray (events.cpp:111-124) ----
+      // A refill starts TWO batches of histories at a time (kRefillBatches; the scheduler lets the FREE queue
+      // fill that far before a wave goes for it).  A spray is two dependent
+      // fetches from tables of hundreds of MB (the guide cell of the take-off draw, then the direction
+      // record) with a few dozen instructions between them: a refill spends its time waiting for them, and
+      // the single-receiver half-space run is all refill (67 % of its wave-cycles were such waits).  So the
+      // fetches of BOTH batches are set going first -- one word of every guide cell, then, as those come in,
+      // one word of every direction record (spray_touch) -- and the sprays proper find their tables near:
+      // two memory round trips per pair of batches where there were four (single-receiver half-space run: step
+      // launch 2.00 -> 1.81 ms; three or four batches at a time: 1.77 / 1.79).  Nothing is held in registers
+      // between the passes but the touched words (both cells in registers at once made the register
+      // allocator spill forty of the kernel's long-lived values, in every phase); each pass evaluates the
+      // generator again.
+      unsigned ids[kRefillBatches];   // (only ever indexed by constants: registers)
+      ids[0] = id;
+      unsigned n_b = 1u;                // (wave-uniform) batches in hand; batch h takes the ids behind batch h - 1's
+      if (kPairs && k == 64u) {
+#pragma unroll
+        for (int h = 1; h < kRefillBatches; h++) {
+          ids[h] = 0u;
+          if (n_b == (unsigned)h) {
+            const uint32_t w2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_ld(&ctl.word[Q_FREE]));
+            if ((w2 & 0xFFFFu) >= 64u && q_pop(ctl, ring(Q_FREE), rmask, rlog, Q_FREE, lane, w2, ids[h]) == 64u) n_b++;
+          }
+        }
+      }
+      const unsigned want = k + (n_b - 1u) * 64u;
       unsigned long long base = 0;
-      if (lane == 0) base = atomicAdd(a.next, (unsigned long long)k);
+      if (lane == 0) base = atomicAdd(a.next, (unsigned long long)want);
       base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(base >> 32), 0) << 32) |
              (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
-      const unsigned take = base >= a.n ? 0u : (a.n - base < k ? (unsigned)(a.n - base) : k);
-      if (take < k && lane == 0)
+      const unsigned take = base >= a.n ? 0u : (a.n - base < want ? (unsigned)(a.n - base) : want);
+      if (take < want && lane == 0)
         __hip_atomic_store(&ctl.word[kDrainedWord], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const bool fresh = lane < take;
+      if (kPairs && n_b > 1u) {
+        uint32_t near_w = 0;
+#pragma nounroll
+        for (unsigned h = 0; h < n_b; h++)
+          if (lane + h * 64u < take) near_w ^= spray_touch<0>(a, a.first_id + base + h * 64u + lane);
+        R3D_SCHED_FENCE();
+#pragma nounroll
+        for (unsigned h = 0; h < n_b; h++)
+          if (lane + h * 64u < take) near_w ^= spray_touch<1>(a, a.first_id + base + h * 64u + lane);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(near_w));   // (the touches are not to be dropped; their words have arrived by the time they are asked for)
+#endif
+      }
       Phonon p;
       uint64_t hid = 0;
-      if (fresh) {
-        Rng rng;
-        hid = a.first_id + base + lane;
-        rng_init(rng, hid);
-        spray(a, p, rng);
-        store_state(id, p, rng, meta_pack(p.type, -1, 0u, Q_MOVE));
-        pu[U_ID * F + id] = U4{rng.id_lo, rng.id_hi, 0u, 0u};
-        dest = Q_MOVE;
+      bool fresh = false;
+#pragma nounroll
+      for (unsigned h = 0; h < n_b; h++) {
+        unsigned slot = ids[0];
+#pragma unroll
+        for (int j = 1; j < kRefillBatches; j++) slot = h == (unsigned)j ? ids[j] : slot;
+        fresh = lane + h * 64u < take;
+        hid = a.first_id + base + h * 64u + lane;
+        if (fresh) {
+          Rng rng;
+          rng_init(rng, hid);
+          spray(a, p, rng);
+          store_state(slot, p, rng, meta_pack(p.type, -1, 0u, Q_MOVE));
+          pu[U_ID * F + slot] = U4{rng.id_lo, rng.id_hi, 0u, 0u};
+        }
+        report(fresh, 0, p, hid);   // GEN
+        if (h == 0) dest = fresh ? Q_MOVE : dest;
+        else {   // the later batches' slots are handed on here; the first's with everyone else's below
+          R3D_PRIO_HIGH();
+          q_push_all(ctl, rings, rcap, rlog, lane, true, fresh ? Q_MOVE : Q_FREE, slot);
+          R3D_PRIO_LOW();
+        }
       }
-      report(fresh, 0, p, hid);   // GEN
       if constexpr (kVectorTally) n_generated = take;
       else tally_n(kEv + R3D_EV_GENERATED, take);
     } else if (q == Q_MOVE) {

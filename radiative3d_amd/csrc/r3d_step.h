@@ -124,6 +124,33 @@ R3D_HD void spray(const KArgs& a, Phonon& p, Rng& rng) {
   p.cell = a.src_cell;
 }
 
+// The same draws, stopped early: spray_touch(level 0) requests one word of the guide cell the take-off draw
+// will read, spray_touch(level 1) goes on to the take-off index and requests one word of its direction
+// record.  A caller that starts several batches of histories runs these ahead of the sprays proper, so that
+// the two dependent fetches of a spray -- from tables of hundreds of MB -- are on their way for all of
+// them at once; the words themselves mean nothing (the caller only keeps them alive until the sprays).
+// The generator is evaluated again by each: instructions are what a refill has to spare.
+template <int LEVEL>
+R3D_HD uint32_t spray_touch(const KArgs& a, uint64_t hid) {
+  Rng rng;
+  rng_init(rng, hid);
+  double u_type, u_dir;
+  rng_draw_pair(rng, rng_key(a.seed), u_type, u_dir);
+  const double r3 = a.src_whole[2] * u_type;
+  const int rt3 = (r3 <= a.src_whole[0]) ? 0 : (r3 <= a.src_whole[1]) ? 1 : 2;
+  const GuideCell* guide = rt3 == 0 ? a.src_guide[0] : rt3 == 1 ? a.src_guide[1] : a.src_guide[2];
+  if (LEVEL == 0) return guide_touch(guide, a.guide_bits, u_dir);
+  const double* cdf = rt3 == 0 ? a.src_cdf[0] : rt3 == 1 ? a.src_cdf[1] : a.src_cdf[2];
+  const double total = rt3 == 0 ? a.src_total[0] : rt3 == 1 ? a.src_total[1] : a.src_total[2];
+  const uint64_t k = sample_cdf_guided(cdf, guide, a.guide_bits, total, u_dir);
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(1))) const uint32_t gword;
+  return *(gword*)(a.toa_dir + 4 * k);
+#else
+  return (uint32_t)k;
+#endif
+}
+
 // ---- seismometers ----------------------------------------------------------
 // reference DataReporter::ReportPhononCollected (dataout.cpp:545-568) +
 // Seismometer::CatchPhonon (dataout.cpp:103-216).  The reference tests every
