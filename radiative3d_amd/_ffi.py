@@ -191,6 +191,10 @@ def hip_lib(reproducible=False, path=None):
     here or in the library reads the environment."""
     key = os.path.abspath(path) if path else bool(reproducible)
     if key not in _hip:
+        # One HIP runtime per process: torch ships its own libamdhip64, and whichever copy is loaded first
+        # serves everyone (same SONAME).  The harness allocates result blocks and grids as torch tensors, so
+        # torch's copy has to be that one -- loaded the other way round, torch finds "no HIP GPUs".
+        import torch  # noqa: F401
         L = _load(path or os.path.join(LIBDIR, "libr3d_hip_repro.so" if reproducible else "libr3d_hip.so"))
         L.r3d_engine_create.restype = C.c_void_p
         L.r3d_engine_create.argtypes = [C.POINTER(ModelDesc), C.c_int]

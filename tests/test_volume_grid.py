@@ -136,3 +136,50 @@ def test_pairs_of_a_grid_and_their_add_rebuild_the_grid(models):
     vol.detach()
     e.close()
     del C
+
+
+@pytest.mark.gpu
+def test_grid_by_frame_between_two_shards_on_one_gpu(models):
+    """The sparse reduction by frame (parallel.DeviceVolume.reduce_scatter_frames_) with the HIP kernels doing
+    the work and the exchange done by hand: two shards of one job fill two grids on the one GPU of the box (the
+    box has no second one for a process group), each compacts the other's frames (r3d_volume_compact) and adds
+    what it is handed (r3d_volume_scatter_add) -- every owner's frames must equal the oracle's grid of the whole
+    job.  (World sizes 2 and 3 through a real process group: tests/test_multi_rank_gloo.py, host tensors.)"""
+    import torch
+    from radiative3d_amd import Engine
+    from radiative3d_amd.parallel import DeviceVolume, shard_range
+    m = models("crustpinch", 4, VIDEO)
+    n, world = 24000, 3
+    _, want = O.run_with_volume(m, n, volume_desc(**GRID))
+    vols = []
+    for r in range(world):
+        e = Engine(m)
+        v = DeviceVolume(e, device="cuda:0", **GRID)
+        lo, hi = shard_range(n, r, world)
+        e.run(hi - lo, first_id=lo)
+        torch.cuda.synchronize()
+        v.detach()
+        e.close()
+        vols.append(v)
+    cap = vols[0].counters.numel() // 4
+    sent = []
+    for r, v in enumerate(vols):                       # every rank's pairs, owner by owner
+        pairs = torch.empty((cap, 2), dtype=torch.int32, device="cuda:0")
+        n_dev = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+        ends = []
+        for owner in range(world):
+            if owner != r:
+                for b, e_ in v._segments(*v.frame_range(owner, world)):
+                    v._compact(b, e_, pairs, n_dev, cap)
+            ends.append(int(n_dev.item()))
+        assert ends[-1] <= cap
+        sent.append((pairs, ends))
+    for owner, v in enumerate(vols):                   # the hand-over, then the owner's add
+        for r, (pairs, ends) in enumerate(sent):
+            if r != owner:
+                v._scatter_add(pairs[(ends[owner - 1] if owner else 0):ends[owner]])
+        v.owned = v.frame_range(owner, world)
+        lo, hi, got = v.frames_numpy()
+        assert (lo, hi) == v.frame_range(owner, world) and (got == want[:, lo:hi]).all(), owner
+        assert v.saturated == 0
+    assert sum(v.total() for v in vols) == int(want.sum(dtype=np.uint64))
