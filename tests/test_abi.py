@@ -147,3 +147,23 @@ def test_engine_opts_mirror_matches_c_layout(tmp_path):
     E = _ffi.EngineOpts
     assert got == [C.sizeof(E), E.residency.offset, E.pool_slots.offset, E.accumulator_bits.offset,
                    E.lds_reserve.offset, E.size.offset]
+
+
+def test_engine_opts_are_validated_before_anything_touches_a_device(models):
+    """r3d_engine_create_ex refuses a malformed r3d_engine_opts with a message of its own (no GPU needed: the
+    check comes before the device is looked for)."""
+    lib = _ffi.hip_lib()
+    m = models("halfspace", 3)
+
+    def refused(**kw):
+        o = _ffi.EngineOpts(C.sizeof(_ffi.EngineOpts), -1, 0, -1, 0)
+        for k, v in kw.items():
+            setattr(o, k, v)
+        assert not lib.r3d_engine_create_ex(m.desc_p, 0, C.byref(o))
+        return lib.r3d_last_error().decode()
+
+    assert "size" in refused(size=8)
+    assert "residency" in refused(residency=3) and "residency" in refused(residency=-2)
+    assert "accumulator_bits" in refused(accumulator_bits=3) and "accumulator_bits" in refused(accumulator_bits=9)
+    assert "pool_slots" in refused(pool_slots=4096)
+    assert "lds_reserve" in refused(lds_reserve=1 << 20)
