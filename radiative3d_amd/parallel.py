@@ -225,8 +225,12 @@ class DeviceVolume:
         t0 = self._clock()
         if mode != "dense" and self.counters.numel() < (1 << 32):
             cap = int(pair_capacity if pair_capacity is not None else max(1024, self.counters.numel() // 16))
-            if self._reduce_scatter_sparse(rank, world, cap, t0) or mode == "sparse":
+            if self._reduce_scatter_sparse(rank, world, cap, t0):
                 return self
+            if mode == "sparse":   # (the same on every rank: they all saw the same counts)
+                raise RuntimeError("sparse reduction of the grid refused: " + self.timing["sparse_refused"])
+        elif mode == "sparse":
+            raise RuntimeError("sparse reduction of the grid needs indices below 2^32")
         headroom = self._headroom(world)
         self.widened = not headroom
         for owner in range(world):

@@ -213,6 +213,8 @@ def _frames_worker(rank, world, port, n, out_dir):
             d.to_numpy()                               # the other frames are stale: not readable as a whole grid
         d.allgather_frames_()
         assert d.owned is None and (d.to_numpy() == want).all()
+    with pytest.raises(RuntimeError, match="refused"):       # asked for by name, the sparse form does not fall back
+        fresh().reduce_scatter_frames_(mode="sparse", pair_capacity=16)
     # a reduce_ leaves the other ranks with scratch that refuses to be read
     r = fresh().reduce_(dst=world - 1)
     if rank == world - 1:
