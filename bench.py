@@ -18,6 +18,11 @@ A step = one pass of the hot path (GenerateEventPhonon + Propagate) over a fresh
 history ids per GPU; tables are resident in HBM before the timed region; the per-receiver bins
 stay in HBM and are summed over ranks with one RCCL all-reduce per buffer at the end of the job,
 inside the timed region (weak scaling: every rank runs the same count).  Rank 0 prints one JSON line.
+
+Beside that figure the line carries `single_launch` (one self-contained launch of the step's size) and `job`:
+the BASELINE configuration AS STATED -- config 1: 1e5 histories, config 2: 1e7, configs 3-5: 1e8 divided over the
+ranks -- as one self-contained launch per rank + the reductions, timed from the first launch to the reduced result
+("scaling": "strong").  Config 5's 10 GB event grid is reduced by frame (--volume-reduce).
 """
 import argparse
 import hashlib
