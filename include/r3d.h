@@ -374,6 +374,15 @@ int r3d_volume_compact(int device, const uint32_t* d_counters, uint64_t begin, u
 int r3d_volume_scatter_add(int device, uint32_t* d_counters, uint64_t len, const uint32_t* d_pairs, uint64_t n,
                            uint64_t* d_flags, void* stream);
 
+/* The same reduction for a host that drives its GPUs from ONE process (r3d_run_model_on's way; no
+ * communication library): engines[0 .. n-1] -- one per shard of the job, each with its own grid of one
+ * shape (r3d_engine_set_volume), on any devices, the same device included -- end up holding the job's
+ * counts for their share of the frames: engine g for frames [frames[g], frames[g + 1]) of both wave
+ * types (`frames`: n + 1 entries, may be NULL; the cut is contiguous and balanced), the rest of its grid
+ * keeps that engine's own counts.  Pairs travel by hipMemcpyPeer.  *saturated (may be NULL) receives the
+ * number of cells that reached 2^32 - 1.  Waits for every launch of the engines.  Returns 0 on success. */
+int r3d_volume_reduce_by_frame(r3d_engine* const* engines, int n, uint32_t* frames, uint64_t* saturated);
+
 /* ---- optional per-event report stream --------------------------------------
  * The reference's `--reports[=KEYWORDS]` (main.cpp:223-258) writes one text line
  * per event with the phonon's state at that moment (dataout.cpp:484-520): GEN

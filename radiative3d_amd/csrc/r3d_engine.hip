@@ -884,6 +884,82 @@ int r3d_volume_read(r3d_engine* e, uint32_t* out, int reset) {
   return 0;
 }
 
+int r3d_volume_reduce_by_frame(r3d_engine* const* engines, int n, uint32_t* frames, uint64_t* saturated) {
+  const int fail_value = 1;
+  if (!engines || n < 1) return g_error = "r3d_volume_reduce_by_frame: at least one engine is needed", 1;
+  for (int g = 0; g < n; g++) {
+    if (!engines[g] || !r3d_volume_device_ptr(engines[g])) return g_error = "r3d_volume_reduce_by_frame: an engine without a grid", 1;
+    const KArgs &a = engines[g]->args, &a0 = engines[0]->args;
+    if (engines[g]->volume_len != engines[0]->volume_len || a.vol_frames != a0.vol_frames || a.vol_dim[0] != a0.vol_dim[0] ||
+        a.vol_dim[1] != a0.vol_dim[1] || a.vol_dim[2] != a0.vol_dim[2])
+      return g_error = "r3d_volume_reduce_by_frame: the engines' grids differ in shape", 1;
+    for (int h = 0; h < g; h++)
+      if (r3d_volume_device_ptr(engines[h]) == r3d_volume_device_ptr(engines[g]))
+        return g_error = "r3d_volume_reduce_by_frame: two engines share one grid", 1;
+  }
+  const uint64_t len = engines[0]->volume_len;
+  if (len >= (uint64_t(1) << 32)) return g_error = "r3d_volume_reduce_by_frame: grids beyond 2^32 cells do not fit a pair's index", 1;
+  const uint64_t n_frames = engines[0]->args.vol_frames, frame_cells = len / (2 * n_frames);
+  // frames [lo, hi) of owner g: contiguous and balanced, as radiative3d_amd/parallel.py shard_range cuts them
+  auto frame_lo = [&](int g) { return n_frames / n * g + std::min<uint64_t>(g, n_frames % n); };
+  if (saturated) *saturated = 0;
+  const uint64_t cap = std::max<uint64_t>(1024, len / 16);
+  for (int src = 0; src < n; src++) {
+    r3d_engine* S = engines[src];
+    // every launch into this grid must have finished (they may sit on caller streams)
+    {
+      R3D_ON_DEVICE(S->device);
+      R3D_HIP_OK(hipDeviceSynchronize());
+    }
+  }
+  for (int src = 0; src < n && n > 1; src++) {
+    r3d_engine* S = engines[src];
+    R3D_ON_DEVICE(S->device);
+    DevBuf pairs, count;
+    R3D_HIP_OK(pairs.alloc_zero(cap * 2 * sizeof(uint32_t)));
+    R3D_HIP_OK(count.alloc_zero(sizeof(uint64_t)));
+    const uint32_t* grid = reinterpret_cast<const uint32_t*>(r3d_volume_device_ptr(S));
+    std::vector<uint64_t> ends(n, 0);
+    for (int owner = 0; owner < n; owner++) {
+      if (owner != src)
+        for (uint64_t t = 0; t < 2; t++) {
+          const uint64_t b = (t * n_frames + frame_lo(owner)) * frame_cells, e = (t * n_frames + frame_lo(owner + 1)) * frame_cells;
+          if (e > b && r3d_volume_compact(S->device, grid, b, e, reinterpret_cast<uint32_t*>(pairs.p), cap,
+                                          reinterpret_cast<uint64_t*>(count.p), S->stream))
+            return 1;
+        }
+      R3D_HIP_OK(hipStreamSynchronize(S->stream));
+      R3D_HIP_OK(hipMemcpy(&ends[owner], count.p, sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
+    if (ends[n - 1] > cap)
+      return g_error = "r3d_volume_reduce_by_frame: the grid is too full for the pair buffer (more than a sixteenth of its "
+                       "cells are non-zero): add the grids densely instead", 1;
+    for (int owner = 0; owner < n; owner++) {
+      const uint64_t lo = owner ? ends[owner - 1] : 0, cnt = ends[owner] - lo;
+      if (owner == src || cnt == 0) continue;
+      r3d_engine* D = engines[owner];
+      DeviceGuard on_dst(D->device);
+      R3D_HIP_OK(on_dst.status);
+      DevBuf got, flags;
+      R3D_HIP_OK(got.alloc_zero(cnt * 2 * sizeof(uint32_t)));
+      R3D_HIP_OK(flags.alloc_zero(2 * sizeof(uint64_t)));
+      // (the pairs to the owner's device: a copy between peers, or within the device when the engines share one)
+      R3D_HIP_OK(hipMemcpyPeer(got.p, D->device, reinterpret_cast<const uint32_t*>(pairs.p) + 2 * lo, S->device, cnt * 2 * sizeof(uint32_t)));
+      if (r3d_volume_scatter_add(D->device, reinterpret_cast<uint32_t*>(r3d_volume_device_ptr(D)), len,
+                                 reinterpret_cast<const uint32_t*>(got.p), cnt, reinterpret_cast<uint64_t*>(flags.p), D->stream))
+        return 1;
+      R3D_HIP_OK(hipStreamSynchronize(D->stream));
+      uint64_t f[2];
+      R3D_HIP_OK(hipMemcpy(f, flags.p, sizeof f, hipMemcpyDeviceToHost));
+      if (f[1]) return g_error = "r3d_volume_reduce_by_frame: internal error: pairs outside the grid", 1;
+      if (saturated) *saturated += f[0];
+    }
+  }
+  if (frames)
+    for (int g = 0; g <= n; g++) frames[g] = (uint32_t)frame_lo(g);
+  return 0;
+}
+
 uint64_t r3d_launch_count(const r3d_engine* e) { return e ? e->launches : 0; }
 
 int r3d_engine_variant(const r3d_engine* e) { return e ? e->kind * 4 + e->res : -1; }

@@ -684,6 +684,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" : "+v"(near_w));   // (the touches are not to be dropped; their words have arrived by the time they are asked for)
 #endif
+        (void)near_w;
       }
       Phonon p;
       uint64_t hid = 0;

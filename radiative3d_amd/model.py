@@ -227,6 +227,20 @@ def run_model(model, n, first_id=0, seed=0x5EED, n_gpus=1, devices=None):
     return res
 
 
+def reduce_volumes_by_frame(engines):
+    """r3d_volume_reduce_by_frame: the grids of several engines of ONE process (one per shard of a job, each
+    with its own grid of the same shape, on any devices) added by frame; engine g ends with the job's counts
+    for frames [frames[g], frames[g + 1]).  Returns (frames, saturated cells)."""
+    lib = engines[0]._lib
+    n = len(engines)
+    handles = (C.c_void_p * n)(*[e._e for e in engines])
+    frames = (C.c_uint32 * (n + 1))()
+    sat = C.c_uint64(0)
+    if lib.r3d_volume_reduce_by_frame(handles, n, frames, C.byref(sat)):
+        raise RuntimeError("r3d_volume_reduce_by_frame failed: " + lib.r3d_last_error().decode())
+    return list(frames), int(sat.value)
+
+
 def volume_desc(origin, cell_size, dims, n_frames, frame_dt):
     v = _ffi.VolumeDesc()
     for k in range(3):

@@ -183,3 +183,48 @@ def test_grid_by_frame_between_two_shards_on_one_gpu(models):
         assert (lo, hi) == v.frame_range(owner, world) and (got == want[:, lo:hi]).all(), owner
         assert v.saturated == 0
     assert sum(v.total() for v in vols) == int(want.sum(dtype=np.uint64))
+
+
+@pytest.mark.gpu
+def test_grids_of_one_process_reduced_by_frame_through_the_c_abi(models):
+    """r3d_volume_reduce_by_frame (include/r3d.h): what a host that drives its GPUs from one process calls after
+    r3d_run_model_on-style shards -- three engines on the box's one GPU, each with its own grid; afterwards
+    engine g holds the oracle's counts of the WHOLE job for its frames (35 frames over 3 owners: 12 + 12 + 11).
+    Reference semantics: vis/seisplot/combine.m:26-33 (replicas add), vis/scattervid/scattervid_above.m:111."""
+    from radiative3d_amd import Engine
+    from radiative3d_amd.model import reduce_volumes_by_frame
+    from radiative3d_amd.parallel import shard_range
+    m = models("crustpinch", 4, VIDEO)
+    n, world = 24000, 3
+    _, want = O.run_with_volume(m, n, volume_desc(**GRID))
+    engines = []
+    for r in range(world):
+        e = Engine(m)
+        e.set_volume(**GRID)
+        lo, hi = shard_range(n, r, world)
+        e.run(hi - lo, first_id=lo)
+        engines.append(e)
+    own = [e.read_volume() for e in engines]
+    frames, sat = reduce_volumes_by_frame(engines)
+    assert frames == [0, 12, 24, 35] and sat == 0
+    for g, e in enumerate(engines):
+        got = e.read_volume()
+        lo, hi = frames[g], frames[g + 1]
+        assert (got[:, lo:hi] == want[:, lo:hi]).all(), g
+        rest = np.ones(35, dtype=bool)
+        rest[lo:hi] = False
+        assert (got[:, rest] == own[g][:, rest]).all()            # the other frames keep the engine's own counts
+    # one engine: nothing to add, the frames are all its own
+    assert reduce_volumes_by_frame(engines[:1]) == ([0, 35], 0)
+    # refusals: an engine without a grid, grids of different shapes, one grid twice
+    bare = Engine(m)
+    with pytest.raises(RuntimeError, match="without a grid"):
+        reduce_volumes_by_frame([engines[0], bare])
+    other = dict(GRID, n_frames=7)
+    bare.set_volume(**other)
+    with pytest.raises(RuntimeError, match="differ in shape"):
+        reduce_volumes_by_frame([engines[0], bare])
+    with pytest.raises(RuntimeError, match="share one grid"):
+        reduce_volumes_by_frame([engines[0], engines[0]])
+    for e in engines + [bare]:
+        e.close()
