@@ -89,12 +89,14 @@ def algorithmic_bytes_per_history(ev, n_toa, n_seis, cell_kind):
 
 
 def kernel_source_hash(csrc=None):
-    """sha256 over the kernel's code and build flags: what the recorded counters are keyed by.
-    Comments and white space do not count (a reworded comment leaves the machine code as it was)."""
+    """sha256 over the traversal kernel's code, its launch geometry and build flags: what the recorded
+    counters are keyed by.  Comments and white space do not count (a reworded comment leaves the machine
+    code as it was); neither do the translation units no traversal kernel is built from or launched by (the
+    table builders and the grid's compaction / add kernels)."""
     h = hashlib.sha256()
     csrc = csrc or os.path.join(REPO, "radiative3d_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
-        if name.endswith((".h", ".hip")):
+        if name.endswith((".h", ".hip")) and name not in ("r3d_volume.hip", "r3d_tables_build.hip", "r3d_tables_build.h"):
             h.update(name.encode())
             text = open(os.path.join(csrc, name), encoding="utf-8").read()
             text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)          # block comments

@@ -346,6 +346,9 @@ size_t r3d_volume_len(const r3d_engine* e);            /* counters (0 if none) *
 /* Copy the counters to `out` (r3d_volume_len entries); reset != 0 zeroes them
  * on the device afterwards.                                                  */
 int    r3d_volume_read(r3d_engine* e, uint32_t* out, int reset);
+/* The same for counters [begin, begin + count) only (e.g. the frames an engine holds job totals for after
+ * r3d_volume_reduce_by_frame); no reset.                                      */
+int    r3d_volume_read_range(r3d_engine* e, uint64_t begin, uint64_t count, uint32_t* out);
 /* Device address of the counters, for an RCCL reduction across ranks.        */
 void*  r3d_volume_device_ptr(r3d_engine* e);
 /* The same grid in CALLER-OWNED device memory (r3d_volume_len counters, zeroed

@@ -271,6 +271,8 @@ def hip_lib(reproducible=False, path=None):
         L.r3d_volume_scatter_add.restype = C.c_int
         L.r3d_volume_scatter_add.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p,
                                              C.c_void_p]
+        L.r3d_volume_read_range.restype = C.c_int
+        L.r3d_volume_read_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
         L.r3d_volume_reduce_by_frame.restype = C.c_int
         L.r3d_volume_reduce_by_frame.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
         L.r3d_last_error.restype = C.c_char_p

@@ -884,6 +884,19 @@ int r3d_volume_read(r3d_engine* e, uint32_t* out, int reset) {
   return 0;
 }
 
+int r3d_volume_read_range(r3d_engine* e, uint64_t begin, uint64_t count, uint32_t* out) {
+  const int fail_value = 1;
+  void* const vol = r3d_volume_device_ptr(e);
+  if (!vol) return g_error = "no volume grid attached", 1;
+  if (begin > e->volume_len || count > e->volume_len - begin) return g_error = "r3d_volume_read_range: range beyond the grid", 1;
+  if (count == 0) return 0;
+  if (!out) return g_error = "null output", 1;
+  R3D_ON_DEVICE(e->device);
+  R3D_HIP_OK(hipDeviceSynchronize());   // (runs may have been enqueued on caller streams)
+  R3D_HIP_OK(hipMemcpy(out, reinterpret_cast<const uint32_t*>(vol) + begin, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int r3d_volume_reduce_by_frame(r3d_engine* const* engines, int n, uint32_t* frames, uint64_t* saturated) {
   const int fail_value = 1;
   if (!engines || n < 1) return g_error = "r3d_volume_reduce_by_frame: at least one engine is needed", 1;

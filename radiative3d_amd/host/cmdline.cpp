@@ -14,7 +14,8 @@ enum OptID {
   OPT_FLATTEN, OPT_EARTHRAD, OPT_EVENT_MT, OPT_EVENT_LOC, OPT_OVR_MFP, OPT_NODEFLECT,
   OPT_REPORTS, OPT_REPORT_FILE, OPT_OUTDIR, OPT_OCSRAW, OPT_SEISBINS, OPT_SEISBINSIZE,
   OPT_SEISARRAY, OPT_SEIS_P2P, OPT_SEIS_P2PW, OPTM_HELP, OPTM_DUMPGRID, OPTM_PARAMOUTFN,
-  OPTM_RTTEST, OPTM_EVENTTEST, OPTM_RUNSIM, OPTX_SEED, OPTX_GPUS, OPTX_DEVTABLES, OPTX_HOSTTABLES
+  OPTM_RTTEST, OPTM_EVENTTEST, OPTM_RUNSIM, OPTX_SEED, OPTX_GPUS, OPTX_DEVTABLES, OPTX_HOSTTABLES,
+  OPTX_DEVICES, OPTX_SCATGRID, OPTX_SCATGRID_FILE
 };
 
 const std::map<std::string, OptID>& option_table() {
@@ -44,7 +45,8 @@ const std::map<std::string, OptID>& option_table() {
       {"--rtcoef-test", OPTM_RTTEST}, {"--event-test", OPTM_EVENTTEST},
       {"--run-simulation", OPTM_RUNSIM}, {"--run-sim", OPTM_RUNSIM},
       {"--seed", OPTX_SEED}, {"--gpus", OPTX_GPUS}, {"--device-tables", OPTX_DEVTABLES},
-      {"--host-tables", OPTX_HOSTTABLES}};
+      {"--host-tables", OPTX_HOSTTABLES}, {"--devices", OPTX_DEVICES},
+      {"--scatter-grid", OPTX_SCATGRID}, {"--scatter-grid-file", OPTX_SCATGRID_FILE}};
   return t;
 }
 
@@ -259,6 +261,27 @@ void ParseCommandLine(const std::vector<std::string>& tokens, ModelParams& par,
       case OPTM_EVENTTEST: mission.bSourcePatternTest = true, mission.bRunSim = false; break;
       case OPTX_SEED: mission.Seed = (unsigned long)std::strtoull(o.text().c_str(), nullptr, 0); break;
       case OPTX_GPUS: mission.Gpus = (int)o.integer(); break;
+      case OPTX_DEVICES:
+        mission.Devices.clear();
+        while (o.has()) mission.Devices.push_back((int)o.integer());
+        if (mission.Devices.empty()) throw Runtime("--devices needs at least one device index.");
+        break;
+      case OPTX_SCATGRID: {
+        long v[4];
+        for (int k = 0; k < 4; k++) v[k] = o.integer();
+        for (int k = 0; k < 3; k++) mission.GridLo[k] = o.real();
+        for (int k = 0; k < 3; k++) mission.GridHi[k] = o.real();
+        for (int k = 0; k < 3; k++) {
+          if (v[k] < 1 || !(mission.GridHi[k] > mission.GridLo[k]))
+            throw Runtime("--scatter-grid=NX,NY,NZ,FRAMES,X0,Y0,Z0,X1,Y1,Z1: cell counts must be positive and X1 > X0 etc.");
+          mission.GridDims[k] = (unsigned)v[k];
+        }
+        if (v[3] < 1) throw Runtime("--scatter-grid: FRAMES must be positive.");
+        mission.GridFrames = (unsigned)v[3];
+        mission.bScatterGrid = true;
+        break;
+      }
+      case OPTX_SCATGRID_FILE: mission.ScatterGridFile = o.text(); break;
       case OPTX_DEVTABLES: par.DeviceTables = true; break;
       case OPTX_HOSTTABLES: par.HostTables = true, par.DeviceTables = false; break;
     }

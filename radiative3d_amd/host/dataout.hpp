@@ -44,4 +44,13 @@ uint32_t ReportMaskFromKeywords(const std::string& csv);
 // reference, carries the cell index.
 void OutputReports(const r3d_event* ev, size_t n, std::ostream& out);
 
+// Header of a scatter-event grid written by --scatter-grid (no counterpart in the reference, whose video
+// pipeline bins its report stream in Octave, vis/scattervid/scattervid_above.m:111): GNU/Octave text with
+// the grid's shape, box, frame length and the name of the raw file beside it, which holds
+// count[type P,S][frame][iz][iy][ix] as little-endian uint32 (x fastest) -- in Octave:
+//   c = reshape(fread(fopen(GridFile), Inf, "uint32"), GridDims(1), GridDims(2), GridDims(3), GridFrames, 2);
+void OutputScatterGridHeader(const unsigned dims[3], unsigned frames, const double lo[3], const double hi[3],
+                             double frame_dt, const std::string& raw_file, unsigned long long events_binned,
+                             unsigned long long saturated_cells, std::ostream& out);
+
 #endif

@@ -105,14 +105,25 @@ struct Shard {
   uint64_t events_reported = 0;
   r3d_result res{};
   std::string error;
+  r3d_engine* engine = nullptr;   // kept until the grids are added (scatter grid runs)
 };
 
-// The replacement for Model::RunSimulation()'s loop: shard the id range over the
-// requested GPUs (one engine per device, one host thread each), sum on the host.
-void run_simulation(const Model& model, uint64_t n, uint64_t seed, int gpus, r3d_result& total,
+// What --scatter-grid asks for, and where it goes.
+struct GridJob {
+  bool on = false;
+  r3d_volume_desc desc{};
+  std::string header_path, raw_path, raw_name;
+};
+
+// The replacement for Model::RunSimulation()'s loop: shard the id range over the requested devices (one
+// engine per entry, one host thread each), sum on the host.  With a scatter grid every shard's engine
+// fills its own grid in HBM; the grids are then added by frame (r3d_volume_reduce_by_frame: every engine
+// ends with the job's counts for its share of the frames) and each engine's frames written to the raw file.
+void run_simulation(const Model& model, uint64_t n, uint64_t seed, const std::vector<int>& devices, r3d_result& total,
                     std::vector<double>& energy, std::vector<uint64_t>& counts, uint32_t report_mask,
-                    std::vector<r3d_event>& events, uint64_t& events_dropped, r3d_engine* engine0) {
+                    std::vector<r3d_event>& events, uint64_t& events_dropped, r3d_engine* engine0, const GridJob& grid) {
   const r3d_model_desc& d = model.Desc();
+  const int gpus = (int)devices.size();
   const size_t ne = (size_t)d.n_seismometers * d.params.n_bins * R3D_N_ENERGY;
   const size_t nc = (size_t)d.n_seismometers * d.params.n_bins * R3D_N_COUNT;
   energy.assign(ne, 0.0), counts.assign(nc, 0);
@@ -127,26 +138,35 @@ void run_simulation(const Model& model, uint64_t n, uint64_t seed, int gpus, r3d
       sh.res.energy = sh.energy.data(), sh.res.counts = sh.counts.data();
       const uint64_t lo = n / gpus * g + std::min<uint64_t>(g, n % gpus);
       const uint64_t cnt = n / gpus + ((uint64_t)g < n % gpus ? 1 : 0);
-      r3d_engine* e = (g == 0 && engine0) ? engine0 : r3d_engine_create(&d, g);
+      r3d_engine* e = (g == 0 && engine0) ? engine0 : r3d_engine_create(&d, devices[g]);
       if (!e) {
         sh.error = r3d_last_error();
         return;
       }
+      sh.engine = e;
       // report stream: room for 256 events per history, at most 2^26 records (6.4 GB) per GPU
       const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(cnt, 1) * 256, uint64_t(1) << 26);
       if (report_mask && r3d_engine_set_event_log(e, report_mask, cap)) sh.error = r3d_last_error();
+      if (sh.error.empty() && grid.on && r3d_engine_set_volume(e, &grid.desc)) sh.error = r3d_last_error();
       if (sh.error.empty() && r3d_run(e, cnt, lo, seed, &sh.res)) sh.error = r3d_last_error();
       if (sh.error.empty() && report_mask) {
         sh.events_reported = r3d_event_log_count(e);
         sh.events.resize((size_t)std::min<uint64_t>(sh.events_reported, cap));
         if (r3d_event_log_read(e, sh.events.data(), sh.events.size(), 0) == ~uint64_t(0)) sh.error = r3d_last_error();
       }
-      r3d_engine_destroy(e);
     });
   }
   for (auto& t : pool) t.join();
+  auto release = [&] {
+    for (Shard& sh : shards)
+      if (sh.engine) r3d_engine_destroy(sh.engine), sh.engine = nullptr;
+  };
+  for (const Shard& sh : shards)
+    if (!sh.error.empty()) {
+      release();
+      throw Runtime(sh.error);
+    }
   for (const Shard& sh : shards) {
-    if (!sh.error.empty()) throw Runtime(sh.error);
     for (size_t i = 0; i < ne; i++) energy[i] += sh.energy[i];
     for (size_t i = 0; i < nc; i++) counts[i] += sh.counts[i];
     total.n_lost += sh.res.n_lost, total.n_timeout += sh.res.n_timeout, total.n_invalid += sh.res.n_invalid;
@@ -155,6 +175,42 @@ void run_simulation(const Model& model, uint64_t n, uint64_t seed, int gpus, r3d
     events.insert(events.end(), sh.events.begin(), sh.events.end());
     events_dropped += sh.events_reported - sh.events.size();
   }
+  if (grid.on) {
+    std::vector<r3d_engine*> engines;
+    for (Shard& sh : shards) engines.push_back(sh.engine);
+    std::vector<uint32_t> frames(gpus + 1);
+    uint64_t saturated = 0;
+    std::string err;
+    if (r3d_volume_reduce_by_frame(engines.data(), gpus, frames.data(), &saturated)) err = r3d_last_error();
+    const uint64_t fc = (uint64_t)grid.desc.dims[0] * grid.desc.dims[1] * grid.desc.dims[2], nf = grid.desc.n_frames;
+    unsigned long long binned = 0;
+    std::ofstream raw(grid.raw_path.c_str(), std::ios::binary);
+    std::vector<uint32_t> buf;
+    // the file is count[type][frame][z][y][x]: for each wave type the owners' frame ranges in turn
+    for (uint64_t t = 0; t < 2 && err.empty(); t++)
+      for (int g = 0; g < gpus && err.empty(); g++) {
+        const uint64_t cnt = (uint64_t)(frames[g + 1] - frames[g]) * fc;
+        buf.resize(cnt);
+        if (cnt && r3d_volume_read_range(engines[g], (t * nf + frames[g]) * fc, cnt, buf.data())) err = r3d_last_error();
+        for (uint32_t v : buf) binned += v;
+        raw.write(reinterpret_cast<const char*>(buf.data()), (std::streamsize)(cnt * sizeof(uint32_t)));
+      }
+    if (err.empty() && !raw) err = "cannot write " + grid.raw_path;
+    if (err.empty()) {
+      std::ofstream hdr(grid.header_path.c_str());
+      const double lo[3] = {grid.desc.origin[0], grid.desc.origin[1], grid.desc.origin[2]};
+      const double hi[3] = {lo[0] + grid.desc.cell_size[0] * grid.desc.dims[0], lo[1] + grid.desc.cell_size[1] * grid.desc.dims[1],
+                            lo[2] + grid.desc.cell_size[2] * grid.desc.dims[2]};
+      OutputScatterGridHeader(grid.desc.dims, grid.desc.n_frames, lo, hi, grid.desc.frame_dt, grid.raw_name, binned, saturated, hdr);
+      std::cout << "|  Scatter-event grid: " << binned << " events binned into " << grid.desc.dims[0] << " x " << grid.desc.dims[1]
+                << " x " << grid.desc.dims[2] << " cells x " << nf << " frames x 2 wave types -> " << grid.raw_path << "\n";
+    }
+    if (!err.empty()) {
+      release();
+      throw Runtime(err);
+    }
+  }
+  release();
 }
 
 }  // namespace
@@ -172,8 +228,10 @@ int main(int argc, char* argv[]) {
   }
   if (mission.bHelpMsg) {
     std::cout << "\nOptions follow the Radiative3D manual (doc/MANUAL.md of the reference);\n"
-              << "additional: --seed=<n>  --gpus=<n>  --host-tables (a simulation run builds the take-off\n"
-              << "set, source and scattering tables in HBM unless told otherwise)  --device-tables\n\n";
+              << "additional: --seed=<n>  --gpus=<n>  --devices=<a,b,...>  --host-tables (a simulation run builds the\n"
+              << "take-off set, source and scattering tables in HBM unless told otherwise)  --device-tables\n"
+              << "--scatter-grid=NX,NY,NZ,FRAMES,X0,Y0,Z0,X1,Y1,Z1 [--scatter-grid-file=<name>]: SCT / REF events per wave\n"
+              << "type, frame and model-space cell, written as <name>.octv + <name>.u32 under --output-dir\n\n";
     return 0;
   }
   // A simulation run makes its tables where it uses them (seconds of host work and GBs of upload
@@ -222,8 +280,28 @@ int main(int argc, char* argv[]) {
         std::vector<uint64_t> counts;
         std::vector<r3d_event> events;
         uint64_t dropped = 0;
-        run_simulation(model, (uint64_t)std::max(0L, par.NumPhonons), mission.Seed,
-                       std::max(1, mission.Gpus), res, energy, counts, report_mask, events, dropped, engine0);
+        std::vector<int> devices = mission.Devices;
+        if (devices.empty())
+          for (int g = 0; g < std::max(1, mission.Gpus); g++) devices.push_back(g);
+        GridJob grid;
+        if (mission.bScatterGrid) {
+          grid.on = true;
+          for (int k = 0; k < 3; k++) {
+            grid.desc.origin[k] = mission.GridLo[k], grid.desc.dims[k] = mission.GridDims[k];
+            grid.desc.cell_size[k] = (mission.GridHi[k] - mission.GridLo[k]) / mission.GridDims[k];
+          }
+          grid.desc.n_frames = mission.GridFrames;
+          grid.desc.frame_dt = par.PhononTTL / mission.GridFrames;
+          const std::string dir = mission.OutputDir.empty() ? "" : mission.OutputDir + "/";
+          grid.raw_name = mission.ScatterGridFile + ".u32";
+          grid.raw_path = dir + grid.raw_name, grid.header_path = dir + mission.ScatterGridFile + ".octv";
+        }
+        if (engine0 && devices[0] != 0) {   // (the tables were made on device 0 for the scatterer dump; the run wants another)
+          r3d_engine_destroy(engine0);
+          engine0 = nullptr;
+        }
+        run_simulation(model, (uint64_t)std::max(0L, par.NumPhonons), mission.Seed, devices, res, energy, counts,
+                       report_mask, events, dropped, engine0, grid);
         engine0 = nullptr;   // (destroyed by its shard)
         if (report_mask) {   // the reference writes them as they happen: stdout, or --report-file
           if (mission.ReportFile.empty()) {

@@ -185,3 +185,42 @@ def test_plain_c_example_runs_on_gpu(tmp_path):
     want = O.run(m, 50000, seed=3)
     assert f"lost {want.n_lost} timeout {want.n_timeout} invalid {want.n_invalid}" in out.stdout
     assert os.path.exists(tmp_path / "seis_000.octv") and os.path.exists(tmp_path / "seis_traces_asc.dat")
+
+
+@pytest.mark.skipif(not os.path.exists(MAIN), reason="./main not built")
+def test_main_cli_scatter_grid_options_are_parsed(tmp_path):
+    """--scatter-grid / --devices: malformed values are refused by the option parser (no GPU needed)."""
+    for bad in ("--scatter-grid=8,8,8", "--scatter-grid=8,8,0,10,0,0,0,1,1,1", "--scatter-grid=8,8,8,10,0,0,0,1,1,0",
+                "--scatter-grid=8,8,8,0,0,0,0,1,1,1", "--devices="):
+        out = subprocess.run([MAIN, "--grid-compiled=40", "--toa-degree=2", bad], capture_output=True, text=True, cwd=tmp_path)
+        assert out.returncode == 1 and "Error processing command-line options" in out.stdout, (bad, out.stdout[-300:])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(MAIN), reason="./main not built")
+def test_main_cli_writes_the_scatter_grid_of_a_video_run_on_gpu(tmp_path):
+    """./main --scatter-grid on the crust-pinch video run (do-crustpinch-vids.sh arguments; the option would
+    travel in the script's ADDITIONAL=): three shards on the box's one GPU (--devices=0,0,0), grids added by
+    frame, raw file + Octave header -- equal to the oracle's histogram of the whole job, bit for bit.
+    Reference semantics: vis/scattervid/preprocess.sh:17-29 + scattervid_above.m:111 (frame = floor(t / dt))."""
+    from radiative3d_amd.configs import crustpinch_vids
+    from radiative3d_amd.model import volume_desc
+    n = 30000
+    dims, frames, lo, hi = (64, 60, 14), 35, (-200.0, -600.0, -130.0), (1080.0, 600.0, 10.0)
+    args = crustpinch_vids(4) + [f"--num-phonons={n}", "--seed=13", f"--output-dir={tmp_path}", "--host-tables", "--devices=0,0,0",
+                                 "--scatter-grid=" + ",".join(str(v) for v in dims + (frames,) + lo + hi),
+                                 "--scatter-grid-file=grid"]
+    run = subprocess.run([MAIN] + args, capture_output=True, text=True, cwd=tmp_path)
+    assert run.returncode == 0, run.stdout[-2000:]
+    hdr = parse_octave_struct(open(tmp_path / "grid.octv").read())
+    assert list(hdr["GridDims"].reshape(-1)) == list(dims) and int(hdr["GridFrames"]) == frames
+    assert float(hdr["GridFrameSeconds"]) == pytest.approx(350.0 / frames)
+    got = np.fromfile(tmp_path / "grid.u32", dtype="<u4").reshape(2, frames, dims[2], dims[1], dims[0])
+    m = Model(crustpinch_vids(4))
+    cell = tuple((h - l) / d for l, h, d in zip(lo, hi, dims))
+    res, want = O.run_with_volume(m, n, volume_desc(lo, cell, dims, frames, 350.0 / frames), seed=13)
+    assert (got == want).all() and int(hdr["GridEventsBinned"]) == int(want.sum()) > 100000
+    assert int(hdr["GridSaturatedCells"]) == 0
+    assert f"{int(want.sum())} events binned" in run.stdout
+    lost = int(re.search(r"Loss surfaces:\s+(\d+)", run.stdout).group(1))
+    assert lost == res.n_lost
