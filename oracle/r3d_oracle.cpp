@@ -1077,6 +1077,39 @@ void r3d_oracle_boundary(const r3d_model_desc* m, int cell, int type, const doub
   out[5] = r.time, out[6] = r.len, out[7] = r.face;
 }
 
+// Tetra::GetPathToBoundary (media.cpp:518-567) on ONE bare cell given as arrays -- four outward unit normals, a
+// point on each face, grad v and v at the origin -- from `loc` along the unit vector `dir` (taken through
+// (theta, phi), as the reference carries it).  Returns the exit face; *len: the arc length (inf: none).
+// For tests/test_face_filter.py: the engine's local tetra move against this, case by case.
+int r3d_oracle_tet_search(const double normals[12], const double points[12], const double g[3], double v0,
+                          const double loc[3], const double dir[3], double* len) {
+  r3d_cell c;
+  std::memset(&c, 0, sizeof c);
+  for (int f = 0; f < 4; f++)
+    for (int k = 0; k < 3; k++) c.faces[f].normal[k] = normals[3 * f + k], c.faces[f].point[k] = points[3 * f + k];
+  for (int k = 0; k < 3; k++) c.vel_grad[0][k] = g[k];
+  c.vel_c[0] = v0;
+  double th, ph;
+  angles_from_node(mk(dir), th, ph);
+  const V lc = mk(loc), gg = mk(c.vel_grad[0]);
+  ArcFrame CT = arc_frame(dot(lc, gg) + v0, gg, lc, from_angles(th, ph));
+  double angle0 = std::atan2(CT.prime_loc.x, CT.prime_loc.z);
+  Gcad rv[4];
+  for (int i = 0; i < 4; i++) rv[i] = plane_arc(c.faces[i], CT);
+  double best = INF;
+  int face = 0;
+  for (int i = 0; i < 4; i++) {
+    double e = rv[i].exit;
+    if (gcad_inside(rv[(i + 1) % 4], e) && gcad_inside(rv[(i + 2) % 4], e) && gcad_inside(rv[(i + 3) % 4], e)) {
+      double nl = (e - angle0) * CT.R;
+      if (nl < 0 && (angle0 > rv[i].half)) nl = best;  // dismiss exit
+      if (nl < best) best = nl, face = i;
+    }
+  }
+  *len = best;
+  return face;
+}
+
 void r3d_oracle_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   oracle_philox4x32_10(ctr, key, out);
 }

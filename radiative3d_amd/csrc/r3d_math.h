@@ -14,8 +14,12 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define R3D_HD __host__ __device__ __forceinline__
+// A function that is CALLED, not inlined: its registers are allocated on their own, and what the caller
+// holds across the call is saved around it -- for code that one move in ten thousand runs.
+#define R3D_HD_COLD inline __host__ __device__ __attribute__((noinline))
 #else
 #define R3D_HD inline
+#define R3D_HD_COLD inline
 #endif
 
 // A point the instruction scheduler may not move code across (device builds).  The long
@@ -82,6 +86,24 @@ R3D_HD double frcp(double x) {
   return 1.0 / x;
 #endif
 }
+// The same two with ONE Newton step (relative error ~2^-50 instead of an ulp): for quantities that feed a
+// decision held with a margin of 1e-8, or a length that is good to 1e-13 anyway (the tetra move's search).
+R3D_HD double frsqrt1(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(x);
+  return __builtin_fma(y, __builtin_fma(-0.5 * x * y, y, 0.5), y);
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+R3D_HD double frcp1(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rcp(x);
+  return __builtin_fma(y, __builtin_fma(-x, y, 1.0), y);
+#else
+  return 1.0 / x;
+#endif
+}
 // True if the condition holds in every active lane of the wave (on the host: in this one).  For
 // choosing a shorter series when ALL lanes qualify -- a per-lane branch would run both.
 //
@@ -99,6 +121,16 @@ R3D_HD bool all_lanes(bool c) {
   return false && c;
 #elif defined(__HIP_DEVICE_COMPILE__)
   return __all(c) != 0;
+#else
+  return c;
+#endif
+}
+
+// True if the condition holds in ANY active lane (on the host: in this one).  Only ever used to skip code that no
+// lane needs: what a lane computes does not depend on it, so the reproducible build keeps it.
+R3D_HD bool any_lanes(bool c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ballot_w64(c) != 0ull;
 #else
   return c;
 #endif

@@ -279,6 +279,198 @@ R3D_HD void tet_advance(const CellTet& c, const TetArc& A, Phonon& p, double len
   p.moves += 1;
 }
 
+// ------------------------------------------------------------------------------------------------
+// THE SAME MOVE IN LOCAL FORM (round 5).  The search above is the reference's own construction: every
+// face's entry / exit / bisector angle on the ray circle, measured from the circle's CENTRE (a thousand
+// cell sizes away in a gently graded model), then twelve interval tests with the reference's slack and
+// dismissal rules -- about 410 vector instructions of a tetra move's ~1000.  What it computes, whenever
+// the phonon is inside its cell (or on a face of it, moving in), is the first point at which the arc
+// leaves the cell.  That has a closed form in quantities measured FROM THE PHONON:
+//
+//   with u = unit vector from the arc's centre to the phonon (u = w / |w|, w = g - (g.d) d: the part of
+//   grad v normal to the direction d), R = v / |w|, a point of the arc at arc angle th ahead is
+//       x(th) = loc + R sin(th) d - R (1 - cos th) u,        tangent  d(th) = cos(th) d - sin(th) u,
+//   and for a face (n, n.p) with  h = n.p - n.loc  (distance inside),  P = R n.d,  M = R n.u  the arc is
+//   on the face where  P sin(th) - M (1 - cos th) = h,  i.e. with t = tan(th / 2):
+//       (2 M + h) t^2 - 2 P t + h = 0 ,      disc = P^2 - h (2 M + h) .
+//   Of its two roots the one where the arc goes from inside to outside is ALWAYS
+//       t_exit = (P - sqrt(disc)) / (2 M + h) = h / (P + sqrt(disc))
+//   (the derivative of the left side there is -2 sqrt(disc)); the first form is stable for P < 0, the
+//   second for P >= 0.  The first exit of the cell is the smallest positive t_exit of the four faces.
+//
+// No centre, no rotated frame, no angles, no sentinels: ~40 instructions a face, and nothing cancels but
+// h itself.  This is not an approximation of the search above -- both are exact formulations, good to
+// rounding -- but the two can DECIDE differently where the reference's rules are not the geometry's:
+// a start outside the cell beyond the 1e-10 rad slack (media_cellface.cpp:768), exits behind the phonon
+// that are dismissed or not by the bisector rule (media.cpp:550-552), angles clipped at the +-90 degree
+// window, ties between faces that meet in an edge, tangent faces.  So the local form CERTIFIES its
+// answer: every quantity a rule could hinge on must be away from its threshold by a margin (1e-8 in
+// tan(th/2) -- rounding is 1e-15) or the lane takes the reference's construction above, unchanged.
+// tests/test_face_filter.py runs both on 1e7 random and 1e5 adversarial starts (edges, vertices,
+// shallow angles, retrograde micro-steps): wherever the local form certifies, the two agree.
+//
+// Certified means (why each suffices is argued in DESIGN.md section 4, "the local tetra move"):
+//   (1) every face: inside (h >= 0), or outside by so little while moving in (h >= 1e-11 P, P = R n.d < 0)
+//       that its entry lies within 1e-11 rad ahead -- a phonon that has just come through that face sits
+//       within 1e-16 R of it, either side -- which is inside the reference's slack;
+//   (2) every face: |disc| >= 1e-10 R^2.  sqrt(disc) / R is the sine of the angle at which the ray CIRCLE meets
+//       the face's plane (negative disc: it does not) times the length of the face normal's part in the arc's
+//       plane, and the reference's entry and exit angles are good to ~1e-16 over that product (its plane
+//       offset n.p - n.centre and its in-plane normal are each good to 1e-16 absolute; measured,
+//       tests/test_face_filter.py): held to 1e-5, its angles are good to 1e-11 -- a thousandth of the margins
+//       below -- and "does the circle cross this plane at all" is not a matter of rounding.  (For a phonon
+//       ON a face this also says it is not grazing: there disc = P^2, so |n.d| >= 1e-5.)
+//   (3) every face that is crossed: |t_exit| >= 1e-8 (no exit within 2e-8 rad either side of the phonon);
+//   (4) the smallest positive t_exit is <= 1 and the next one is at least 1e-8 larger (no tie);
+//   (5) the arc's start and its exit point have cosines >= 1e-3 in the reference's frame (inside the
+//       window where velocity is positive, and where its comparisons of sines are well conditioned).
+// (tests/emul tallies which condition sent a lane to the reference's construction; nothing in a device build)
+#ifndef R3D_LOC_REASON
+#define R3D_LOC_REASON(k, mask) ((void)0)
+#endif
+constexpr double kLocTau = 1e-11, kLocEpsT = 1e-8, kLocEpsC = 1e-10, kLocKappa = 1e-3;
+constexpr double kLocNone = 4.0;   // stands for "no exit ahead" among the t_exit (every real one is <= 1)
+struct TetLocal {
+  V3 U, w;               // loc - centre = R u;  w = g - (g.d) d
+  double R, iw, m2, gd;  // radius, 1 / |w|, |w|^2, g.d
+};
+struct TetFast {
+  double t, sn, cs, omc;   // tan(th/2), sin th, cos th, 1 - cos th of the exit
+  int face;
+  bool ok;                 // certified: else the lane takes tet_arc / tet_exit
+};
+R3D_HD TetFast tet_fast_exit(const CellTet& c, const Phonon& p, TetLocal& L) {
+  const V3 g = v3(c.g);
+  const double vel = dot(p.loc, g) + c.v0;
+  L.gd = dot(g, p.dir);
+  L.w = g - L.gd * p.dir;
+  L.m2 = mag2(L.w);
+  L.iw = frsqrt(L.m2);
+  L.R = vel * L.iw;
+  L.U = (L.R * L.iw) * L.w;
+  const double eR2 = kLocEpsC * (L.R * L.R);
+  LaneMask bad = lm_andnot(lm_all(), lm(L.R > 0.0));   // (a velocity <= 0 or a NaN: not this routine's business)
+  double tq[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const V3 n = v3(c.n[i]);
+    const double h = c.d[i] - dot(n, p.loc);
+    const double r = dot(n, p.dir);
+    const double M = dot(n, L.U);
+    const double P = L.R * r;
+    const double k = 2.0 * M + h;
+    const double P2 = P * P;
+    const double disc = P2 - h * k;
+    const LaneMask Dpos = lm(disc > eR2), Dneg = lm(disc < -eR2);
+    const double S = disc * frsqrt1(disc);   // (garbage where disc <= 0: never looked at there)
+    const bool fwd = P >= 0.0;
+    const double q = fwd ? P + S : P - S;
+    const double num = fwd ? h : q, den = fwd ? q : k;
+    const double t = num * frcp1(den);
+    const LaneMask Tpos = lm(t >= kLocEpsT), Tneg = lm(t <= -kLocEpsT);
+    const LaneMask inside = lm(h >= 0.0) | lm(h >= kLocTau * P);
+    R3D_LOC_REASON(0, lm_andnot(lm_all(), Dpos | Dneg));
+    R3D_LOC_REASON(1, lm_andnot(Dpos, Tpos | Tneg));
+    R3D_LOC_REASON(2, lm_andnot(lm_all(), inside));
+    bad = bad | lm_andnot(lm_all(), Dpos | Dneg) | lm_andnot(Dpos, Tpos | Tneg) | lm_andnot(lm_all(), inside);
+    tq[i] = lm_lane(Dpos & Tpos) ? t : kLocNone;
+  }
+  TetFast F;
+  const double t01 = fmin(tq[0], tq[1]), t23 = fmin(tq[2], tq[3]);
+  const int f01 = tq[1] < tq[0] ? 1 : 0, f23 = tq[3] < tq[2] ? 3 : 2;
+  F.t = fmin(t01, t23);
+  F.face = t23 < t01 ? f23 : f01;
+  const double lim = F.t + kLocEpsT;
+  const LaneMask n0 = lm(tq[0] < lim), n1 = lm(tq[1] < lim), n2 = lm(tq[2] < lim), n3 = lm(tq[3] < lim);
+  R3D_LOC_REASON(3, (n0 & n1) | (n2 & n3) | ((n0 | n1) & (n2 | n3)));
+  R3D_LOC_REASON(4, lm_andnot(lm_all(), lm(F.t <= 1.0)));
+  bad = bad | (n0 & n1) | (n2 & n3) | ((n0 | n1) & (n2 | n3)) | lm_andnot(lm_all(), lm(F.t <= 1.0));
+  const double inv = frcp(1.0 + F.t * F.t);
+  F.sn = (2.0 * F.t) * inv, F.omc = F.t * F.sn, F.cs = 1.0 - F.omc;
+  // the window of the reference's frame: cos a0 = |w| / |g|, sin a0 = -g.d / |g|
+  const double c0 = (L.m2 * L.iw) * c.inv_gmag, s0 = -L.gd * c.inv_gmag;
+  const double c1 = c0 * F.cs - s0 * F.sn;
+  R3D_LOC_REASON(5, lm_andnot(lm_all(), lm(c0 >= kLocKappa) & lm(c1 >= kLocKappa)));
+  bad = bad | lm_andnot(lm_all(), lm(c0 >= kLocKappa) & lm(c1 >= kLocKappa));
+  F.ok = lm_lane(lm_andnot(lm_all(), bad));
+  return F;
+}
+// th = 2 atan(t) for the exit's t = tan(th / 2) in (0, 1]; (sn, cs) its sine and cosine.  A tetra leg spans a
+// fraction of a degree in a gently graded model: the Maclaurin series through t^13 when every lane has
+// t <= 1/16 (next term t^14 / 15: 1e-18 relative); else the general routine on (sn, cs).
+R3D_HD double two_atan(double t, double sn, double cs) {
+  if (all_lanes(t <= 0.0625)) {
+    const double z = t * t;
+    double s = 1.0 / 13.0;
+    s = __builtin_fma(s, z, -1.0 / 11.0);
+    s = __builtin_fma(s, z, 1.0 / 9.0);
+    s = __builtin_fma(s, z, -1.0 / 7.0);
+    s = __builtin_fma(s, z, 1.0 / 5.0);
+    s = __builtin_fma(s, z, -1.0 / 3.0);
+    const double a = __builtin_fma(t * z, s, t);
+    return a + a;
+  }
+  return angle_from_sincos(sn, cs);
+}
+// reference Tetra::AdvanceLength (media.cpp:442-499) + Phonon::Move, in the local form: the leg ends at arc
+// angle th ahead, given by (sn, cs, omc) = (sin th, cos th, 1 - cos th).  Travel time as in tet_advance:
+// atanh(s1) - atanh(s0) = atanh((s1 - s0) / (1 - s0 s1)) with s = sin(a) = -g.d / |g|, and
+// s1 - s0 = (g.d (1 - cos th) + |w| sin th) / |g| straight from the rotation (no difference of nearby sines).
+R3D_HD void tet_advance_local(const CellTet& c, const TetLocal& L, Phonon& p, double len, double sn, double cs,
+                              double omc) {
+  const V3 nl = p.loc + ((L.R * sn) * p.dir + (-omc) * L.U);
+  const V3 nd = cs * p.dir + (-sn * L.iw) * L.w;
+  const double s0 = -L.gd * c.inv_gmag;
+  const double ds = (L.gd * omc + (L.m2 * L.iw) * sn) * c.inv_gmag;
+  const double y = ds * frcp(1.0 - s0 * (s0 + ds));
+  const double time = c.inv_gmag * atanh_lean(y);
+  p.path += len, p.t += time, p.recent += time;
+  p.loc = nl;
+  p.dir = nd;
+  p.lamp += c.att * time;
+  p.moves += 1;
+}
+
+// The whole move by the reference's construction, for the lanes whose local form did not certify: search,
+// free path, advance (what step_move did for every lane until round 5).  A function of its own, CALLED: at 168
+// registers the kernel holds this code with nothing to spare, and inlined beside the local form it put
+// twenty of the kernel's long-lived values in scratch memory in every phase; called, it has its own
+// registers, and the caller's are saved around the call -- on a path one move in ten thousand takes.
+struct TetSlowOut {
+  Phonon p;
+  int32_t face, scatters, fate;
+};
+R3D_HD TetSlowOut tet_move_reference_inline(const CellTet* cp, Phonon p, double u_free, double mfp) {
+  const CellTet c = *cp;
+  TetSlowOut o;
+  o.fate = FATE_ALIVE, o.scatters = 0;
+  const TetArc tarc = tet_arc(c, p);
+  const TetExit texit = tet_exit(c, tarc);
+  o.face = texit.face;
+  const double elen = tet_exit_length(tarc, texit);
+  if (elen == pos_inf()) {  // phonons.cpp:595-598
+    o.fate = FATE_TIMEOUT, o.p = p;
+    return o;
+  }
+  double scatlen = pos_inf();
+  if (!((1.0 - u_free) * mfp >= elen)) scatlen = -log_lean(u_free) * mfp;
+  const bool scatters = scatlen < elen;
+  const double len = scatters ? scatlen : elen;
+  double s1 = texit.s, c1 = texit.c;   // a boundary leg ends at the exit point itself
+  if (scatters || !(elen > -pos_inf())) {
+    double sd, cd;                      // scatter leg: rotate the start angle by len / R
+    rotation(len * frcp(tarc.R), &sd, &cd);
+    s1 = tarc.s0 * cd + tarc.c0 * sd, c1 = tarc.c0 * cd - tarc.s0 * sd;
+  }
+  tet_advance(c, tarc, p, len, s1, c1);
+  o.p = p, o.scatters = scatters ? 1 : 0;
+  return o;
+}
+
+R3D_HD_COLD TetSlowOut tet_move_reference(const CellTet* cp, Phonon p, double u_free, double mfp) {
+  return tet_move_reference_inline(cp, p, u_free, mfp);
+}
+
 // ===================================================================== SPH ==
 R3D_HD double sph_linear_exit(double radius, V3 loc, V3 dir) {
   // reference SphereFace::LinearRayDistToExit, media_cellface.cpp:664-684

@@ -28,6 +28,20 @@
 #define R3D_ADD_U32(ptr, val) (*(ptr) += (unsigned int)(val))
 #endif
 
+// The tetra move: 1 the local form, certified, with the reference's construction behind it; 0 (developer builds:
+// timing comparisons) the reference's construction for every lane.  R3D_TET_SLOW_CALL: that construction as a called
+// function (1) or inlined (0).
+#ifndef R3D_TET_LOCAL
+#define R3D_TET_LOCAL 1
+#endif
+#ifndef R3D_TET_SLOW_CALL
+#define R3D_TET_SLOW_CALL 0
+#endif
+// (tests/emul counts the moves that take the reference's construction; nothing in a device build)
+#ifndef R3D_COUNT_SLOW_MOVE
+#define R3D_COUNT_SLOW_MOVE() ((void)0)
+#endif
+
 namespace r3d {
 
 template <int KIND> struct CellOf;
@@ -280,17 +294,65 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
 
   // --- where does the ray leave the cell? (phonons.cpp:590)
   Exit e;
-  TetArc tarc;
-  TetExit texit;
+  bool scatters;
+  if constexpr (KIND == CELL_TET) {
+    // The move in local form (r3d_physics.h tet_fast_exit) wherever it certifies its answer; a lane that
+    // does not -- a start outside the cell, a tie between faces, a tangent plane, an exit at the phonon's
+    // feet: one move in 1e4 in a tetrahedral grid -- takes the reference's own construction, as before.
+    // (the certified lanes' whole move first, then the others': nothing of the local form is alive across the
+    //  reference's construction, which needs every register the kernel has)
+#if R3D_TET_LOCAL
+    bool slow;
+    e.len = 0.0, scatters = false;
+    {
+      TetLocal L;
+      const TetFast F = tet_fast_exit(c, p, L);
+      slow = !F.ok;
+      e.face = F.face;
+      if (!slow) {
+        e.len = L.R * two_atan(F.t, F.sn, F.cs);
+        // free path (scatterers.cpp:297-307, phonons.cpp:601), screened as below
+        const double mfp = T.scat_head[cell_scat(c)].mfp[p.type];
+        double scatlen = pos_inf();
+        if (!((1.0 - u_free) * mfp >= e.len)) scatlen = -log_lean(u_free) * mfp;
+        scatters = scatlen < e.len;
+        double len = e.len, sn = F.sn, cs = F.cs, omc = F.omc;
+        if (any_lanes(scatters)) {
+          if (scatters) {                       // scatter leg: the arc angle is len / R
+            len = scatlen;
+            rotation(len * frcp(L.R), &sn, &cs);
+            omc = (sn * sn) * frcp(1.0 + cs);   // 1 - cos without the cancellation (|th| < pi: a leg inside one cell)
+          }
+        }
+        tet_advance_local(c, L, p, len, sn, cs, omc);
+      }
+    }
+    if (any_lanes(slow)) {
+      if (slow) {
+        R3D_COUNT_SLOW_MOVE();
+#if R3D_TET_SLOW_CALL
+        const TetSlowOut o = tet_move_reference(&cell_rec<KIND>(T, p.cell, p.type), p, u_free,
+                                                T.scat_head[cell_scat(c)].mfp[p.type]);
+#else
+        const TetSlowOut o = tet_move_reference_inline(&cell_rec<KIND>(T, p.cell, p.type), p, u_free,
+                                                       T.scat_head[cell_scat(c)].mfp[p.type]);
+#endif
+        if (o.fate != FATE_ALIVE) return o.fate;
+        p = o.p, e.face = o.face, scatters = o.scatters != 0;
+      }
+    }
+#else   // (developer builds: the reference's construction for every lane, as until round 5)
+    {
+      const TetSlowOut o = tet_move_reference_inline(&c, p, u_free, T.scat_head[cell_scat(c)].mfp[p.type]);
+      if (o.fate != FATE_ALIVE) return o.fate;
+      p = o.p, e.face = o.face, scatters = o.scatters != 0;
+    }
+#endif
+  } else {
   SphArc sarc;
   SphExit sexit;
   if constexpr (KIND == CELL_CYL) {
     e = cyl_exit(c, a.cyl_radius2, p);
-  } else if constexpr (KIND == CELL_TET) {
-    tarc = tet_arc(c, p);
-    texit = tet_exit(c, tarc);
-    e.face = texit.face;
-    e.len = tet_exit_length(tarc, texit);
   } else {
     sarc = sph_arc(c, v3(a.earth_center[0], a.earth_center[1], a.earth_center[2]), p);
     sexit = sph_exit(c, sarc, p);
@@ -302,23 +364,14 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
   //     (scatterers.cpp:297-307, phonons.cpp:601)
   // scatlen = -ln(u) mfp.  Since -ln(u) >= 1 - u, (1-u) mfp >= len already rules a scatter
   // out, and the logarithm is only taken for the lanes that pass this screen.
-  if constexpr (KIND == CELL_TET) mfp = T.scat_head[cell_scat(c)].mfp[p.type];
   double scatlen = pos_inf();
   if (!((1.0 - u_free) * mfp >= e.len)) scatlen = -log_lean(u_free) * mfp;
-  const bool scatters = scatlen < e.len;
+  scatters = scatlen < e.len;
   const double len = scatters ? scatlen : e.len;
 
   // --- advance (both branches) and Move (phonons.cpp:608-609, :623)
   if constexpr (KIND == CELL_CYL) {
     cyl_advance(c, p, len);
-  } else if constexpr (KIND == CELL_TET) {
-    double s1 = texit.s, c1 = texit.c;   // a boundary leg ends at the exit point itself
-    if (scatters || !(e.len > -pos_inf())) {
-      double sd, cd;                      // scatter leg: rotate the start angle by len / R
-      rotation(len * frcp(tarc.R), &sd, &cd);
-      s1 = tarc.s0 * cd + tarc.c0 * sd, c1 = tarc.c0 * cd - tarc.s0 * sd;
-    }
-    tet_advance(c, tarc, p, len, s1, c1);
   } else {
     double s1 = sexit.sx, c1 = sexit.cx;  // a boundary leg ends at the exit point itself
     if (scatters || !sexit.on_arc) {
@@ -327,6 +380,7 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
       s1 = sarc.s0 * cd + sarc.c0 * sd, c1 = sarc.c0 * cd - sarc.s0 * sd;
     }
     sph_advance(c, sarc, p, len, s1, c1);
+  }
   }
 
   ev.face = scatters ? -1 : e.face;

@@ -8,6 +8,12 @@
 #include <cstring>
 
 #include "../../include/r3d.h"
+// tetra moves that did not certify the local form and took the reference's construction (r3d_step.h)
+static unsigned long long g_slow_moves = 0;
+#define R3D_COUNT_SLOW_MOVE() (++g_slow_moves)
+static unsigned long long g_loc_reason[8] = {0};
+#define R3D_LOC_REASON(k, mask) (g_loc_reason[k] += (mask) ? 1 : 0)
+#include <cstdlib>
 #include "../../radiative3d_amd/csrc/r3d_pack.h"
 #include "../../radiative3d_amd/csrc/r3d_step.h"
 
@@ -53,6 +59,19 @@ static void run_kind(const KArgs& a, uint64_t n, uint64_t first_id, uint64_t see
       f.type = (uint8_t)p.type;
       f.n_catch = (uint16_t)(st.n_catch > 65535u ? 65535u : st.n_catch);
     }
+  }
+}
+
+extern "C" unsigned long long r3d_emul_slow_moves(int reset) {
+  const unsigned long long v = g_slow_moves;
+  if (reset) g_slow_moves = 0;
+  return v;
+}
+
+extern "C" void r3d_emul_loc_reasons(unsigned long long* out, int reset) {
+  for (int i = 0; i < 8; i++) {
+    out[i] = g_loc_reason[i];
+    if (reset) g_loc_reason[i] = 0;
   }
 }
 
@@ -128,5 +147,160 @@ extern "C" void r3d_emul_sample_cdf(const double* cdf, uint64_t n, uint32_t bits
   for (uint64_t i = 0; i < m; i++) {
     out_guided[i] = sample_cdf_guided(cdf, cells.data(), bits, cdf[n - 1], u[i]);
     out_plain[i] = sample_cdf(cdf, n, u[i]);
+  }
+}
+
+// ---- the tetra move's two searches side by side (tests/test_face_filter.py) ------------------------------
+// Random tetrahedra with a linear velocity, a start and a direction per case; the local form
+// (tet_fast_exit) and the reference's construction (tet_arc / tet_exit / tet_exit_length) both run.  Where
+// the local form CERTIFIES its answer the two must agree: same face, same arc length.  mode:
+//   0 interior starts, any direction          1 starts on a face (to rounding, either side), moving in
+//   2 starts on / near an edge or a vertex    3 directions aimed at an edge or a vertex (ties)
+//   4 starts outside a face by 1e-17 .. 1e-7 R, moving in or out (retrograde micro-steps)
+//   5 sliver cells (faces meeting at shallow angles)   6 arcs tangent to a face (strong gradients)
+// out[0] cases, out[1] certified, out[2] certified and face differs, out[3] certified, same face, arc
+// lengths differ by more than tol * R, out[4] the reference gave no exit (len = inf) among the certified, out[5]
+// (with an oracle) certified cases on which the engine's sine-space search and the oracle's differ;
+// dev[0] largest |len_local - len_ref| / R among the certified, dev[1] the same / max(len, 1e-300).
+namespace {
+struct SplitMix {
+  uint64_t s;
+  uint64_t next() {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  double u() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }   // [0, 1)
+  double sym() { return 2.0 * u() - 1.0; }
+  double logu(double lo, double hi) { return lo * std::pow(hi / lo, u()); }
+};
+static V3 rnd_unit(SplitMix& g) {
+  for (;;) {
+    V3 v = v3(g.sym(), g.sym(), g.sym());
+    const double m = mag2(v);
+    if (m > 1e-4 && m <= 1.0) return (1.0 / std::sqrt(m)) * v;
+  }
+}
+}  // namespace
+typedef int (*tet_search_fn)(const double normals[12], const double points[12], const double g[3], double v0,
+                             const double loc[3], const double dir[3], double* len);
+extern "C" void r3d_emul_face_filter(int mode, uint64_t n, uint64_t seed, double tol, uint64_t* out, double* dev,
+                                     double* first_bad /* 16 doubles or null */,
+                                     tet_search_fn oracle /* oracle/r3d_oracle.cpp r3d_oracle_tet_search, or null */) {
+  SplitMix g{seed * 0x2545F4914F6CDD1Dull + (uint64_t)mode};
+  for (int i = 0; i < 6; i++) out[i] = 0;
+  dev[0] = dev[1] = 0.0;
+  for (uint64_t it = 0; it < n; it++) {
+    // the cell: four corners in a box of edge ~10; slivers: the fourth corner close to the others' plane
+    V3 x[4];
+    for (;;) {
+      for (int k = 0; k < 4; k++) x[k] = v3(10 * g.u(), 10 * g.u(), 10 * g.u());
+      if (mode == 5) {
+        const V3 nn = unit(cross(x[1] - x[0], x[2] - x[0]));
+        const V3 c3 = (1.0 / 3.0) * (x[0] + x[1] + x[2]);
+        x[3] = c3 + g.logu(1e-4, 1e-1) * nn + 3.0 * (g.sym() * unit(x[1] - x[0]) + g.sym() * unit(x[2] - x[0]));
+      }
+      const double vol6 = std::fabs(dot(cross(x[1] - x[0], x[2] - x[0]), x[3] - x[0]));
+      if (vol6 > (mode == 5 ? 1e-6 : 1.0)) break;
+    }
+    CellTet c;
+    std::memset(&c, 0, sizeof c);
+    double points[12];
+    for (int f = 0; f < 4; f++) {   // face f: opposite corner f, normal pointing away from it
+      const V3 a = x[(f + 1) & 3], b = x[(f + 2) & 3], d = x[(f + 3) & 3];
+      V3 nn = unit(cross(b - a, d - a));
+      if (dot(nn, x[f] - a) > 0) nn = -nn;
+      c.n[f][0] = nn.x, c.n[f][1] = nn.y, c.n[f][2] = nn.z;
+      c.d[f] = dot(nn, a);
+      points[3 * f] = a.x, points[3 * f + 1] = a.y, points[3 * f + 2] = a.z;
+    }
+    const V3 centre = 0.25 * (x[0] + x[1] + x[2] + x[3]);
+    // velocity: 5 at the centre, gradient of any direction; arc radius from ~the cell's size to 1e5 of it
+    const V3 gd = rnd_unit(g);
+    const double gm = (mode == 6) ? 5.0 / g.logu(12.0, 60.0) : 5.0 / g.logu(20.0, 1e6);   // (velocity > 0 throughout the cell)
+    c.g[0] = gm * gd.x, c.g[1] = gm * gd.y, c.g[2] = gm * gd.z;
+    c.v0 = 5.0 - dot(v3(c.g), centre);
+    c.inv_gmag = 1.0 / gm;
+    c.att = -0.01;
+    Phonon p;
+    std::memset(&p, 0, sizeof p);
+    p.pc = 1.0, p.type = 0;
+    // start
+    double w[4];
+    double sum = 0;
+    for (int k = 0; k < 4; k++) sum += (w[k] = -std::log(1.0 - g.u()));
+    for (int k = 0; k < 4; k++) w[k] /= sum;
+    const int f0 = (int)(g.next() & 3), f1 = (f0 + 1 + (int)(g.next() % 3)) & 3;
+    if (mode == 1 || mode == 4) w[f0] = 0;                     // on face f0 (corner f0 has no weight)
+    if (mode == 2) {
+      w[f0] = 0, w[f1] = (g.u() < 0.5) ? 0.0 : g.logu(1e-16, 1e-6);   // on / near the edge shared by f0 and f1
+      if (g.u() < 0.3) w[(f1 + 1) & 3 == f0 ? (f1 + 2) & 3 : (f1 + 1) & 3] = g.logu(1e-16, 1e-6);   // near a vertex
+    }
+    sum = w[0] + w[1] + w[2] + w[3];
+    p.loc = v3(0, 0, 0);
+    for (int k = 0; k < 4; k++) p.loc = p.loc + (w[k] / sum) * x[k];
+    p.dir = rnd_unit(g);
+    const V3 nf0 = v3(c.n[f0]);
+    if (mode == 1 || mode == 2) {   // moving in through f0 (any angle, grazing included)
+      if (dot(nf0, p.dir) > 0) p.dir = p.dir - (2.0 * dot(nf0, p.dir)) * nf0;
+      if (g.u() < 0.2) {             // grazing: mostly along the face
+        V3 tang = unit(cross(nf0, rnd_unit(g)));
+        p.dir = unit(tang + (-g.logu(1e-9, 1e-1)) * nf0);
+      }
+      if (mode == 1 && g.u() < 0.5) p.loc = p.loc + (g.sym() * g.logu(1e-17, 1e-12) * 10.0) * nf0;   // rounding, either side
+    }
+    if (mode == 3) {   // aimed at a point of an edge or at a vertex, from inside
+      V3 target = x[f0];
+      if (g.u() < 0.7) {
+        const double s = g.u();
+        target = s * x[f0] + (1 - s) * x[f1];
+      }
+      if (g.u() < 0.5) target = target + (g.logu(1e-14, 1e-4)) * rnd_unit(g);
+      p.dir = unit(target - p.loc);   // (a straight aim: the arc misses by its sagitta, which varies with the gradient)
+    }
+    if (mode == 4) {   // outside f0 by a hair (or more), moving in or out
+      const double R_guess = 5.0 / gm;
+      p.loc = p.loc + (g.logu(1e-17, 1e-7) * R_guess) * nf0;
+      if (g.u() < 0.5 && dot(nf0, p.dir) > 0) p.dir = p.dir - (2.0 * dot(nf0, p.dir)) * nf0;
+    }
+    if (mode == 6) {   // a direction nearly parallel to face f1, so that the arc bends to or away from it
+      V3 tang = unit(cross(v3(c.n[f1]), rnd_unit(g)));
+      p.dir = unit(tang + (g.sym() * g.logu(1e-6, 3e-1)) * v3(c.n[f1]));
+    }
+    out[0]++;
+    TetLocal L;
+    const TetFast F = tet_fast_exit(c, p, L);
+    if (!F.ok) continue;
+    out[1]++;
+    const double len_loc = L.R * two_atan(F.t, F.sn, F.cs);
+    const TetArc A = tet_arc(c, p);
+    const TetExit E = tet_exit(c, A);
+    double len_ref = tet_exit_length(A, E);
+    int face_ref = E.face;
+    bool bad = false;
+    if (oracle) {   // the reference's construction as the ORACLE has it (angles, acos, atan2): it must say the same
+      const double loc[3] = {p.loc.x, p.loc.y, p.loc.z}, dir[3] = {p.dir.x, p.dir.y, p.dir.z};
+      double len_o = 0;
+      const int face_o = oracle(&c.n[0][0], points, c.g, c.v0, loc, dir, &len_o);
+      if (face_o != face_ref || !(std::fabs(len_o - len_ref) <= tol * L.R)) out[5]++;   // (engine's sine-space search vs oracle)
+      face_ref = face_o, len_ref = len_o;
+    }
+    if (!(len_ref < pos_inf())) out[4]++, bad = true;
+    else if (face_ref != F.face) out[2]++, bad = true;
+    else {
+      const double d = std::fabs(len_loc - len_ref);
+      if (!(d <= tol * L.R)) out[3]++, bad = true;
+      if (d / L.R > dev[0]) dev[0] = d / L.R;
+      if (d / std::fmax(std::fabs(len_ref), 1e-300) > dev[1]) dev[1] = d / std::fmax(std::fabs(len_ref), 1e-300);
+    }
+    static int want_kind = getenv("R3D_FF_KIND") ? atoi(getenv("R3D_FF_KIND")) : 0;   // debugging: which kind of mismatch to record
+    const bool rec = want_kind == 0 ? (out[2] + out[3] + out[4] == 1) : (want_kind == 4 ? (!(len_ref < pos_inf()) && out[4] == 1) : (want_kind == 2 ? (face_ref != F.face && out[2] == 1) : false));
+    if (bad && first_bad && rec) {
+      first_bad[0] = (double)it, first_bad[1] = F.face, first_bad[2] = face_ref, first_bad[3] = len_loc, first_bad[4] = len_ref;
+      first_bad[5] = L.R, first_bad[6] = F.t;
+      for (int f = 0; f < 4; f++) first_bad[7 + f] = c.d[f] - dot(v3(c.n[f]), p.loc);
+      for (int f = 0; f < 4; f++) first_bad[11 + f] = dot(v3(c.n[f]), p.dir);
+    }
   }
 }

@@ -32,6 +32,8 @@ def lib():
         L.r3d_emul_sample_cdf.restype = None
         L.r3d_emul_sample_cdf.argtypes = [C.POINTER(C.c_double), C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.c_uint64,
                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.r3d_emul_slow_moves.restype = C.c_ulonglong
+        L.r3d_emul_slow_moves.argtypes = [C.c_int]
         L.r3d_emul_math.restype = C.c_double
         L.r3d_emul_math.argtypes = [C.c_int, C.c_double, C.c_double]
         _lib = L
