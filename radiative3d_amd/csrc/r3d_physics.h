@@ -349,7 +349,7 @@ R3D_HD TetFast tet_fast_exit(const CellTet& c, const Phonon& p, TetLocal& L) {
   L.R = vel * L.iw;
   L.U = (L.R * L.iw) * L.w;
   const double eR2 = kLocEpsC * (L.R * L.R);
-  LaneMask bad = lm_andnot(lm_all(), lm(L.R > 0.0));   // (a velocity <= 0 or a NaN: not this routine's business)
+  LaneMask good = lm(L.R > 0.0);   // (a velocity <= 0 or a NaN: not this routine's business)
   double tq[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
@@ -363,6 +363,7 @@ R3D_HD TetFast tet_fast_exit(const CellTet& c, const Phonon& p, TetLocal& L) {
     const double disc = P2 - h * k;
     const LaneMask Dpos = lm(disc > eR2), Dneg = lm(disc < -eR2);
     const double S = disc * frsqrt1(disc);   // (garbage where disc <= 0: never looked at there)
+    // t_exit = h / (P + S) for P >= 0, (P - S) / k for P < 0   (q = P + sign(P) S by a copysign: no fewer instructions)
     const bool fwd = P >= 0.0;
     const double q = fwd ? P + S : P - S;
     const double num = fwd ? h : q, den = fwd ? q : k;
@@ -372,7 +373,7 @@ R3D_HD TetFast tet_fast_exit(const CellTet& c, const Phonon& p, TetLocal& L) {
     R3D_LOC_REASON(0, lm_andnot(lm_all(), Dpos | Dneg));
     R3D_LOC_REASON(1, lm_andnot(Dpos, Tpos | Tneg));
     R3D_LOC_REASON(2, lm_andnot(lm_all(), inside));
-    bad = bad | lm_andnot(lm_all(), Dpos | Dneg) | lm_andnot(Dpos, Tpos | Tneg) | lm_andnot(lm_all(), inside);
+    good = good & (Dneg | (Dpos & (Tpos | Tneg))) & inside;
     tq[i] = lm_lane(Dpos & Tpos) ? t : kLocNone;
   }
   TetFast F;
@@ -382,17 +383,17 @@ R3D_HD TetFast tet_fast_exit(const CellTet& c, const Phonon& p, TetLocal& L) {
   F.face = t23 < t01 ? f23 : f01;
   const double lim = F.t + kLocEpsT;
   const LaneMask n0 = lm(tq[0] < lim), n1 = lm(tq[1] < lim), n2 = lm(tq[2] < lim), n3 = lm(tq[3] < lim);
-  R3D_LOC_REASON(3, (n0 & n1) | (n2 & n3) | ((n0 | n1) & (n2 | n3)));
+  const LaneMask tie = (n0 & n1) | (n2 & n3) | ((n0 | n1) & (n2 | n3));
+  R3D_LOC_REASON(3, tie);
   R3D_LOC_REASON(4, lm_andnot(lm_all(), lm(F.t <= 1.0)));
-  bad = bad | (n0 & n1) | (n2 & n3) | ((n0 | n1) & (n2 | n3)) | lm_andnot(lm_all(), lm(F.t <= 1.0));
   const double inv = frcp(1.0 + F.t * F.t);
   F.sn = (2.0 * F.t) * inv, F.omc = F.t * F.sn, F.cs = 1.0 - F.omc;
   // the window of the reference's frame: cos a0 = |w| / |g|, sin a0 = -g.d / |g|
   const double c0 = (L.m2 * L.iw) * c.inv_gmag, s0 = -L.gd * c.inv_gmag;
   const double c1 = c0 * F.cs - s0 * F.sn;
   R3D_LOC_REASON(5, lm_andnot(lm_all(), lm(c0 >= kLocKappa) & lm(c1 >= kLocKappa)));
-  bad = bad | lm_andnot(lm_all(), lm(c0 >= kLocKappa) & lm(c1 >= kLocKappa));
-  F.ok = lm_lane(lm_andnot(lm_all(), bad));
+  good = lm_andnot(good, tie) & lm(F.t <= 1.0) & lm(c0 >= kLocKappa) & lm(c1 >= kLocKappa);
+  F.ok = lm_lane(good);
   return F;
 }
 // th = 2 atan(t) for the exit's t = tan(th / 2) in (0, 1]; (sn, cs) its sine and cosine.  A tetra leg spans a

@@ -318,6 +318,12 @@ constexpr uint32_t kTailBatch = R3D_POOL_TAIL_BATCH, kTailServers = 2;
 constexpr int kKeepersWord = 7;   // PoolCtl::word[kKeepersWord]: waves that keep lanes at the moment
 // A refill starts kRefillBatches batches of histories at a time, their table fetches set going together (the
 // FREE phase below); the FREE queue counts as full for the scheduler at kRefillFull entries.
+#ifndef R3D_TET_REFILL_PAIRS
+#define R3D_TET_REFILL_PAIRS 0
+#endif
+#ifndef R3D_TET_VECTOR_TALLY
+#define R3D_TET_VECTOR_TALLY 0
+#endif
 #ifndef R3D_POOL_REFILL_PAIRS
 #define R3D_POOL_REFILL_PAIRS 1
 #endif
@@ -348,7 +354,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   // refills in pairs of batches (the FREE phase): not in the tetra kernel, whose boundary search leaves the
   // register allocator no slack at all -- the pair's second queue take alone had it spill two registers in the
   // move, and 64 slots waiting for their partners are a smaller pool (NSCP +3 % with it, half-space -10 %)
-  constexpr bool kPairs = kRefillPairs && KIND != CELL_TET;
+  constexpr bool kPairs = kRefillPairs && (KIND != CELL_TET || R3D_TET_REFILL_PAIRS);
   extern __shared__ __align__(16) unsigned char smem[];
   const unsigned tid = threadIdx.x, lane = tid & 63u;
 
@@ -482,7 +488,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   // A batch's counts go to the block's tallies as ONE LDS instruction where the batch ends (lane j adds
   // to tally j), in the layered and the spherical kernel; the tetra kernel, with no vector register to
   // spare for that, adds them one by one where they arise (the vector form there: +0.8 %).
-  constexpr bool kVectorTally = KIND != CELL_TET;
+  constexpr bool kVectorTally = KIND != CELL_TET || R3D_TET_VECTOR_TALLY;
   uint32_t n_lost = 0, n_timeout = 0;   // (per batch, like the event counts: reset where a batch starts)
   auto finish = [&](bool died, int fate, int reason, const Phonon& p, uint64_t hid, uint32_t catches) {
     if (!any_lane(died)) return;

@@ -34,6 +34,9 @@
 #ifndef R3D_TET_LOCAL
 #define R3D_TET_LOCAL 1
 #endif
+#ifndef R3D_TET_EARLY_MFP
+#define R3D_TET_EARLY_MFP 0
+#endif
 #ifndef R3D_TET_SLOW_CALL
 #define R3D_TET_SLOW_CALL 0
 #endif
@@ -287,7 +290,7 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
   //  soon as that is in, not where the free path is formed, a boundary search later; the tetra
   //  kernel has no register to spare for it across the search: +2 % with two spilled)
   double mfp = 0;
-  if constexpr (KIND != CELL_TET) {
+  if constexpr (KIND != CELL_TET || R3D_TET_EARLY_MFP) {
     mfp = T.scat_head[cell_scat(c)].mfp[p.type];
     R3D_SCHED_FENCE();
   }
@@ -312,7 +315,7 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
       if (!slow) {
         e.len = L.R * two_atan(F.t, F.sn, F.cs);
         // free path (scatterers.cpp:297-307, phonons.cpp:601), screened as below
-        const double mfp = T.scat_head[cell_scat(c)].mfp[p.type];
+        if (!R3D_TET_EARLY_MFP) mfp = T.scat_head[cell_scat(c)].mfp[p.type];
         double scatlen = pos_inf();
         if (!((1.0 - u_free) * mfp >= e.len)) scatlen = -log_lean(u_free) * mfp;
         scatters = scatlen < e.len;

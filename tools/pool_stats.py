@@ -10,7 +10,7 @@ from radiative3d_amd.parallel import DeviceResult
 from radiative3d_amd.configs import CONFIGS
 name, deg, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 m = Model(CONFIGS[name](deg) + ["--device-tables"]); e = Engine(m, lib=os.environ.get("R3D_HIP_LIB"))
-L = _ffi.hip_lib(); out = (C.c_ulonglong * 40)()
+L = _ffi.hip_lib(path=os.environ.get("R3D_HIP_LIB")); out = (C.c_ulonglong * 40)()
 buf = DeviceResult(m, "cuda:0")
 e.run_device(n, 0, 0x5EED, *buf.pointers(), carry="carry"); torch.cuda.synchronize(); L.r3d_debug_pool_stats(out)
 e.run_device(n, n, 0x5EED, *buf.pointers(), carry="carry"); torch.cuda.synchronize(); ms = e.last_kernel_ms(); L.r3d_debug_pool_stats(out)
