@@ -89,13 +89,15 @@ $(LIBDIR)/libr3d_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -shared -pthread -o $@ $(HOST_SRC)
 
+# (librccl: the shards' result blocks are summed on the devices, r3d_node_run in csrc/r3d_engine.hip)
+RCCL_LIBS ?= -L/opt/rocm/lib -lrccl
 $(LIBDIR)/libr3d_hip.so: $(call engine_objs,main)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=gfx950 -shared -pthread -o $@ $(call engine_objs,main)
+	$(HIPCC) --offload-arch=gfx950 -shared -pthread -o $@ $(call engine_objs,main) $(RCCL_LIBS)
 
 $(LIBDIR)/libr3d_hip_repro.so: $(call engine_objs,repro)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=gfx950 -shared -pthread -o $@ $(call engine_objs,repro)
+	$(HIPCC) --offload-arch=gfx950 -shared -pthread -o $@ $(call engine_objs,repro) $(RCCL_LIBS)
 
 oracle/libr3d_oracle.so: oracle/r3d_oracle.cpp oracle/philox.h include/r3d.h
 	$(CXX) $(CXXFLAGS) -shared -o $@ oracle/r3d_oracle.cpp
@@ -130,4 +132,4 @@ variant:
 	$(HIPCC) $(HIPFLAGS) $(HIPFLAGS_SPH) $(VDEFS) $(DEFS_SPH) -DR3D_KIND=2 -c -o $(VOBJ)_sph.o $(CSRC)/r3d_kernels_kind.hip & p5=$$!; \
 	rc=0; for p in $$p1 $$p2 $$p3 $$p4 $$p5 $$p6; do wait $$p || rc=1; done; exit $$rc
 	$(HIPCC) --offload-arch=gfx950 -shared -pthread -o $(LIBDIR)/variant_$(NAME).so $(VOBJ)_engine.o \
-	    $(VOBJ)_tables.o $(VOBJ)_volume.o $(VOBJ)_cyl.o $(VOBJ)_tet.o $(VOBJ)_sph.o
+	    $(VOBJ)_tables.o $(VOBJ)_volume.o $(VOBJ)_cyl.o $(VOBJ)_tet.o $(VOBJ)_sph.o $(RCCL_LIBS)

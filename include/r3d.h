@@ -289,9 +289,9 @@ int r3d_run_device(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,
                    r3d_final* d_finals, void* stream);
 
 /* The seam in one call: engines on devices 0 .. n_gpus-1, the id
- * range [first_id, first_id + n) cut into n_gpus contiguous shards run concurrently
- * (one host thread per device), and the shards' results ADDED into *out on the
- * host.  Equals r3d_run on one engine for the same ids (integers exactly, energies
+ * range [first_id, first_id + n) cut into n_gpus contiguous shards run concurrently,
+ * and the shards' results summed on the devices (RCCL, see r3d_node_run below) and
+ * ADDED into *out.  Equals r3d_run on one engine for the same ids (integers exactly, energies
  * to summation order).  Returns 0 on success.                                 */
 int r3d_run_model(const r3d_model_desc* model, uint64_t n, uint64_t first_id, uint64_t seed,
                   int n_gpus, r3d_result* out);
@@ -302,6 +302,28 @@ int r3d_run_model(const r3d_model_desc* model, uint64_t n, uint64_t first_id, ui
  * vis/seisplot/combine.m:26-33.)                                               */
 int r3d_run_model_on(const r3d_model_desc* model, uint64_t n, uint64_t first_id, uint64_t seed,
                      const int* devices, int n_devices, r3d_result* out);
+
+/* A NODE: the same seam for a host that runs more than one job on a model (r3d_run_model_on builds and
+ * drops a node per call: tables made or uploaded every time).  r3d_node_create: one engine per entry of
+ * `devices`, kept until r3d_node_destroy.  r3d_node_run: the id range cut into contiguous shards as
+ * above, every shard's kernel enqueued on its engine's stream into that engine's own block in HBM, and
+ * the blocks -- f64 energies, u64 counts, u64 counters -- SUMMED ON THE DEVICES by one grouped RCCL
+ * reduce per buffer (ncclReduce, sum, to devices[0], in stream order behind the kernels: xGMI between
+ * the GPUs of a node); the host reads that one block and ADDS it into *out.  This is the reference's
+ * "replicas + combine" (scripts/do-parallel.sh:23-29, vis/seisplot/combine.m:26-33: replicas' traces
+ * add).  RCCL refuses a communicator that names a device twice: a node whose shards share a device
+ * adds the blocks on the host instead -- r3d_node_reduction says which ("rccl" / "host").  Counts and
+ * counters equal one engine's run of the same ids exactly, energies to summation order.  If a shard
+ * fails nothing is added to *out and the message names shard and device.
+ * r3d_node_engine: shard g's engine (to attach an event log or a grid before a run, to read them
+ * after); it stays the node's.                                                        */
+typedef struct r3d_node r3d_node;
+r3d_node* r3d_node_create(const r3d_model_desc* model, const int* devices, int n_devices);
+int r3d_node_run(r3d_node* node, uint64_t n, uint64_t first_id, uint64_t seed, r3d_result* out);
+int r3d_node_size(const r3d_node* node);
+r3d_engine* r3d_node_engine(r3d_node* node, int shard);
+const char* r3d_node_reduction(const r3d_node* node);
+void r3d_node_destroy(r3d_node* node);
 
 /* r3d_run_device for a CHAIN of batches (same engine, same seed, launches in stream
  * order).  A batch ends in a drain phase in which ever fewer lanes still carry a
@@ -383,7 +405,11 @@ int r3d_volume_scatter_add(int device, uint32_t* d_counters, uint64_t len, const
  * counts for their share of the frames: engine g for frames [frames[g], frames[g + 1]) of both wave
  * types (`frames`: n + 1 entries, may be NULL; the cut is contiguous and balanced), the rest of its grid
  * keeps that engine's own counts.  Pairs travel by hipMemcpyPeer.  *saturated (may be NULL) receives the
- * number of cells that reached 2^32 - 1.  Waits for every launch of the engines.  Returns 0 on success. */
+ * number of cells that reached 2^32 - 1.  Waits for every launch of the engines.  Returns 0 on success.
+ * In two phases: first every engine compacts and COUNTS what it would send -- a grid too full for its pair
+ * buffer (more than a sixteenth of its cells non-zero in the other owners' frames) fails the call here, with
+ * every grid as it was --, only then do pairs travel and owners add.  After a failure in the second phase (a
+ * failed HIP call) the grids are undefined.                                                            */
 int r3d_volume_reduce_by_frame(r3d_engine* const* engines, int n, uint32_t* frames, uint64_t* saturated);
 
 /* ---- optional per-event report stream --------------------------------------

@@ -256,6 +256,17 @@ def hip_lib(reproducible=False, path=None):
         L.r3d_engine_carry_pending.argtypes = [C.c_void_p]
         L.r3d_engine_set_volume_buffer.restype = C.c_int
         L.r3d_engine_set_volume_buffer.argtypes = [C.c_void_p, C.POINTER(VolumeDesc), C.c_void_p]
+        L.r3d_node_create.restype = C.c_void_p
+        L.r3d_node_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(C.c_int), C.c_int]
+        L.r3d_node_run.restype = C.c_int
+        L.r3d_node_run.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(Result)]
+        L.r3d_node_size.restype = C.c_int
+        L.r3d_node_size.argtypes = [C.c_void_p]
+        L.r3d_node_engine.restype = C.c_void_p
+        L.r3d_node_engine.argtypes = [C.c_void_p, C.c_int]
+        L.r3d_node_reduction.restype = C.c_char_p
+        L.r3d_node_reduction.argtypes = [C.c_void_p]
+        L.r3d_node_destroy.argtypes = [C.c_void_p]
         L.r3d_run_model_on.restype = C.c_int
         L.r3d_run_model_on.argtypes = [C.POINTER(ModelDesc), C.c_uint64, C.c_uint64, C.c_uint64,
                                        C.POINTER(C.c_int), C.c_int, C.POINTER(Result)]

@@ -17,6 +17,7 @@
 // The product has no CPU path: without a HIP device every entry point fails with an error
 // message.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // the shards' blocks are summed on the devices (r3d_node_run)
 
 #include <algorithm>
 #include <cmath>
@@ -638,48 +639,188 @@ int r3d_run(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, r3d_res
   return run_host(e, n, first_id, seed, out, nullptr);
 }
 
+// ---- a node: one engine per shard, kept alive across runs, the shards' blocks summed ON THE DEVICES ------------
+// (include/r3d.h r3d_node_*).  Each run: every shard's kernel is enqueued on its engine's stream into the engine's
+// own block in HBM; then ONE grouped ncclReduce (sum) per buffer -- f64 energies, u64 counts, u64 counters -- over
+// the shards' streams brings the job's totals to shard 0's device, and the host reads that one block.  This is the
+// reference's "replicas + combine" (scripts/do-parallel.sh:23-29, vis/seisplot/combine.m:26-33) with the combine
+// done by RCCL over xGMI.  RCCL refuses a communicator that names a device twice: such a node (shards sharing a
+// GPU -- tests, or a user who wants it) adds the blocks on the host instead, as r3d_run_model_on always did.
+struct r3d_node {
+  std::vector<int> devices;
+  std::vector<r3d_engine*> engines;
+  std::vector<ncclComm_t> comms;   // empty: host sum
+  DevBuf sum_energy, sum_counts, sum_scalars;   // on devices[0]: where the reduce puts the job's totals
+  size_t ne = 0, nc = 0;
+  uint64_t runs = 0;
+};
+
+#define R3D_NCCL_OK(call)                                                                     \
+  do {                                                                                        \
+    ncclResult_t r__ = (call);                                                                \
+    if (r__ != ncclSuccess) {                                                                 \
+      g_error = std::string(#call) + ": " + ncclGetErrorString(r__);                          \
+      return fail_value;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+void r3d_node_destroy(r3d_node* nd) {
+  if (!nd) return;
+  for (size_t g = 0; g < nd->comms.size(); g++) {
+    DeviceGuard on(nd->devices[g]);
+    (void)ncclCommDestroy(nd->comms[g]);
+  }
+  for (r3d_engine* e : nd->engines)
+    if (e) r3d_engine_destroy(e);
+  DeviceGuard on(nd->devices.empty() ? 0 : nd->devices[0]);   // (the reduced block is freed on its device)
+  delete nd;
+}
+
+r3d_node* r3d_node_create(const r3d_model_desc* model, const int* devices, int n_devices) {
+  if (!model) return g_error = "null model", nullptr;
+  if (n_devices < 1 || !devices) return g_error = "at least one device is needed (the engine has no CPU path)", nullptr;
+  auto nd = std::make_unique<r3d_node>();
+  nd->devices.assign(devices, devices + n_devices);
+  nd->ne = (size_t)model->n_seismometers * model->params.n_bins * R3D_N_ENERGY;
+  nd->nc = (size_t)model->n_seismometers * model->params.n_bins * R3D_N_COUNT;
+  nd->engines.assign(n_devices, nullptr);
+  // the engines are built side by side (tables made in HBM: tens of milliseconds; uploaded: seconds each)
+  std::vector<std::string> errors(n_devices);
+  {
+    std::vector<std::thread> pool;
+    for (int g = 0; g < n_devices; g++)
+      pool.emplace_back([&, g] {
+        nd->engines[g] = r3d_engine_create(model, devices[g]);
+        if (!nd->engines[g]) errors[g] = "shard " + std::to_string(g) + " (device " + std::to_string(devices[g]) + "): " + g_error;
+      });
+    for (auto& t : pool) t.join();
+  }
+  for (int g = 0; g < n_devices; g++)
+    if (!errors[g].empty()) {
+      g_error = errors[g];
+      r3d_node_destroy(nd.release());
+      return nullptr;
+    }
+  bool distinct = true;
+  for (int g = 0; g < n_devices; g++)
+    for (int h = 0; h < g; h++) distinct = distinct && devices[g] != devices[h];
+  if (distinct) {
+    nd->comms.assign(n_devices, nullptr);
+    const ncclResult_t r = ncclCommInitAll(nd->comms.data(), n_devices, devices);
+    if (r != ncclSuccess) {
+      g_error = std::string("ncclCommInitAll: ") + ncclGetErrorString(r);
+      nd->comms.clear();
+      r3d_node_destroy(nd.release());
+      return nullptr;
+    }
+    DeviceGuard on(devices[0]);
+    if (on.status != hipSuccess || nd->sum_energy.alloc_zero(std::max<size_t>(nd->ne, 1) * sizeof(double)) != hipSuccess ||
+        nd->sum_counts.alloc_zero(std::max<size_t>(nd->nc, 1) * sizeof(uint64_t)) != hipSuccess ||
+        nd->sum_scalars.alloc_zero(R3D_N_SCALARS * sizeof(uint64_t)) != hipSuccess) {
+      g_error = "r3d_node_create: no memory for the reduced block";
+      r3d_node_destroy(nd.release());
+      return nullptr;
+    }
+  }
+  return nd.release();
+}
+
+int r3d_node_size(const r3d_node* nd) { return nd ? (int)nd->engines.size() : 0; }
+r3d_engine* r3d_node_engine(r3d_node* nd, int shard) {
+  if (!nd || shard < 0 || shard >= (int)nd->engines.size()) return g_error = "r3d_node_engine: no such shard", nullptr;
+  return nd->engines[shard];
+}
+const char* r3d_node_reduction(const r3d_node* nd) { return !nd ? "" : nd->comms.empty() ? "host" : "rccl"; }
+
+int r3d_node_run(r3d_node* nd, uint64_t n, uint64_t first_id, uint64_t seed, r3d_result* out) {
+  const int fail_value = 1;
+  if (!nd) return g_error = "null node", 1;
+  if (!out || !out->energy || !out->counts) return g_error = "null result", 1;
+  const int N = (int)nd->engines.size();
+  const size_t ne = nd->ne, nc = nd->nc;
+  // every shard's launch, asynchronously, each on its engine's stream into its engine's block
+  for (int g = 0; g < N; g++) {
+    r3d_engine* e = nd->engines[g];
+    const uint64_t lo = n / N * g + std::min<uint64_t>(g, n % N);
+    const uint64_t cnt = n / N + ((uint64_t)g < n % N ? 1 : 0);
+    auto shard_error = [&](const std::string& what) {
+      g_error = "shard " + std::to_string(g) + " (device " + std::to_string(nd->devices[g]) + "): " + what;
+      for (int h = 0; h <= g; h++) {   // what was enqueued runs out before anyone reads or reuses the blocks
+        DeviceGuard on(nd->devices[h]);
+        (void)hipStreamSynchronize(nd->engines[h]->stream);
+      }
+      return 1;
+    };
+    DeviceGuard on(e->device);
+    if (on.status != hipSuccess || hipMemsetAsync(e->d_energy.p, 0, e->d_energy.bytes, e->stream) != hipSuccess ||
+        hipMemsetAsync(e->d_counts.p, 0, e->d_counts.bytes, e->stream) != hipSuccess ||
+        hipMemsetAsync(e->d_scalars.p, 0, e->d_scalars.bytes, e->stream) != hipSuccess)
+      return shard_error("cannot clear the result block");
+    if (enqueue(e, cnt, first_id + lo, seed, reinterpret_cast<double*>(e->d_energy.p), reinterpret_cast<uint64_t*>(e->d_counts.p),
+                reinterpret_cast<uint64_t*>(e->d_scalars.p), nullptr, e->stream))
+      return shard_error(g_error);
+  }
+  std::vector<double> he(std::max<size_t>(ne, 1), 0.0);
+  std::vector<uint64_t> hc(std::max<size_t>(nc, 1), 0);
+  uint64_t hs[R3D_N_SCALARS] = {0};
+  auto wait_all = [&]() -> int {
+    for (int g = 0; g < N; g++) {
+      R3D_ON_DEVICE(nd->devices[g]);
+      R3D_HIP_OK(hipStreamSynchronize(nd->engines[g]->stream));
+    }
+    return 0;
+  };
+  if (!nd->comms.empty()) {
+    // one grouped reduce per buffer, in stream order behind each shard's kernel: the sums land on devices[0]
+    R3D_NCCL_OK(ncclGroupStart());
+    for (int g = 0; g < N; g++) {
+      r3d_engine* e = nd->engines[g];
+      if (ne) R3D_NCCL_OK(ncclReduce(e->d_energy.p, g == 0 ? nd->sum_energy.p : nullptr, ne, ncclDouble, ncclSum, 0, nd->comms[g], e->stream));
+      if (nc) R3D_NCCL_OK(ncclReduce(e->d_counts.p, g == 0 ? nd->sum_counts.p : nullptr, nc, ncclUint64, ncclSum, 0, nd->comms[g], e->stream));
+      R3D_NCCL_OK(ncclReduce(e->d_scalars.p, g == 0 ? nd->sum_scalars.p : nullptr, R3D_N_SCALARS, ncclUint64, ncclSum, 0, nd->comms[g], e->stream));
+    }
+    R3D_NCCL_OK(ncclGroupEnd());
+    if (wait_all()) return 1;
+    R3D_ON_DEVICE(nd->devices[0]);
+    if (ne) R3D_HIP_OK(hipMemcpy(he.data(), nd->sum_energy.p, ne * sizeof(double), hipMemcpyDeviceToHost));
+    if (nc) R3D_HIP_OK(hipMemcpy(hc.data(), nd->sum_counts.p, nc * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    R3D_HIP_OK(hipMemcpy(hs, nd->sum_scalars.p, sizeof hs, hipMemcpyDeviceToHost));
+  } else {
+    if (wait_all()) return 1;
+    std::vector<double> te(std::max<size_t>(ne, 1));
+    std::vector<uint64_t> tc(std::max<size_t>(nc, 1));
+    uint64_t ts[R3D_N_SCALARS];
+    for (int g = 0; g < N; g++) {
+      r3d_engine* e = nd->engines[g];
+      R3D_ON_DEVICE(e->device);
+      if (ne) R3D_HIP_OK(hipMemcpy(te.data(), e->d_energy.p, ne * sizeof(double), hipMemcpyDeviceToHost));
+      if (nc) R3D_HIP_OK(hipMemcpy(tc.data(), e->d_counts.p, nc * sizeof(uint64_t), hipMemcpyDeviceToHost));
+      R3D_HIP_OK(hipMemcpy(ts, e->d_scalars.p, sizeof ts, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < ne; i++) he[i] += te[i];
+      for (size_t i = 0; i < nc; i++) hc[i] += tc[i];
+      for (int i = 0; i < R3D_N_SCALARS; i++) hs[i] += ts[i];
+    }
+  }
+  // (nothing was added to *out until every shard had run and the sums were read)
+  for (size_t i = 0; i < ne; i++) out->energy[i] += he[i];
+  for (size_t i = 0; i < nc; i++) out->counts[i] += hc[i];
+  out->n_lost += hs[0], out->n_timeout += hs[1], out->n_invalid += hs[2];
+  for (int r = 0; r < R3D_INV_NUM; r++) out->invalid_reasons[r] += hs[3 + r];
+  for (int k = 0; k < R3D_EV_NUM; k++) out->events[k] += hs[3 + R3D_INV_NUM + k];
+  nd->runs++;
+  return 0;
+}
+
 int r3d_run_model_on(const r3d_model_desc* model, uint64_t n, uint64_t first_id, uint64_t seed,
                      const int* devices, int n_devices, r3d_result* out) {
   if (!model || !out || !out->energy || !out->counts) return g_error = "null argument", 1;
-  if (n_devices < 1 || !devices) return g_error = "at least one device is needed (the engine has no CPU path)", 1;
-  const size_t ne = (size_t)model->n_seismometers * model->params.n_bins * R3D_N_ENERGY;
-  const size_t nc = (size_t)model->n_seismometers * model->params.n_bins * R3D_N_COUNT;
-  struct Shard {
-    std::vector<double> energy;
-    std::vector<uint64_t> counts;
-    r3d_result res{};
-    std::string error;
-  };
-  std::vector<Shard> shards(n_devices);
-  std::vector<std::thread> pool;
-  for (int g = 0; g < n_devices; g++) {
-    pool.emplace_back([&, g] {
-      Shard& sh = shards[g];
-      sh.energy.assign(std::max<size_t>(ne, 1), 0.0), sh.counts.assign(std::max<size_t>(nc, 1), 0);
-      sh.res.energy = sh.energy.data(), sh.res.counts = sh.counts.data();
-      const uint64_t lo = n / n_devices * g + std::min<uint64_t>(g, n % n_devices);
-      const uint64_t cnt = n / n_devices + ((uint64_t)g < n % n_devices ? 1 : 0);
-      r3d_engine* e = r3d_engine_create(model, devices[g]);
-      if (!e) {
-        sh.error = "shard " + std::to_string(g) + " (device " + std::to_string(devices[g]) + "): " + g_error;   // (thread-local: this thread's message)
-        return;
-      }
-      if (r3d_run(e, cnt, first_id + lo, seed, &sh.res))
-        sh.error = "shard " + std::to_string(g) + " (device " + std::to_string(devices[g]) + "): " + g_error;
-      r3d_engine_destroy(e);
-    });
-  }
-  for (auto& t : pool) t.join();
-  for (const Shard& sh : shards)
-    if (!sh.error.empty()) return g_error = sh.error, 1;   // nothing is added to *out unless every shard ran
-  for (const Shard& sh : shards) {
-    for (size_t i = 0; i < ne; i++) out->energy[i] += sh.energy[i];
-    for (size_t i = 0; i < nc; i++) out->counts[i] += sh.counts[i];
-    out->n_lost += sh.res.n_lost, out->n_timeout += sh.res.n_timeout, out->n_invalid += sh.res.n_invalid;
-    for (int r = 0; r < R3D_INV_NUM; r++) out->invalid_reasons[r] += sh.res.invalid_reasons[r];
-    for (int k = 0; k < R3D_EV_NUM; k++) out->events[k] += sh.res.events[k];
-  }
-  return 0;
+  r3d_node* nd = r3d_node_create(model, devices, n_devices);
+  if (!nd) return 1;
+  const int rc = r3d_node_run(nd, n, first_id, seed, out);
+  const std::string keep = rc ? g_error : std::string();
+  r3d_node_destroy(nd);
+  if (rc) g_error = keep;
+  return rc;
 }
 
 int r3d_run_model(const r3d_model_desc* model, uint64_t n, uint64_t first_id, uint64_t seed, int n_gpus,
@@ -925,30 +1066,45 @@ int r3d_volume_reduce_by_frame(r3d_engine* const* engines, int n, uint32_t* fram
       R3D_HIP_OK(hipDeviceSynchronize());
     }
   }
+  // Phase 1, nothing modified yet: every source compacts the other owners' frame ranges of its grid into its own
+  // pair buffer (on its own device) and the counts are read.  A source whose pairs do not fit is found HERE, before
+  // any owner's grid has been added to: the call then fails with every grid as it was.
+  struct Source {
+    DevBuf pairs, count;
+    std::vector<uint64_t> ends;
+  };
+  std::vector<Source> sources(n > 1 ? n : 0);
   for (int src = 0; src < n && n > 1; src++) {
     r3d_engine* S = engines[src];
+    Source& P = sources[src];
     R3D_ON_DEVICE(S->device);
-    DevBuf pairs, count;
-    R3D_HIP_OK(pairs.alloc_zero(cap * 2 * sizeof(uint32_t)));
-    R3D_HIP_OK(count.alloc_zero(sizeof(uint64_t)));
+    R3D_HIP_OK(P.pairs.alloc_zero(cap * 2 * sizeof(uint32_t)));
+    R3D_HIP_OK(P.count.alloc_zero(sizeof(uint64_t)));
     const uint32_t* grid = reinterpret_cast<const uint32_t*>(r3d_volume_device_ptr(S));
-    std::vector<uint64_t> ends(n, 0);
+    P.ends.assign(n, 0);
     for (int owner = 0; owner < n; owner++) {
       if (owner != src)
         for (uint64_t t = 0; t < 2; t++) {
           const uint64_t b = (t * n_frames + frame_lo(owner)) * frame_cells, e = (t * n_frames + frame_lo(owner + 1)) * frame_cells;
-          if (e > b && r3d_volume_compact(S->device, grid, b, e, reinterpret_cast<uint32_t*>(pairs.p), cap,
-                                          reinterpret_cast<uint64_t*>(count.p), S->stream))
+          if (e > b && r3d_volume_compact(S->device, grid, b, e, reinterpret_cast<uint32_t*>(P.pairs.p), cap,
+                                          reinterpret_cast<uint64_t*>(P.count.p), S->stream))
             return 1;
         }
       R3D_HIP_OK(hipStreamSynchronize(S->stream));
-      R3D_HIP_OK(hipMemcpy(&ends[owner], count.p, sizeof(uint64_t), hipMemcpyDeviceToHost));
+      R3D_HIP_OK(hipMemcpy(&P.ends[owner], P.count.p, sizeof(uint64_t), hipMemcpyDeviceToHost));
     }
-    if (ends[n - 1] > cap)
-      return g_error = "r3d_volume_reduce_by_frame: the grid is too full for the pair buffer (more than a sixteenth of its "
-                       "cells are non-zero): add the grids densely instead", 1;
+    if (P.ends[n - 1] > cap)
+      return g_error = "r3d_volume_reduce_by_frame: the grid of engine " + std::to_string(src) + " is too full for the pair buffer (" +
+                       std::to_string(P.ends[n - 1]) + " non-zero cells in the other owners' frames, room for " + std::to_string(cap) +
+                       ": a sixteenth of the grid); no grid has been modified", 1;
+  }
+  // Phase 2: the pairs to their owners, added there.  (A failure from here on is a failed HIP call -- a lost device,
+  // no memory for the received pairs --, and leaves the owners' frames partly summed: the grids are then undefined.)
+  for (int src = 0; src < n && n > 1; src++) {
+    r3d_engine* S = engines[src];
+    const Source& P = sources[src];
     for (int owner = 0; owner < n; owner++) {
-      const uint64_t lo = owner ? ends[owner - 1] : 0, cnt = ends[owner] - lo;
+      const uint64_t lo = owner ? P.ends[owner - 1] : 0, cnt = P.ends[owner] - lo;
       if (owner == src || cnt == 0) continue;
       r3d_engine* D = engines[owner];
       DeviceGuard on_dst(D->device);
@@ -957,7 +1113,7 @@ int r3d_volume_reduce_by_frame(r3d_engine* const* engines, int n, uint32_t* fram
       R3D_HIP_OK(got.alloc_zero(cnt * 2 * sizeof(uint32_t)));
       R3D_HIP_OK(flags.alloc_zero(2 * sizeof(uint64_t)));
       // (the pairs to the owner's device: a copy between peers, or within the device when the engines share one)
-      R3D_HIP_OK(hipMemcpyPeer(got.p, D->device, reinterpret_cast<const uint32_t*>(pairs.p) + 2 * lo, S->device, cnt * 2 * sizeof(uint32_t)));
+      R3D_HIP_OK(hipMemcpyPeer(got.p, D->device, reinterpret_cast<const uint32_t*>(P.pairs.p) + 2 * lo, S->device, cnt * 2 * sizeof(uint32_t)));
       if (r3d_volume_scatter_add(D->device, reinterpret_cast<uint32_t*>(r3d_volume_device_ptr(D)), len,
                                  reinterpret_cast<const uint32_t*>(got.p), cnt, reinterpret_cast<uint64_t*>(flags.p), D->stream))
         return 1;

@@ -272,11 +272,11 @@ void ParseCommandLine(const std::vector<std::string>& tokens, ModelParams& par,
         for (int k = 0; k < 3; k++) mission.GridLo[k] = o.real();
         for (int k = 0; k < 3; k++) mission.GridHi[k] = o.real();
         for (int k = 0; k < 3; k++) {
-          if (v[k] < 1 || !(mission.GridHi[k] > mission.GridLo[k]))
-            throw Runtime("--scatter-grid=NX,NY,NZ,FRAMES,X0,Y0,Z0,X1,Y1,Z1: cell counts must be positive and X1 > X0 etc.");
+          if (v[k] < 1 || v[k] > 0xFFFFFFFFL || !(mission.GridHi[k] > mission.GridLo[k]))
+            throw Runtime("--scatter-grid=NX,NY,NZ,FRAMES,X0,Y0,Z0,X1,Y1,Z1: cell counts must be positive (and below 2^32) and X1 > X0 etc.");
           mission.GridDims[k] = (unsigned)v[k];
         }
-        if (v[3] < 1) throw Runtime("--scatter-grid: FRAMES must be positive.");
+        if (v[3] < 1 || v[3] > 0xFFFFFFFFL) throw Runtime("--scatter-grid: FRAMES must be positive (and below 2^32).");
         mission.GridFrames = (unsigned)v[3];
         mission.bScatterGrid = true;
         break;

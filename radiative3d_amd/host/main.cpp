@@ -9,6 +9,7 @@
 // reference seeds from the clock and is single-process); `--reports` keywords
 // other than INV / ALL_OFF are accepted but the per-event text stream is not
 // produced.
+#include <cstdio>
 #include <cstdlib>
 #include <fstream>
 #include <iomanip>
@@ -98,16 +99,6 @@ void run_event_test(const ModelParams& par) {
   }
 }
 
-struct Shard {
-  std::vector<double> energy;
-  std::vector<uint64_t> counts;
-  std::vector<r3d_event> events;
-  uint64_t events_reported = 0;
-  r3d_result res{};
-  std::string error;
-  r3d_engine* engine = nullptr;   // kept until the grids are added (scatter grid runs)
-};
-
 // What --scatter-grid asks for, and where it goes.
 struct GridJob {
   bool on = false;
@@ -115,103 +106,103 @@ struct GridJob {
   std::string header_path, raw_path, raw_name;
 };
 
-// The replacement for Model::RunSimulation()'s loop: shard the id range over the requested devices (one
-// engine per entry, one host thread each), sum on the host.  With a scatter grid every shard's engine
-// fills its own grid in HBM; the grids are then added by frame (r3d_volume_reduce_by_frame: every engine
-// ends with the job's counts for its share of the frames) and each engine's frames written to the raw file.
-void run_simulation(const Model& model, uint64_t n, uint64_t seed, const std::vector<int>& devices, r3d_result& total,
+// A scatter grid is checked BEFORE the run (a 1e8-history job must not find out at its end that its grid
+// cannot be reduced or written): the pair exchange of r3d_volume_reduce_by_frame carries 32-bit cell indices,
+// and the output directory must take the files.
+void check_grid_job(const GridJob& grid, size_t n_shards) {
+  if (!grid.on) return;
+  const unsigned long long cells = 2ull * grid.desc.dims[0] * grid.desc.dims[1] * grid.desc.dims[2] * grid.desc.n_frames;
+  if (n_shards > 1 && cells >= (1ull << 32))
+    throw Runtime("--scatter-grid: 2 x NX x NY x NZ x FRAMES = " + std::to_string(cells) + " cells do not fit the 32-bit cell "
+                  "indices the shards' grids are added with (r3d_volume_reduce_by_frame); use one device or a coarser grid.");
+  const std::string probe = grid.raw_path + ".part";
+  std::ofstream f(probe.c_str(), std::ios::binary);
+  if (!f) throw Runtime("--scatter-grid: cannot write " + probe);
+  f.close();
+  std::remove(probe.c_str());
+}
+
+// The replacement for Model::RunSimulation()'s loop: a node (include/r3d.h r3d_node_*) shards the id range over
+// the requested devices, one engine per entry, and sums the shards' blocks on the devices (RCCL; on the host when
+// two shards share a device).  With a scatter grid every shard's engine fills its own grid in HBM; the grids are
+// then added by frame (r3d_volume_reduce_by_frame: every engine ends with the job's counts for its share of the
+// frames) and each engine's frames written to the raw file.
+void run_simulation(const Model& model, uint64_t n, uint64_t seed, r3d_node* node, r3d_result& total,
                     std::vector<double>& energy, std::vector<uint64_t>& counts, uint32_t report_mask,
-                    std::vector<r3d_event>& events, uint64_t& events_dropped, r3d_engine* engine0, const GridJob& grid) {
+                    std::vector<r3d_event>& events, uint64_t& events_dropped, const GridJob& grid) {
   const r3d_model_desc& d = model.Desc();
-  const int gpus = (int)devices.size();
+  const int gpus = r3d_node_size(node);
   const size_t ne = (size_t)d.n_seismometers * d.params.n_bins * R3D_N_ENERGY;
   const size_t nc = (size_t)d.n_seismometers * d.params.n_bins * R3D_N_COUNT;
   energy.assign(ne, 0.0), counts.assign(nc, 0);
   total = r3d_result{};
   total.energy = energy.data(), total.counts = counts.data();
-  std::vector<Shard> shards(gpus);
-  std::vector<std::thread> pool;
+  std::vector<r3d_engine*> engines;
+  std::vector<uint64_t> caps(gpus, 0);
   for (int g = 0; g < gpus; g++) {
-    pool.emplace_back([&, g] {
-      Shard& sh = shards[g];
-      sh.energy.assign(ne, 0.0), sh.counts.assign(nc, 0);
-      sh.res.energy = sh.energy.data(), sh.res.counts = sh.counts.data();
-      const uint64_t lo = n / gpus * g + std::min<uint64_t>(g, n % gpus);
-      const uint64_t cnt = n / gpus + ((uint64_t)g < n % gpus ? 1 : 0);
-      r3d_engine* e = (g == 0 && engine0) ? engine0 : r3d_engine_create(&d, devices[g]);
-      if (!e) {
-        sh.error = r3d_last_error();
-        return;
-      }
-      sh.engine = e;
-      // report stream: room for 256 events per history, at most 2^26 records (6.4 GB) per GPU
-      const uint64_t cap = std::min<uint64_t>(std::max<uint64_t>(cnt, 1) * 256, uint64_t(1) << 26);
-      if (report_mask && r3d_engine_set_event_log(e, report_mask, cap)) sh.error = r3d_last_error();
-      if (sh.error.empty() && grid.on && r3d_engine_set_volume(e, &grid.desc)) sh.error = r3d_last_error();
-      if (sh.error.empty() && r3d_run(e, cnt, lo, seed, &sh.res)) sh.error = r3d_last_error();
-      if (sh.error.empty() && report_mask) {
-        sh.events_reported = r3d_event_log_count(e);
-        sh.events.resize((size_t)std::min<uint64_t>(sh.events_reported, cap));
-        if (r3d_event_log_read(e, sh.events.data(), sh.events.size(), 0) == ~uint64_t(0)) sh.error = r3d_last_error();
-      }
-    });
+    r3d_engine* e = r3d_node_engine(node, g);
+    engines.push_back(e);
+    // report stream: room for 256 events per history, at most 2^26 records (6.4 GB) per GPU
+    const uint64_t cnt = n / gpus + ((uint64_t)g < n % gpus ? 1 : 0);
+    caps[g] = std::min<uint64_t>(std::max<uint64_t>(cnt, 1) * 256, uint64_t(1) << 26);
+    if (report_mask && r3d_engine_set_event_log(e, report_mask, caps[g])) throw Runtime(r3d_last_error());
+    if (grid.on && r3d_engine_set_volume(e, &grid.desc)) throw Runtime(r3d_last_error());
   }
-  for (auto& t : pool) t.join();
-  auto release = [&] {
-    for (Shard& sh : shards)
-      if (sh.engine) r3d_engine_destroy(sh.engine), sh.engine = nullptr;
-  };
-  for (const Shard& sh : shards)
-    if (!sh.error.empty()) {
-      release();
-      throw Runtime(sh.error);
+  if (r3d_node_run(node, n, 0, seed, &total)) throw Runtime(r3d_last_error());
+  std::cout << "|  Shards: " << gpus << " (summed by " << r3d_node_reduction(node) << ")\n";
+  if (report_mask)
+    for (int g = 0; g < gpus; g++) {   // in shard order: ids ascend across shards
+      const uint64_t reported = r3d_event_log_count(engines[g]);
+      const size_t at = events.size(), got = (size_t)std::min<uint64_t>(reported, caps[g]);
+      events.resize(at + got);
+      if (got && r3d_event_log_read(engines[g], events.data() + at, got, 0) == ~uint64_t(0)) throw Runtime(r3d_last_error());
+      events_dropped += reported - got;
+      if (r3d_engine_set_event_log(engines[g], 0, 0)) throw Runtime(r3d_last_error());   // (its HBM back before the grids are added)
     }
-  for (const Shard& sh : shards) {
-    for (size_t i = 0; i < ne; i++) energy[i] += sh.energy[i];
-    for (size_t i = 0; i < nc; i++) counts[i] += sh.counts[i];
-    total.n_lost += sh.res.n_lost, total.n_timeout += sh.res.n_timeout, total.n_invalid += sh.res.n_invalid;
-    for (int r = 0; r < R3D_INV_NUM; r++) total.invalid_reasons[r] += sh.res.invalid_reasons[r];
-    for (int k = 0; k < R3D_EV_NUM; k++) total.events[k] += sh.res.events[k];
-    events.insert(events.end(), sh.events.begin(), sh.events.end());
-    events_dropped += sh.events_reported - sh.events.size();
-  }
   if (grid.on) {
-    std::vector<r3d_engine*> engines;
-    for (Shard& sh : shards) engines.push_back(sh.engine);
     std::vector<uint32_t> frames(gpus + 1);
     uint64_t saturated = 0;
-    std::string err;
-    if (r3d_volume_reduce_by_frame(engines.data(), gpus, frames.data(), &saturated)) err = r3d_last_error();
+    if (r3d_volume_reduce_by_frame(engines.data(), gpus, frames.data(), &saturated)) throw Runtime(r3d_last_error());
     const uint64_t fc = (uint64_t)grid.desc.dims[0] * grid.desc.dims[1] * grid.desc.dims[2], nf = grid.desc.n_frames;
     unsigned long long binned = 0;
-    std::ofstream raw(grid.raw_path.c_str(), std::ios::binary);
-    std::vector<uint32_t> buf;
-    // the file is count[type][frame][z][y][x]: for each wave type the owners' frame ranges in turn
-    for (uint64_t t = 0; t < 2 && err.empty(); t++)
-      for (int g = 0; g < gpus && err.empty(); g++) {
-        const uint64_t cnt = (uint64_t)(frames[g + 1] - frames[g]) * fc;
-        buf.resize(cnt);
-        if (cnt && r3d_volume_read_range(engines[g], (t * nf + frames[g]) * fc, cnt, buf.data())) err = r3d_last_error();
-        for (uint32_t v : buf) binned += v;
-        raw.write(reinterpret_cast<const char*>(buf.data()), (std::streamsize)(cnt * sizeof(uint32_t)));
-      }
-    if (err.empty() && !raw) err = "cannot write " + grid.raw_path;
-    if (err.empty()) {
-      std::ofstream hdr(grid.header_path.c_str());
-      const double lo[3] = {grid.desc.origin[0], grid.desc.origin[1], grid.desc.origin[2]};
-      const double hi[3] = {lo[0] + grid.desc.cell_size[0] * grid.desc.dims[0], lo[1] + grid.desc.cell_size[1] * grid.desc.dims[1],
-                            lo[2] + grid.desc.cell_size[2] * grid.desc.dims[2]};
-      OutputScatterGridHeader(grid.desc.dims, grid.desc.n_frames, lo, hi, grid.desc.frame_dt, grid.raw_name, binned, saturated, hdr);
-      std::cout << "|  Scatter-event grid: " << binned << " events binned into " << grid.desc.dims[0] << " x " << grid.desc.dims[1]
-                << " x " << grid.desc.dims[2] << " cells x " << nf << " frames x 2 wave types -> " << grid.raw_path << "\n";
+    // (written under a temporary name and renamed when complete: a failed run leaves no half-written grid behind)
+    const std::string part = grid.raw_path + ".part";
+    std::string err;
+    {
+      std::ofstream raw(part.c_str(), std::ios::binary);
+      std::vector<uint32_t> buf;
+      // the file is count[type][frame][z][y][x]: for each wave type the owners' frame ranges in turn
+      for (uint64_t t = 0; t < 2 && err.empty(); t++)
+        for (int g = 0; g < gpus && err.empty(); g++) {
+          const uint64_t cnt = (uint64_t)(frames[g + 1] - frames[g]) * fc;
+          buf.resize(cnt);
+          if (cnt && r3d_volume_read_range(engines[g], (t * nf + frames[g]) * fc, cnt, buf.data())) err = r3d_last_error();
+          for (uint32_t v : buf) binned += v;
+          raw.write(reinterpret_cast<const char*>(buf.data()), (std::streamsize)(cnt * sizeof(uint32_t)));
+        }
+      if (err.empty() && !raw) err = "cannot write " + part;
     }
+    if (err.empty() && std::rename(part.c_str(), grid.raw_path.c_str())) err = "cannot rename " + part + " to " + grid.raw_path;
     if (!err.empty()) {
-      release();
+      std::remove(part.c_str());
       throw Runtime(err);
     }
+    std::ofstream hdr(grid.header_path.c_str());
+    const double lo[3] = {grid.desc.origin[0], grid.desc.origin[1], grid.desc.origin[2]};
+    const double hi[3] = {lo[0] + grid.desc.cell_size[0] * grid.desc.dims[0], lo[1] + grid.desc.cell_size[1] * grid.desc.dims[1],
+                          lo[2] + grid.desc.cell_size[2] * grid.desc.dims[2]};
+    OutputScatterGridHeader(grid.desc.dims, grid.desc.n_frames, lo, hi, grid.desc.frame_dt, grid.raw_name, binned, saturated, hdr);
+    std::cout << "|  Scatter-event grid: " << binned << " events binned into " << grid.desc.dims[0] << " x " << grid.desc.dims[1]
+              << " x " << grid.desc.dims[2] << " cells x " << nf << " frames x 2 wave types -> " << grid.raw_path << "\n";
   }
-  release();
 }
+
+struct NodeHolder {   // (the node goes with the scope, whichever way it is left)
+  r3d_node* node = nullptr;
+  ~NodeHolder() {
+    if (node) r3d_node_destroy(node);
+  }
+};
 
 }  // namespace
 
@@ -261,13 +252,36 @@ int main(int argc, char* argv[]) {
       Model model(par);
       phase = "during model retrospective output:";
       if (mission.bDumpGrid) model.GetGridRef().DumpGridToAscii();
-      r3d_engine* engine0 = nullptr;
+      // the devices of the run, and -- for a simulation run or tables made in HBM -- the node: one engine per
+      // shard on the devices NAMED (nothing is built on device 0 unless it is one of them)
+      std::vector<int> devices = mission.Devices;
+      if (devices.empty())
+        for (int g = 0; g < std::max(1, mission.Gpus); g++) devices.push_back(g);
+      GridJob grid;
+      if (mission.bRunSim && mission.bScatterGrid) {
+        grid.on = true;
+        for (int k = 0; k < 3; k++) {
+          grid.desc.origin[k] = mission.GridLo[k], grid.desc.dims[k] = mission.GridDims[k];
+          grid.desc.cell_size[k] = (mission.GridHi[k] - mission.GridLo[k]) / mission.GridDims[k];
+        }
+        grid.desc.n_frames = mission.GridFrames;
+        grid.desc.frame_dt = par.PhononTTL / mission.GridFrames;
+        const std::string dir = mission.OutputDir.empty() ? "" : mission.OutputDir + "/";
+        grid.raw_name = mission.ScatterGridFile + ".u32";
+        grid.raw_path = dir + grid.raw_name, grid.header_path = dir + mission.ScatterGridFile + ".octv";
+        check_grid_job(grid, devices.size());
+      }
+      NodeHolder held;
+      if (mission.bRunSim || model.DeviceTables()) {
+        const std::vector<int> on = mission.bRunSim ? devices : std::vector<int>(1, devices[0]);
+        held.node = r3d_node_create(&model.Desc(), on.data(), (int)on.size());
+        if (!held.node) throw Runtime(r3d_last_error());
+      }
       if (model.DeviceTables()) {   // the tables (and so the MFPs the dump prints) are made in HBM
-        engine0 = r3d_engine_create(&model.Desc(), 0);
-        if (!engine0) throw Runtime(r3d_last_error());
+        r3d_engine* e0 = r3d_node_engine(held.node, 0);
         for (int s = 0; s < model.Desc().n_scatterers; s++) {
           double st[8];
-          if (r3d_engine_scatterer_stats(engine0, s, st)) throw Runtime(r3d_last_error());
+          if (r3d_engine_scatterer_stats(e0, s, st)) throw Runtime(r3d_last_error());
           model.SetScattererStats(s, st, st + 2);
         }
       }
@@ -280,29 +294,8 @@ int main(int argc, char* argv[]) {
         std::vector<uint64_t> counts;
         std::vector<r3d_event> events;
         uint64_t dropped = 0;
-        std::vector<int> devices = mission.Devices;
-        if (devices.empty())
-          for (int g = 0; g < std::max(1, mission.Gpus); g++) devices.push_back(g);
-        GridJob grid;
-        if (mission.bScatterGrid) {
-          grid.on = true;
-          for (int k = 0; k < 3; k++) {
-            grid.desc.origin[k] = mission.GridLo[k], grid.desc.dims[k] = mission.GridDims[k];
-            grid.desc.cell_size[k] = (mission.GridHi[k] - mission.GridLo[k]) / mission.GridDims[k];
-          }
-          grid.desc.n_frames = mission.GridFrames;
-          grid.desc.frame_dt = par.PhononTTL / mission.GridFrames;
-          const std::string dir = mission.OutputDir.empty() ? "" : mission.OutputDir + "/";
-          grid.raw_name = mission.ScatterGridFile + ".u32";
-          grid.raw_path = dir + grid.raw_name, grid.header_path = dir + mission.ScatterGridFile + ".octv";
-        }
-        if (engine0 && devices[0] != 0) {   // (the tables were made on device 0 for the scatterer dump; the run wants another)
-          r3d_engine_destroy(engine0);
-          engine0 = nullptr;
-        }
-        run_simulation(model, (uint64_t)std::max(0L, par.NumPhonons), mission.Seed, devices, res, energy, counts,
-                       report_mask, events, dropped, engine0, grid);
-        engine0 = nullptr;   // (destroyed by its shard)
+        run_simulation(model, (uint64_t)std::max(0L, par.NumPhonons), mission.Seed, held.node, res, energy, counts,
+                       report_mask, events, dropped, grid);
         if (report_mask) {   // the reference writes them as they happen: stdout, or --report-file
           if (mission.ReportFile.empty()) {
             OutputReports(events.data(), events.size(), std::cout);
@@ -320,7 +313,6 @@ int main(int argc, char* argv[]) {
         std::ofstream trace("seis_traces_asc.dat");
         OutputPostSimSummary(model, res, mission.OutputDir, std::cout, trace);
       }
-      if (engine0) r3d_engine_destroy(engine0);
     }
   } catch (std::exception& e) {
     std::cout << "**\n** Error " << phase << "\n** What: " << e.what() << "\n** Exiting...\n";

@@ -227,6 +227,46 @@ def run_model(model, n, first_id=0, seed=0x5EED, n_gpus=1, devices=None):
     return res
 
 
+class Node:
+    """r3d_node_*: one engine per entry of `devices`, kept across runs; a run shards the id range over them
+    and sums the shards' blocks on the devices (RCCL ncclReduce to devices[0]; on the host when two shards
+    share a device -- `reduction` says which)."""
+
+    def __init__(self, model, devices, lib=None):
+        self.model = model
+        self._lib = _ffi.hip_lib(path=lib)
+        devs = (C.c_int * len(devices))(*devices)
+        self._n = self._lib.r3d_node_create(model.desc_p, devs, len(devices))
+        if not self._n:
+            raise RuntimeError("r3d_node_create failed: " + self._lib.r3d_last_error().decode())
+
+    @property
+    def reduction(self):
+        return self._lib.r3d_node_reduction(self._n).decode()
+
+    def __len__(self):
+        return self._lib.r3d_node_size(self._n)
+
+    def run(self, n, first_id=0, seed=0x5EED, result=None):
+        res = result if result is not None else self.model.new_result()
+        c = res._as_c()
+        if self._lib.r3d_node_run(self._n, n, first_id, seed, C.byref(c)):
+            raise RuntimeError("r3d_node_run failed: " + self._lib.r3d_last_error().decode())
+        res._from_c(c)
+        return res
+
+    def close(self):
+        if self._n:
+            self._lib.r3d_node_destroy(self._n)
+            self._n = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def reduce_volumes_by_frame(engines):
     """r3d_volume_reduce_by_frame: the grids of several engines of ONE process (one per shard of a job, each
     with its own grid of the same shape, on any devices) added by frame; engine g ends with the job's counts

@@ -577,6 +577,38 @@ def test_run_model_on_three_engines_on_one_device(engines):
         run_model(e.model, 100, devices=[])
 
 
+def test_node_sums_the_shards_on_the_device_through_rccl(engines):
+    """r3d_node_*: the product's own RCCL reduce (north_star: "an RCCL reduce over xGMI of the per-receiver
+    energy-envelope histograms at the end"; semantics combine.m:26-33).  A node on the box's one GPU goes
+    through ncclCommInitAll / ncclReduce (a one-rank communicator) and equals Engine.run and the oracle; a
+    node whose shards share the device takes the host sum; both equal each other (counts exactly, energies
+    to summation order); a node is reusable -- a second run adds into the caller's block without rebuilding
+    tables; a failing run leaves *out untouched."""
+    from radiative3d_amd import Node
+    e = engines("crustpinch")
+    n = 6001
+    want = e.run(n, first_id=5, seed=77)
+    one = Node(e.model, [0])
+    assert one.reduction == "rccl" and len(one) == 1
+    got = one.run(n, first_id=5, seed=77)
+    assert (got.counts == want.counts).all() and got.events == want.events
+    assert (got.n_lost, got.n_timeout, got.n_invalid) == (want.n_lost, want.n_timeout, want.n_invalid)
+    assert np.allclose(got.energy, want.energy, rtol=1e-12, atol=1e-300)
+    assert_result_equals_oracle(got, O.run(e.model, n, 5, 77), "r3d_node_run over RCCL")
+    three = Node(e.model, [0, 0, 0])
+    assert three.reduction == "host" and len(three) == 3
+    host = three.run(n, first_id=5, seed=77)
+    assert (host.counts == got.counts).all() and host.events == got.events
+    assert np.allclose(host.energy, got.energy, rtol=1e-12, atol=1e-300)
+    # the same node again: its result is ADDED to what the caller's block holds
+    again = one.run(n, first_id=5, seed=77, result=got)
+    assert again is got and (got.counts == 2 * want.counts).all() and got.events["generated"] == 2 * n
+    assert np.allclose(got.energy, 2 * want.energy, rtol=1e-12, atol=1e-300)
+    one.close(), three.close()
+    with pytest.raises(RuntimeError, match=r"shard 1 \(device 99\): device index out of range"):
+        Node(e.model, [0, 99])
+
+
 def test_run_device_rejects_unknown_carry_words_and_keeps_launch_ids_in_step(engines):
     e = engines("halfspace")
     buf = DeviceResult(e.model, "cuda:0")

@@ -117,6 +117,7 @@ def test_main_cli_end_to_end_on_gpu(tmp_path):
     lost = int(re.search(r"Loss surfaces:\s+(\d+)", run.stdout).group(1))
     tmo = int(re.search(r"Timeout:\s+(\d+)", run.stdout).group(1))
     assert lost + tmo == 200000
+    assert "|  Shards: 1 (summed by rccl)" in run.stdout     # the product's own reduce: r3d_node_run, ncclReduce
     m = Model(halfspace(4))
     want = O.run(m, 200000, seed=7)
     assert (lost, tmo) == (want.n_lost, want.n_timeout)
@@ -222,5 +223,13 @@ def test_main_cli_writes_the_scatter_grid_of_a_video_run_on_gpu(tmp_path):
     assert (got == want).all() and int(hdr["GridEventsBinned"]) == int(want.sum()) > 100000
     assert int(hdr["GridSaturatedCells"]) == 0
     assert f"{int(want.sum())} events binned" in run.stdout
+    assert "|  Shards: 3 (summed by host)" in run.stdout     # (three shards on ONE device: RCCL refuses that communicator)
     lost = int(re.search(r"Loss surfaces:\s+(\d+)", run.stdout).group(1))
     assert lost == res.n_lost
+    assert not os.path.exists(tmp_path / "grid.u32.part")
+    # a grid that the shards could not add up is refused BEFORE the run, and nothing is left behind
+    big = subprocess.run([MAIN] + crustpinch_vids(4) + ["--num-phonons=1000", f"--output-dir={tmp_path}", "--host-tables", "--devices=0,0",
+                          "--scatter-grid=1024,1024,64,64," + ",".join(str(v) for v in lo + hi), "--scatter-grid-file=big"],
+                         capture_output=True, text=True, cwd=tmp_path)
+    assert big.returncode == 1 and "do not fit the 32-bit cell" in big.stdout and "__BEGINNING_SIMULATION__" not in big.stdout
+    assert not os.path.exists(tmp_path / "big.u32") and not os.path.exists(tmp_path / "big.u32.part")
