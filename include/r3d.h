@@ -183,6 +183,8 @@ enum {
   R3D_EV_REFLECT,       /* REF (free surface + interface reflections)       */
   R3D_EV_TRANSFER,      /* CEL */
   R3D_EV_RTSOLVE,       /* Refraction_FullRT calls                          */
+  R3D_EV_VOLUME_OUT,    /* SCT / REF events that fell outside an attached event grid (r3d_engine_set_volume): with
+                           a grid attached, the grid's total = SCATTER + REFLECT - VOLUME_OUT, exactly            */
   R3D_EV_NUM
 };
 

@@ -179,6 +179,7 @@ struct TravelRec {  // media.hpp:94-119
 // vis/scattervid/preprocess.sh:17-29, scattervid_above.m:111), in model coordinates.
 const r3d_volume_desc* g_vol_desc = nullptr;
 uint32_t* g_vol = nullptr;
+uint64_t g_vol_outside = 0;   // events that fell outside the attached grid (r3d_result.events[R3D_EV_VOLUME_OUT])
 void volume_count(double t, V loc, int type) {
   if (!g_vol) return;
   const r3d_volume_desc& v = *g_vol_desc;
@@ -187,8 +188,10 @@ void volume_count(double t, V loc, int type) {
   double y = (loc.y - v.origin[1]) * (1.0 / v.cell_size[1]);
   double z = (loc.z - v.origin[2]) * (1.0 / v.cell_size[2]);
   if (!(f >= 0 && x >= 0 && y >= 0 && z >= 0 && f < v.n_frames && x < v.dims[0] && y < v.dims[1] &&
-        z < v.dims[2]))
+        z < v.dims[2])) {
+    g_vol_outside++;
     return;
+  }
   size_t idx = ((((size_t)type * v.n_frames + (size_t)f) * v.dims[2] + (size_t)z) * v.dims[1] + (size_t)y) *
                    v.dims[0] + (size_t)x;
   g_vol[idx] += 1;
@@ -1003,6 +1006,7 @@ int r3d_oracle_run(const r3d_model_desc* model, uint64_t n, uint64_t first_id, u
   Ctx c;
   c.m = model;
   c.out = out;
+  g_vol_outside = 0;
   for (uint64_t i = 0; i < n; i++) {
     oracle_rng_init(&c.rng, seed, first_id + i);
     c.id = first_id + i;
@@ -1022,6 +1026,7 @@ int r3d_oracle_run(const r3d_model_desc* model, uint64_t n, uint64_t first_id, u
       f.n_catch = (uint16_t)(c.n_catch > 65535 ? 65535 : c.n_catch);
     }
   }
+  out->events[R3D_EV_VOLUME_OUT] += g_vol_outside;
   return 0;
 }
 

@@ -15,7 +15,7 @@ R3D_CELL_CYLINDER, R3D_CELL_TETRA, R3D_CELL_SPHERESHELL = 0, 1, 2
 R3D_FACE_COLLECT, R3D_FACE_REFLECT, R3D_FACE_ADJOIN, R3D_FACE_DISCON = 1, 2, 4, 8
 R3D_INV_NUM = 7
 R3D_EV_NAMES = ("generated", "iterations", "scatter", "collect", "catch", "reflect",
-                "transfer", "rtsolve")
+                "transfer", "rtsolve", "volume_out")
 R3D_EV_NUM = len(R3D_EV_NAMES)
 R3D_N_ENERGY, R3D_N_COUNT = 5, 2
 R3D_N_SCALARS = 3 + R3D_INV_NUM + R3D_EV_NUM

@@ -638,6 +638,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
     else dest = Q_FREE;
     // the batch's event counts (wave-uniform; scalar registers), added to the block's tallies together below
     uint32_t n_iter = 0, n_transfer = 0, n_reflect = 0, n_generated = 0, n_collect = 0, n_catch = 0;
+    uint32_t n_volout = 0;   // (video runs: events outside the attached grid)
     n_lost = 0, n_timeout = 0;
 
 #ifndef R3D_PRIO_NARROW
@@ -741,7 +742,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         Pending ev;
         ev.vel = 0.0, ev.face = -1, ev.flags = 0u, ev.nbr = -1;
         bool leaving = false;
-        LaneStats st = {0, 0, 0, 0, 0, 0, 0};
+        LaneStats st = {0, 0, 0, 0, 0, 0, 0, 0};
         if (live) {
           fate = step_move<KIND>(a, T, p, rng, st, &reason, ev);
           leaving = true;
@@ -766,6 +767,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
           report(st.transfer != 0u, 4, p, hid);   // CEL
         }
         n_iter += count(st.iterations != 0u), n_transfer += count(st.transfer != 0u), n_reflect += count(st.reflect != 0u);
+        if (a.vol) n_volout += count(st.vol_out != 0u);
         live = light;
         const unsigned n_live = (unsigned)__popcll(ballot(live));
         // a full batch goes on while most of its lanes can (the others' slots are wanted by the
@@ -843,13 +845,14 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         }
       }
       const bool light = act && dest == Q_MOVE;
-      LaneStats st = {0, 0, 0, 0, 0, 0, 0};
+      LaneStats st = {0, 0, 0, 0, 0, 0, 0, 0};
       if (light) step_event<KIND, EV_BEND>(a, T, p, rng, st, ev, (int)nbr);
       if (TRACE) {
         report(st.reflect != 0u, 2, p, hid);    // REF
         report(st.transfer != 0u, 4, p, hid);   // CEL
       }
       n_transfer += count(st.transfer != 0u), n_reflect += count(st.reflect != 0u);
+      if (a.vol) n_volout += count(st.vol_out != 0u);
       if (act) {
         const uint32_t m2 = died ? meta_pack(0, -1, 0u, Q_FREE)
                                  : meta_pack(p.type, light ? -1 : ev.face, light ? 0u : ev.flags, dest);
@@ -865,7 +868,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       Rng rng;
       uint32_t meta = 0, nbr = 0;
       uint64_t hid = 0;
-      LaneStats st = {0, 0, 0, 0, 0, 0, 0};
+      LaneStats st = {0, 0, 0, 0, 0, 0, 0, 0};
       if (act) {
         load_state(id, p, rng, meta, nbr);
 #ifndef R3D_PRIO_NARROW
@@ -905,11 +908,13 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         report(st.transfer != 0u, 4, p, hid);       // CEL
       }
       if (q == Q_RT) n_transfer += count(st.transfer != 0u), n_reflect += count(st.reflect != 0u);
+      if (a.vol) n_volout += count(st.vol_out != 0u);
     }
     if constexpr (!kVectorTally) {
       if (q == Q_SCATTER) tally_n(kEv + R3D_EV_SCATTER, k);
       tally_n(kEv + R3D_EV_ITERATIONS, n_iter), tally_n(kEv + R3D_EV_TRANSFER, n_transfer);
       tally_n(kEv + R3D_EV_REFLECT, n_reflect);
+      tally_n(kEv + R3D_EV_VOLUME_OUT, n_volout);
       if (q == Q_RT) tally_n(kEv + R3D_EV_RTSOLVE, k);
     } else {
       // lane j holds what the batch adds to tally j (include/r3d.h: lost, timeout, invalid + reasons, the
@@ -930,6 +935,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       R3D_PUT(kEv + R3D_EV_COLLECT, n_collect);
       R3D_PUT(kEv + R3D_EV_CATCH, n_catch);
       R3D_PUT(kEv + R3D_EV_REFLECT, n_reflect);
+      R3D_PUT(kEv + R3D_EV_VOLUME_OUT, n_volout);
       R3D_PUT(kEv + R3D_EV_TRANSFER, n_transfer);
       R3D_PUT(kEv + R3D_EV_RTSOLVE, q == Q_RT ? k : 0u);
 #undef R3D_PUT

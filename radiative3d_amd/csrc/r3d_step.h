@@ -55,6 +55,7 @@ template <> struct CellOf<CELL_SPH> { using type = CellSph; };
 // Per-lane event tallies (reported through r3d_result.events).
 struct LaneStats {
   uint32_t iterations, scatter, collect, n_catch, reflect, transfer, rtsolve;
+  uint32_t vol_out;   // SCT / REF events outside an attached event grid (r3d_result.events[R3D_EV_VOLUME_OUT])
 };
 
 // Where the step finds its tables (pointers may be LDS or HBM).
@@ -222,15 +223,17 @@ R3D_HD void collect(const KArgs& a, const Tables<KIND>& T, const Phonon& p, doub
 // One count per SCT / REF event, binned by resulting wave type, frame
 // floor(t / dt) and model-space cell: the histogram the reference's video
 // scripts build from its per-event text stream.
-R3D_HD void volume_count(const KArgs& a, const Phonon& p) {
+R3D_HD void volume_count(const KArgs& a, const Phonon& p, LaneStats& st) {
   if (!a.vol) return;
   const double f = p.t * a.vol_inv_dt;
   const double x = (p.loc.x - a.vol_origin[0]) * a.vol_inv_cell[0];
   const double y = (p.loc.y - a.vol_origin[1]) * a.vol_inv_cell[1];
   const double z = (p.loc.z - a.vol_origin[2]) * a.vol_inv_cell[2];
   if (!(f >= 0 && x >= 0 && y >= 0 && z >= 0 && f < a.vol_frames_f && x < a.vol_dim_f[0] &&
-        y < a.vol_dim_f[1] && z < a.vol_dim_f[2]))
+        y < a.vol_dim_f[1] && z < a.vol_dim_f[2])) {
+    st.vol_out++;
     return;
+  }
   const size_t idx = ((((size_t)p.type * a.vol_frames + (size_t)f) * a.vol_dim[2] + (size_t)z) *
                           a.vol_dim[1] + (size_t)y) * a.vol_dim[0] + (size_t)x;
   R3D_ADD_U32(a.vol + idx, 1u);
@@ -464,7 +467,7 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
       }
       scatter_transform(p, a.toa_dir + 4 * k, rc, rs, (conv & 1) ? RAY_S : RAY_P);
     }
-    volume_count(a, p);   // SCT
+    volume_count(a, p, st);   // SCT
     return FATE_ALIVE;
   }
   if (PART == EV_SCATTER) return FATE_ALIVE;   // (not reached)
@@ -517,7 +520,7 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
     p.cell = nbr, st.transfer++;
   } else {
     st.reflect++;
-    volume_count(a, p);   // REF
+    volume_count(a, p, st);   // REF
   }
   return FATE_ALIVE;
 }
@@ -550,7 +553,7 @@ R3D_HD void rt_event_apply(const KArgs& a, const Tables<KIND>& T, Phonon& p, Lan
     p.cell = nbr, st.transfer++;
   } else {
     st.reflect++;
-    volume_count(a, p);   // REF
+    volume_count(a, p, st);   // REF
   }
 }
 

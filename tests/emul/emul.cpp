@@ -31,7 +31,7 @@ static void run_kind(const KArgs& a, uint64_t n, uint64_t first_id, uint64_t see
   for (uint64_t i = 0; i < n; i++) {
     Phonon p;
     Rng rng;
-    LaneStats st = {0, 0, 0, 0, 0, 0, 0};
+    LaneStats st = {0, 0, 0, 0, 0, 0, 0, 0};
     rng_init(rng, first_id + i);
     spray(a, p, rng);
     out->events[R3D_EV_GENERATED]++;
@@ -48,6 +48,7 @@ static void run_kind(const KArgs& a, uint64_t n, uint64_t first_id, uint64_t see
     out->events[R3D_EV_REFLECT] += st.reflect;
     out->events[R3D_EV_TRANSFER] += st.transfer;
     out->events[R3D_EV_RTSOLVE] += st.rtsolve;
+    out->events[R3D_EV_VOLUME_OUT] += st.vol_out;
     if (finals) {
       r3d_final& f = finals[i];
       std::memset(&f, 0, sizeof f);

@@ -303,6 +303,38 @@ def reference_event_mix(e, name, whole, n):
         assert abs(whole.events[k] / n - v) <= tol, (k, whole.events[k] / n, v, tol)
 
 
+def test_full_size_halfspace_one_receiver():
+    """BASELINE config 1 at full size: do-halfspace.sh's arguments (reference do-halfspace.sh:41-101) at TOA
+    degree 9 with ONE receiver, as BASELINE.json names it.  The literal job -- 1e5 histories, one self-contained
+    launch -- and a 1e7-history run for the size-independent properties (every history ends, the receiver's
+    books close, X + Y + Z == P + S), the survey's event mix of the unmodified reference at its own
+    Monte-Carlo error, and 3 000 histories of the degree-9 engine against the oracle, history by history on
+    the diagnostic kernel and bin by bin on the production, chain-step and drain kernels."""
+    m = Model(halfspace(9, one_receiver=True))
+    assert m.n_toa == 20 * 4 ** 9 and m.n_seismometers == 1
+    e = Engine(m)
+    job = e.run(100_000, first_id=(7 << 40))                      # the job as stated
+    assert job.n_lost + job.n_timeout + job.n_invalid == 100_000 and job.events["generated"] == 100_000
+    assert job.n_invalid == 0 and int(job.counts.sum()) == job.events["catch"]
+    n = 10_000_000
+    a = e.run(n)
+    assert a.n_lost + a.n_timeout + a.n_invalid == n and a.events["generated"] == n and a.n_invalid == 0
+    assert int(a.counts.sum()) == a.events["catch"] > 0
+    assert np.allclose(a.energy[:, :, :3].sum(-1), a.energy[:, :, 3:].sum(-1), rtol=1e-10, atol=1e-300)
+    # the literal job is a sample of the same population: its event rates sit within 5 sigma of the big run's
+    for k in ("iterations", "transfer", "reflect", "scatter", "collect"):
+        rate, small = a.events[k] / n, job.events[k] / 100_000
+        assert abs(small - rate) < 5 * np.sqrt(max(rate, 1e-9) * 4 / 100_000) + 1e-3, (k, small, rate)
+    reference_event_mix(e, "halfspace", a, n)
+    # the one receiver catches a few histories in a million: an independent half catches a compatible number
+    b = e.run(n, first_id=n)
+    ca, cb = a.events["catch"], b.events["catch"]
+    assert abs(ca - cb) < 6 * np.sqrt(ca + cb) + 10, (ca, cb)
+    check_against_oracle(e, 3000, first_id=31415926, allow_frac=0.0005)
+    check_production_against_oracle(e, 3000, first_id=31415926)
+    e.close()
+
+
 def test_full_size_lopnor_properties():
     """BASELINE config 3 at its full table size (TOA degree 9: 21 scatterers, 4.4 GB of tables;
     explosion source), 1e7 histories: size-independent properties, the survey's event mix, and a

@@ -20,9 +20,14 @@ def test_oracle_histogram_accounts_for_every_event_in_range(models):
     n = 3000
     big = volume_desc((-5000, -5000, -1000), (10000, 10000, 2000), (1, 1, 1), 1, 1e9)  # one all-embracing cell
     res, vol = O.run_with_volume(m, n, big)
-    assert int(vol.sum()) == res.events["scatter"] + res.events["reflect"]
+    assert int(vol.sum()) == res.events["scatter"] + res.events["reflect"] and res.events["volume_out"] == 0
     # 7.2 SCT + 2.8 REF ~ 10 grid increments per history with these overrides
     assert vol.sum() / n == pytest.approx(10.0, rel=0.15)
+    # a grid that does not hold everything: what falls outside is counted, so the books close exactly
+    res, vol = O.run_with_volume(m, n, volume_desc(**GRID))
+    assert res.events["volume_out"] > 0
+    assert int(vol.sum()) == res.events["scatter"] + res.events["reflect"] - res.events["volume_out"]
+    assert O.run(m, n).events["volume_out"] == 0          # no grid attached: nothing to fall outside of
 
 
 def test_kernel_code_fills_the_same_histogram_as_the_oracle(models):
@@ -30,7 +35,8 @@ def test_kernel_code_fills_the_same_histogram_as_the_oracle(models):
     v = volume_desc(**GRID)
     ro, vo = O.run_with_volume(m, 2500, v)
     re, ve = E.run_with_volume(m, 2500, v)
-    assert ro.events == re.events
+    assert ro.events == re.events and re.events["volume_out"] > 0
+    assert int(ve.sum()) == re.events["scatter"] + re.events["reflect"] - re.events["volume_out"]
     assert vo.sum() > 10000 and (vo == ve).all()
     assert vo[0].sum() > 0 and vo[1].sum() > 0            # both wave types present
     # the wavefront expands: the first frames occupy more and more cells
@@ -51,6 +57,7 @@ def test_engine_histogram_matches_oracle_and_accumulates(models):
     vg = e.read_volume()
     assert rg.events == ro.events
     assert (vg == vo).all()                               # integer work: bit-exact
+    assert int(vg.sum()) == rg.events["scatter"] + rg.events["reflect"] - rg.events["volume_out"] and rg.events["volume_out"] > 0
     e.run(n, first_id=n)                                  # a second shard accumulates on top
     _, vo2 = O.run_with_volume(m, n, v, first_id=n)
     assert (e.read_volume(reset=True) == vo + vo2).all()
@@ -58,19 +65,46 @@ def test_engine_histogram_matches_oracle_and_accumulates(models):
 
 
 @pytest.mark.gpu
-def test_dense_volume_grid_at_scale(models):
-    """Config 5 flavour: a dense grid (2 x 300 x 64 x 256 x 256 uint32 = 10 GB) under 1e7 histories."""
-    from radiative3d_amd import Engine
-    m = models("crustpinch", 6, VIDEO)
+def test_full_size_crustpinch_video_run_with_the_10_gb_grid():
+    """BASELINE config 5 at full size: do-crustpinch-vids.sh's arguments at TOA degree 9 (reference
+    do-crustpinch-vids.sh:22-72), the bench's dense grid (2 x 300 x 64 x 256 x 256 uint32 = 10 GB,
+    radiative3d_amd/configs.py CRUSTPINCH_VOLUME), 1e7 histories through the production kernel: every history
+    ends, the receivers' books close, and the GRID's books close exactly -- its total is the SCT + REF events
+    minus the ones counted as falling outside it (r3d_result.events[R3D_EV_VOLUME_OUT]).  Then, on the same
+    degree-9 engine and the same grid, 3 000 histories against the oracle: the grid cell for cell, the bins, the
+    counters, and the histories one by one (diagnostic and production kernels)."""
+    from radiative3d_amd import Engine, Model
+    from radiative3d_amd.configs import CRUSTPINCH_VOLUME, crustpinch_vids
+    from test_gpu_parity import check_against_oracle, check_production_against_oracle
+    m = Model(crustpinch_vids(9))
+    assert m.n_toa == 20 * 4 ** 9
     e = Engine(m)
-    e.set_volume(origin=(-300.0, -900.0, -400.0), cell_size=(6.0, 7.5, 6.5), dims=(256, 256, 64),
-                 n_frames=300, frame_dt=350.0 / 300)
+    e.set_volume(**CRUSTPINCH_VOLUME)
     n = 10_000_000
     r = e.run(n)
-    vol = e.read_volume()
-    assert r.n_lost + r.n_timeout + r.n_invalid == n
+    assert r.n_lost + r.n_timeout + r.n_invalid == n and r.events["generated"] == n and r.n_invalid == 0
+    assert int(r.counts.sum()) == r.events["catch"]
+    assert np.allclose(r.energy[:, :, :3].sum(-1), r.energy[:, :, 3:].sum(-1), rtol=1e-10, atol=1e-300)
+    vol = e.read_volume(reset=True)
+    assert vol.nbytes == 2 * 300 * 64 * 256 * 256 * 4 > 10e9
     total = int(vol.sum(dtype=np.uint64))
-    assert 0.8 * (r.events["scatter"] + r.events["reflect"]) < total <= r.events["scatter"] + r.events["reflect"]
+    assert total == r.events["scatter"] + r.events["reflect"] - r.events["volume_out"], (total, r.events)
+    assert r.events["scatter"] / n > 5 and total > 0.9 * (r.events["scatter"] + r.events["reflect"])
+    del vol
+    # 3 000 histories against the oracle, grid included (the oracle's 10 GB array is touched in ~30 000 places)
+    k, first = 3000, 777_000_000
+    rg = e.run(k, first_id=first)
+    ro, vo = O.run_with_volume(m, k, volume_desc(**CRUSTPINCH_VOLUME), first_id=first)
+    assert rg.events == ro.events and (rg.counts == ro.counts).all()
+    vg = e.read_volume(reset=True).reshape(-1)
+    vo = vo.reshape(-1)
+    ig, io = np.flatnonzero(vg), np.flatnonzero(vo)
+    assert ig.size == io.size > 15000 and (ig == io).all() and (vg[ig] == vo[io]).all()
+    assert int(vg[ig].sum()) == rg.events["scatter"] + rg.events["reflect"] - rg.events["volume_out"]
+    del vg, vo
+    check_against_oracle(e, 3000, first_id=first, allow_frac=0.0005)
+    check_production_against_oracle(e, 3000, first_id=first)
+    e.close()
 
 
 @pytest.mark.gpu
