@@ -345,6 +345,19 @@ int r3d_run_device_carry(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t 
 int r3d_run_traced(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,
                    r3d_result* out, r3d_final* finals);
 
+/* The same records out of the PRODUCTION kernels -- the code objects r3d_run, r3d_run_device,
+ * r3d_run_device_carry and a chain's flush launch, i.e. the ones that are timed (r3d_run_traced runs the
+ * diagnostic kernel, another compilation).  r3d_engine_set_production_finals attaches an engine-owned buffer of
+ * `capacity` records: from then on a history with base_id <= id < base_id + capacity leaves its final record
+ * where it ends, in whichever launch of a chain that is (capacity 0 detaches); while a buffer is attached a
+ * launch whose ids it does not cover is refused, and a buffer cannot be attached or detached while histories
+ * are carried over.  r3d_production_finals_read
+ * copies records [first, first + count) to the host (waits for the engine's launches).  A record never
+ * written has fate 255; n_catch is 0xFFFF in all of them (only the diagnostic kernel counts catches per
+ * history).  Costs a run without a buffer one scalar test per batch in which a history ends.           */
+int r3d_engine_set_production_finals(r3d_engine* e, uint64_t base_id, uint64_t capacity);
+int r3d_production_finals_read(r3d_engine* e, r3d_final* out, uint64_t first, uint64_t count);
+
 /* ---- optional volumetric scatter-event grid ---------------------------------
  * The reference's "scattervid" data are one text line per SCT / REF event
  * (dataout.cpp:484-520, 570-577), cut down to (t, x, y, z) per resulting wave

@@ -19,6 +19,19 @@ def finals_differ(a, b, rtol=1e-9):
             or abs(a.amp - b.amp) > rtol)
 
 
+def production_finals_differ(a, b, rtol=1e-9):
+    """The production kernels' records (r3d_engine_set_production_finals) carry no catch count (0xFFFF): every
+    other field as finals_differ holds it, and position and direction as well -- those to 100 rtol: a direction
+    is the end of a chain of rotations (SphereEarth: 90 scatterings and 170 arcs per history), through which the
+    last bits of each travel where a time or a path length only adds them up."""
+    import copy
+    a2 = copy.copy(a)
+    a2.n_catch = b.n_catch
+    return (finals_differ(a2, b, rtol)
+            or any(abs(x - y) > 100 * rtol * max(1.0, abs(y)) for x, y in zip(a.loc, b.loc))
+            or any(abs(x - y) > 100 * rtol for x, y in zip(a.dir, b.dir)))
+
+
 def forked_ids(finals_engine, finals_oracle, first_id, rtol=1e-9):
     """Ids of the histories whose final records differ between engine and oracle."""
     return [first_id + i for i, (a, b) in enumerate(zip(finals_engine, finals_oracle)) if finals_differ(a, b, rtol)]

@@ -256,6 +256,10 @@ def hip_lib(reproducible=False, path=None):
         L.r3d_engine_carry_pending.argtypes = [C.c_void_p]
         L.r3d_engine_set_volume_buffer.restype = C.c_int
         L.r3d_engine_set_volume_buffer.argtypes = [C.c_void_p, C.POINTER(VolumeDesc), C.c_void_p]
+        L.r3d_engine_set_production_finals.restype = C.c_int
+        L.r3d_engine_set_production_finals.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.r3d_production_finals_read.restype = C.c_int
+        L.r3d_production_finals_read.argtypes = [C.c_void_p, C.POINTER(Final), C.c_uint64, C.c_uint64]
         L.r3d_node_create.restype = C.c_void_p
         L.r3d_node_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(C.c_int), C.c_int]
         L.r3d_node_run.restype = C.c_int

@@ -122,6 +122,8 @@ struct r3d_engine {
   void* volume_ext = nullptr;   // caller-owned counters (r3d_engine_set_volume_buffer)
   size_t volume_len = 0;
   std::unique_ptr<DevBuf> d_evlog, d_evlog_count;
+  std::unique_ptr<DevBuf> d_pfinals;   // final records out of the production kernels (r3d_engine_set_production_finals)
+  uint64_t pfinals_base = 0, pfinals_cap = 0;   // ... of the histories base <= id < base + cap
   struct ScatStats {
     double mfp[2], dipole[2], total[4];
   };
@@ -563,6 +565,8 @@ static int enqueue(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, 
   a.scalars = reinterpret_cast<unsigned long long*>(d_scalars);
   a.finals = d_finals;
   a.carry_in = a.carry_out = nullptr;
+  if (a.pfinals && n && (first_id < e->pfinals_base || first_id - e->pfinals_base > e->pfinals_cap || n > e->pfinals_cap - (first_id - e->pfinals_base)))
+    return g_error = "the production finals buffer does not cover this launch's ids (r3d_engine_set_production_finals)", 1;
   bool must_launch = n > 0;
   bool pending_after = e->carry_pending;
   if (carry) {
@@ -941,6 +945,40 @@ int r3d_engine_set_event_log(r3d_engine* e, uint32_t mask, uint64_t capacity) {
   a.evlog = buf->p, a.evlog_count = reinterpret_cast<unsigned long long*>(cnt->p);
   a.evlog_cap = capacity, a.evlog_mask = mask & R3D_RPT_ALL;
   e->d_evlog = std::move(buf), e->d_evlog_count = std::move(cnt);
+  return 0;
+}
+
+int r3d_engine_set_production_finals(r3d_engine* e, uint64_t base_id, uint64_t capacity) {
+  const int fail_value = 1;
+  if (!e) return g_error = "null engine", 1;
+  R3D_ON_DEVICE(e->device);
+  R3D_HIP_OK(hipDeviceSynchronize());   // (launches that write into the old buffer)
+  if (e->carry_pending) return g_error = "r3d_engine_set_production_finals: histories are carried over from a launch made under the old setting (close the chain first)", 1;
+  KArgs& a = e->args;
+  a.pfinals = nullptr, e->pfinals_base = 0, e->pfinals_cap = 0;
+  e->d_pfinals.reset();
+  if (capacity == 0) return 0;
+  auto buf = std::make_unique<DevBuf>();
+  R3D_HIP_OK(buf->alloc_zero(capacity * sizeof(r3d_final)));
+  R3D_HIP_OK(hipMemset(buf->p, 0xFF, capacity * sizeof(r3d_final)));   // (fate 255: no record written)
+  // (the kernel indexes by the history id itself: the address less base_id records)
+  a.pfinals = reinterpret_cast<void*>(reinterpret_cast<uintptr_t>(buf->p) - (uintptr_t)base_id * sizeof(r3d_final));
+  e->pfinals_base = base_id, e->pfinals_cap = capacity;
+  e->d_pfinals = std::move(buf);
+  return 0;
+}
+
+int r3d_production_finals_read(r3d_engine* e, r3d_final* out, uint64_t first, uint64_t count) {
+  const int fail_value = 1;
+  if (!e || !e->d_pfinals) return g_error = "no production finals attached", 1;
+  if (first > e->pfinals_cap || count > e->pfinals_cap - first) return g_error = "r3d_production_finals_read: range beyond the buffer", 1;
+  if (count == 0) return 0;
+  if (!out) return g_error = "null output", 1;
+  R3D_ON_DEVICE(e->device);
+  R3D_HIP_OK(hipDeviceSynchronize());
+  R3D_HIP_OK(hipMemcpy(out, reinterpret_cast<const r3d_final*>(e->d_pfinals->p) + first, count * sizeof(r3d_final), hipMemcpyDeviceToHost));
+  for (uint64_t i = 0; i < count; i++)
+    if (out[i].fate != 255) out[i].amp = std::exp(out[i].amp);   // (the kernel left ln(amplitude): r3d_pool.h finish)
   return 0;
 }
 

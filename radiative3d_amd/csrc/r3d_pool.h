@@ -318,6 +318,11 @@ constexpr uint32_t kTailBatch = R3D_POOL_TAIL_BATCH, kTailServers = 2;
 constexpr int kKeepersWord = 7;   // PoolCtl::word[kKeepersWord]: waves that keep lanes at the moment
 // A refill starts kRefillBatches batches of histories at a time, their table fetches set going together (the
 // FREE phase below); the FREE queue counts as full for the scheduler at kRefillFull entries.
+// Final records out of the production kernels when a buffer is attached (include/r3d.h
+// r3d_engine_set_production_finals); 0 compiles the code out (developer builds: what it costs).
+#ifndef R3D_PRODUCTION_FINALS
+#define R3D_PRODUCTION_FINALS 1
+#endif
 #ifndef R3D_TET_REFILL_PAIRS
 #define R3D_TET_REFILL_PAIRS 0
 #endif
@@ -490,7 +495,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   // spare for that, adds them one by one where they arise (the vector form there: +0.8 %).
   constexpr bool kVectorTally = KIND != CELL_TET || R3D_TET_VECTOR_TALLY;
   uint32_t n_lost = 0, n_timeout = 0;   // (per batch, like the event counts: reset where a batch starts)
-  auto finish = [&](bool died, int fate, int reason, const Phonon& p, uint64_t hid, uint32_t catches) {
+  auto finish = [&](bool died, int fate, int reason, const Phonon& p, uint64_t hid, uint32_t catches, unsigned slot) {
     if (!any_lane(died)) return;
     if constexpr (kVectorTally) {
       n_lost += count(died && fate == FATE_LOST), n_timeout += count(died && fate == FATE_TIMEOUT);
@@ -502,6 +507,29 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       tally(died && fate == FATE_INVALID, 2);
 #pragma unroll
       for (int r = 0; r < R3D_INV_NUM; r++) tally(died && fate == FATE_INVALID && reason == r, 3 + r);
+    }
+    if (!TRACE && TAIL && R3D_PRODUCTION_FINALS) {
+      // (the production kernels' own witness, when a buffer is attached: everything but the catch count, which
+      //  only the diagnostic kernel keeps per history.  In the self-contained and the drain kernel; compiled into
+      //  the chain-step kernel too it cost the NSCP launch 3.5 % -- four to six registers spilled -- with no
+      //  buffer attached, so that kernel's histories are held through the bins and counters they leave)
+      if (a.pfinals) {
+        if (died) {
+          // (the id from the slot, not from `hid`: nothing but this would keep that pair of registers alive
+          //  through the move)
+          const U4 ids = pu[U_ID * F + slot];
+          r3d_final* f = reinterpret_cast<r3d_final*>(a.pfinals) + (((uint64_t)ids.b << 32) | ids.a);
+          // (the amplitude as its logarithm, which is what the kernel carries: r3d_production_finals_read
+          //  exponentiates on the host -- an exponential here is thirty instructions under full register load)
+          f->time = p.t, f->path = p.path, f->amp = p.lamp;
+          f->loc[0] = p.loc.x, f->loc[1] = p.loc.y, f->loc[2] = p.loc.z;
+          f->dir[0] = p.dir.x, f->dir[1] = p.dir.y, f->dir[2] = p.dir.z;
+          f->moves = p.moves;
+          f->fate = (uint8_t)fate;
+          f->type = (uint8_t)p.type;
+          f->n_catch = (uint16_t)0xFFFFu;
+        }
+      }
     }
     if (TRACE) {
       report(died && fate == FATE_LOST, 5, p, hid);
@@ -792,7 +820,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         if (last) break;
       }
       const bool died = act && dest == Q_FREE;
-      finish(died, fate, reason, p, hid, (TRACE && died) ? pu[U_ID * F + id].c : 0u);
+      finish(died, fate, reason, p, hid, (TRACE && died) ? pu[U_ID * F + id].c : 0u, id);
     } else if (q == Q_COLLECT) {
       // ---- arrival at a collection face: the receivers, with the incident state
       //      (phonons.cpp:629-631), then on to what the face itself asks for ----
@@ -860,7 +888,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         else pu[U_STATE * F + id].d = m2;
         if (TRACE) pu[U_ID * F + id].c += catches;
       }
-      finish(died, FATE_LOST, 0, p, hid, (TRACE && died) ? pu[U_ID * F + id].c : 0u);
+      finish(died, FATE_LOST, 0, p, hid, (TRACE && died) ? pu[U_ID * F + id].c : 0u, id);
     } else {
       // ---- RT: reflection / transmission solve; SCATTER: deflection drawn from the scatterer's
       //      tables (phonons.cpp:611-618, :640-661) ----

@@ -194,7 +194,11 @@ struct KArgs {
   double* energy;
   unsigned long long* counts;
   unsigned long long* scalars;
-  void* finals;              // r3d_final[n] or null
+  void* finals;              // r3d_final[n] or null (the diagnostic kernel's: indexed by id - first_id)
+  // final records out of the PRODUCTION kernels (r3d_engine_set_production_finals): the record of history `id` is
+  // pfinals[id] -- the buffer's address less its first id, so that the kernel holds ONE word for it (the engine
+  // refuses launches whose ids the buffer does not cover); null = off
+  void* pfinals;
   // optional volumetric scatter-event grid (null = off): count[type][frame][z][y][x]
   unsigned int* vol;
   double vol_origin[3], vol_inv_cell[3], vol_inv_dt;

@@ -407,6 +407,17 @@ class Engine:
                 raise RuntimeError("detaching the volume failed: " + self._lib.r3d_last_error().decode())
         self._volume_keepalive = None
 
+    def set_production_finals(self, base_id, capacity):
+        """Final records out of the production kernels for ids [base_id, base_id + capacity) (capacity 0: off)."""
+        if self._lib.r3d_engine_set_production_finals(self._e, base_id, capacity):
+            raise RuntimeError("r3d_engine_set_production_finals failed: " + self._lib.r3d_last_error().decode())
+
+    def production_finals(self, first, count):
+        out = (_ffi.Final * count)()
+        if self._lib.r3d_production_finals_read(self._e, out, first, count):
+            raise RuntimeError("r3d_production_finals_read failed: " + self._lib.r3d_last_error().decode())
+        return out
+
     def read_volume(self, reset=False):
         out = np.zeros(self._vol_shape, dtype=np.uint32)
         assert out.size == self._lib.r3d_volume_len(self._e)

@@ -8,7 +8,7 @@ import torch
 
 from conftest import finals_differ
 from oracle import oracle_ffi as O
-from oracle.check import assert_aggregates_equal, assert_aggregates_equal_without, forked_ids
+from oracle.check import assert_aggregates_equal, assert_aggregates_equal_without, forked_ids, production_finals_differ
 from radiative3d_amd import Engine, Model, _ffi
 from radiative3d_amd.parallel import DeviceResult, shard_range
 from tests.configs import crustpinch, halfspace, lopnor, sphere_deep
@@ -57,9 +57,17 @@ def check_production_against_oracle(engine, n, first_id=0, seed=0x5EED, pieces=4
     r3d_run_device[_carry]) and pool_drain_kernel (a chain's flush) -- against the oracle, not
     against the diagnostic kernel or themselves (reference phonons.cpp:540-682, dataout.cpp:103-216)."""
     model = engine.model
-    want = O.run(model, n, first_id, seed)
+    want, want_finals = O.run(model, n, first_id, seed, trace=True)
+    # (the final records these kernels themselves leave, history by history: r3d_engine_set_production_finals --
+    #  the self-contained kernel writes all of them, the drain kernel those that end in a chain's flush)
+    engine.set_production_finals(first_id, n)
     got = engine.run(n, first_id, seed)                       # one self-contained production launch
     assert_result_equals_oracle(got, want, "r3d_run")
+    mine = engine.production_finals(0, n) if n else []
+    assert all(f.fate != 255 and f.n_catch == 0xFFFF for f in mine), "a history left no final record"
+    differ = [first_id + i for i, (a, b) in enumerate(zip(mine, want_finals)) if production_finals_differ(a, b)]
+    assert not differ, f"self-contained production kernel: {len(differ)} of {n} final records differ from the oracle: ids {differ[:20]}"
+    engine.set_production_finals(first_id, n)                 # (a fresh buffer for the chain)
     # the same ids as a carry chain of `pieces` launches + a flush-only launch (n = 0: the drain kernel)
     total = DeviceResult(model, "cuda:0")
     per = n // pieces
@@ -72,6 +80,12 @@ def check_production_against_oracle(engine, n, first_id=0, seed=0x5EED, pieces=4
     torch.cuda.synchronize()
     assert not engine.carry_pending
     assert_result_equals_oracle(total.to_result(), want, "carry chain + drain")
+    mine = engine.production_finals(0, n) if n else []
+    written = [i for i, f in enumerate(mine) if f.fate != 255]   # histories that ended in the flush (the step kernel writes none)
+    assert n < 1000 or len(written) > n // 4, (len(written), n)
+    differ = [first_id + i for i in written if production_finals_differ(mine[i], want_finals[i])]
+    assert not differ, f"drain kernel: {len(differ)} of {len(written)} final records differ from the oracle: ids {differ[:20]}"
+    engine.set_production_finals(0, 0)
     return got, want
 
 
