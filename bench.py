@@ -88,6 +88,42 @@ def algorithmic_bytes_per_history(ev, n_toa, n_seis, cell_kind):
             + 104)
 
 
+def contract_terms(ev, n_toa, n_seis, cell_kind):
+    """algorithmic_bytes_per_history term by term (the same formula): which of the reference's must-touch
+    bytes are what -- the all-receiver scan of every surface arrival is most of them."""
+    probes = 2 + math.ceil(math.log2(n_toa))
+    b_cell = {0: 150, 1: 340, 2: 120}[cell_kind]
+    return {"source_draw": probes * 8 + 16,
+            "cell_records": ev["iterations"] * b_cell,
+            "cell_hand_overs": ev["transfer"] * 64,
+            "interface_solves": ev["rtsolve"] * 112,
+            "scatter_draws": ev["scatter"] * (probes * 8 + 8 + 16),
+            "receiver_scan_all_receivers_per_arrival": ev["collect"] * n_seis * 48,
+            "catches": ev["catch"] * 56,
+            "history_state": 104}
+
+
+def phase_floor(ev, cell_kind):
+    """Vector instructions per history if nothing but each phase's common path were executed: the static counts of
+    tools/microbench/phase_floor.hip (profiles/<round>/phase_floor.json, made by tools/phase_floor.py on these kernel
+    sources) times this run's own event counts.  No queue, slot or tally code, no rare branch, the short tier of every
+    series; light face events (hand-overs, Snell bends) and the receiver candidates that do not catch are not counted:
+    a FLOOR.  achieved / floor falls when instructions are removed from the kernel and the floor stands."""
+    rel = os.path.join("profiles", PROFILE_ROUND, "phase_floor.json")
+    try:
+        rec = json.load(open(os.path.join(REPO, rel)))
+    except (OSError, ValueError):
+        return None, rel, "no floor file"
+    if rec.get("kernel_source_hash") != kernel_source_hash():
+        return None, rel, "counted on other kernel sources"
+    v = rec["valu"]
+    move = v[{0: "move_cyl", 1: "move_tet", 2: "move_sph"}[cell_kind]]
+    terms = {"spray": ev["generated"] * v["spray"], "moves": ev["iterations"] * move, "interface_solves": ev["rtsolve"] * v["rt"],
+             "scatterings": ev["scatter"] * v["scatter"], "arrivals": ev["collect"] * v["collect_arrival"],
+             "catches": ev["catch"] * (v["collect_candidate"] + v["collect_catch"])}
+    return {"per_history": sum(terms.values()), "by_term": terms, "per_event": {"move": move, **{k: v[k] for k in v if not k.startswith("move_")}}}, rel, None
+
+
 def kernel_source_hash(csrc=None):
     """sha256 over the traversal kernel's code, its launch geometry and build flags: what the recorded
     counters are keyed by.  Comments and white space do not count (a reworded comment leaves the machine
@@ -495,6 +531,11 @@ def main():
                 "valu_insts_per_launch": rec.get("SQ_INSTS_VALU"),
                 "valu_busy_at_recorded_clock": rec.get("valu_busy"),
                 "lanes_active_per_valu_inst": rec.get("lane_activity"),
+                # busy x lanes: the share of the chip's lane-issue slots that carried a lane's instruction
+                "lane_weighted_frac": achieved / peak * rec["lane_activity"] if rec.get("lane_activity") else None,
+                # what one history costs in lane-instructions (falls when instructions are removed; frac does not)
+                "valu_lane_insts_per_history": rec["SQ_INSTS_VALU"] * 64.0 * rec["lane_activity"] / n
+                if rec.get("lane_activity") and rec.get("SQ_INSTS_VALU") else None,
                 "hbm": {"bytes_per_launch": traffic,
                         "GBps": traffic / (avg_step_ms * 1e-3) / 1e9 if traffic else None,
                         "frac_of_peak": traffic / (avg_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
@@ -502,8 +543,20 @@ def main():
         else:
             roofline.update({"achieved": None, "peak": N_SIMD * MAX_CLOCK_GHZ, "unit": "G SIMD-cycles/s",
                              "frac": None, "traffic": None, "counters": f"none ({why_not}: {rec_path})"})
+        floor, floor_path, floor_why_not = phase_floor(ev, model.desc.cell_kind)
+        if floor is not None:
+            roofline["floor_lane_insts_per_history"] = floor["per_history"]
+            roofline["floor"] = {"source": floor_path, "by_term": floor["by_term"], "valu_insts_per_event": floor["per_event"],
+                                 "note": "static v_* counts of each phase's common path (tools/microbench/phase_floor.hip) x this run's "
+                                         "event counts: no queue / slot / tally code, no rare branch, no light face event"}
+            if roofline.get("valu_lane_insts_per_history"):
+                roofline["achieved_over_floor"] = roofline["valu_lane_insts_per_history"] / floor["per_history"]
+        else:
+            roofline["floor_lane_insts_per_history"] = None
+            roofline["floor"] = f"none ({floor_why_not}: {floor_path})"
         contract = {
             "per_history": b_hist, "per_launch": b_hist * n,
+            "by_term": contract_terms(ev, model.n_toa, model.n_seismometers, model.desc.cell_kind),
             "GBps": n * b_hist / (avg_step_ms * 1e-3) / 1e9,
             "over_hbm_peak": n * b_hist / (avg_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "note": "SURVEY.md 8(d) must-touch bytes of the reference's algorithm (all receivers tested per "

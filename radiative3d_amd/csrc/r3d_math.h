@@ -117,7 +117,12 @@ R3D_HD double frcp1(double x) {
 // whatever the pool size, launch boundaries or batch-mates (tests/test_gpu_parity.py
 // test_reproducible_build_*), at the cost stated in DESIGN.md section 4.
 R3D_HD bool all_lanes(bool c) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(R3D_REPRODUCIBLE)
+#if defined(R3D_FLOOR_TIERS)   // (tools/microbench/phase_floor.hip: instruction counts of the short tiers; never run)
+#if !defined(R3D_DEV_BUILD)
+#error "R3D_FLOOR_TIERS is a counting-only switch of tools/microbench/phase_floor.hip"
+#endif
+  return true || c;
+#elif defined(__HIP_DEVICE_COMPILE__) && defined(R3D_REPRODUCIBLE)
   return false && c;
 #elif defined(__HIP_DEVICE_COMPILE__)
   return __all(c) != 0;
