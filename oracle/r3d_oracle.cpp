@@ -1115,6 +1115,28 @@ int r3d_oracle_tet_search(const double normals[12], const double points[12], con
   return face;
 }
 
+// SphereShell::GetPathToBoundary (media.cpp:668-757) on ONE bare shell v = a r^2 + c (a < 0) between the radii
+// r_top and r_bottom about the origin, from `loc` along the unit vector `dir`.  Returns the exit face (0 top,
+// 1 bottom); *len: the arc length, squashed at zero as the reference does.  For tests/test_face_filter.py.
+int r3d_oracle_shell_search(double a, double c0, double r_top, double r_bottom, const double loc[3], const double dir[3],
+                            double* len) {
+  r3d_model_desc m;
+  std::memset(&m, 0, sizeof m);
+  r3d_cell c;
+  std::memset(&c, 0, sizeof c);
+  c.vel_a[0] = a, c.vel_c[0] = c0, c.zero_rad2[0] = -c0 / a;
+  c.faces[0].radius = r_top, c.faces[1].radius = -r_bottom;
+  const V lc = mk(loc), d = mk(dir);
+  RayArc A = shell_arc(m, c, 0, lc, d);
+  double dt = sphere_arc_exit(c.faces[0], lc, d, A);
+  double db = sphere_arc_exit(c.faces[1], lc, d, A);
+  int ef = (dt < db) ? 0 : 1;
+  double dist = ef == 0 ? dt : db;
+  if (dist < 0) dist = 0;
+  *len = dist;
+  return ef;
+}
+
 void r3d_oracle_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   oracle_philox4x32_10(ctr, key, out);
 }

@@ -313,11 +313,12 @@ R3D_HD void tet_advance(const CellTet& c, const TetArc& A, Phonon& p, double len
 //   (1) every face: inside (h >= 0), or outside by so little while moving in (h >= 1e-11 P, P = R n.d < 0)
 //       that its entry lies within 1e-11 rad ahead -- a phonon that has just come through that face sits
 //       within 1e-16 R of it, either side -- which is inside the reference's slack;
-//   (2) every face: |disc| >= 1e-10 R^2.  sqrt(disc) / R is the sine of the angle at which the ray CIRCLE meets
+//   (2) every face: |disc| >= 1e-10 (R^2 + |loc|^2).  sqrt(disc) / R is the sine of the angle at which the ray CIRCLE meets
 //       the face's plane (negative disc: it does not) times the length of the face normal's part in the arc's
 //       plane, and the reference's entry and exit angles are good to ~1e-16 over that product (its plane
 //       offset n.p - n.centre and its in-plane normal are each good to 1e-16 absolute; measured,
-//       tests/test_face_filter.py): held to 1e-5, its angles are good to 1e-11 -- a thousandth of the margins
+//       tests/test_face_filter.py; of |loc| + R where the cell lies further from the origin than the arc's centre
+//       from the cell): held to 1e-5, its angles are good to 1e-11 -- a thousandth of the margins
 //       below -- and "does the circle cross this plane at all" is not a matter of rounding.  (For a phonon
 //       ON a face this also says it is not grazing: there disc = P^2, so |n.d| >= 1e-5.)
 //   (3) every face that is crossed: |t_exit| >= 1e-8 (no exit within 2e-8 rad either side of the phonon);
@@ -348,7 +349,8 @@ R3D_HD TetFast tet_fast_exit(const CellTet& c, const Phonon& p, TetLocal& L) {
   L.iw = frsqrt(L.m2);
   L.R = vel * L.iw;
   L.U = (L.R * L.iw) * L.w;
-  const double eR2 = kLocEpsC * (L.R * L.R);
+  // (R^2 + |loc|^2: the reference's plane offset n.p - n.centre is good to 1e-16 of |centre| <= |loc| + R)
+  const double eR2 = kLocEpsC * (L.R * L.R + mag2(p.loc));
   LaneMask good = lm(L.R > 0.0);   // (a velocity <= 0 or a NaN: not this routine's business)
   double tq[4];
 #pragma unroll
@@ -636,6 +638,141 @@ R3D_HD void sph_advance(const CellSph& c, const SphArc& A, Phonon& p, double len
   p.path += len, p.t += time, p.recent += time;
   p.lamp += c.att * att_time;
   p.moves += 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// THE SHELL MOVE IN LOCAL FORM (round 5), as the tetra move above.  In a shell with v = a r^2 + c the ray
+// is a circle too, and everything the tetra's local form uses carries over with the LOCAL gradient
+// g = grad v = 2 a X (X = loc - Earth's centre):  w = g - (g.d) d,  u = w / |w|,  R = v / |w|,
+//     x(th) = loc + R sin(th) d - R (1 - cos th) u .
+// The faces are spheres about the Earth's centre, and |x(th)|^2 = r^2 + 2 R [sin(th) X.d + (1 - cos th)(R - X.u)]
+// is again linear in sin th and 1 - cos th: with (all times 2 R, so that nothing is divided)
+//     top    (inside while |x| <= rho_t):  h = rho_t^2 - r^2,   P = 2 R X.d,   M = 2 (X.U - R^2)      (U = R u)
+//     bottom (inside while |x| >= rho_b):  h = r^2 - rho_b^2,   P, M with the other sign
+// the face is met where  P sin th - M (1 - cos th) = h -- the tetra's equation, and its exit root
+//     t_exit = tan(th / 2) = h / (P + S)  for P >= 0,   (P - S) / (2 M + h)  for P < 0,   S = sqrt(P^2 - h (2 M + h)).
+// The reference (SphereShell::GetPathToBoundary, media.cpp:668-757; SphereFace::CircularArcDistToExit,
+// media_cellface.cpp:717-748) measures both faces' angles from the arc's BOTTOM and takes the top unless the
+// bottom's distance is smaller; for a phonon inside its shell that is the first exit ahead.  Where its
+// special cases could apply -- a start outside the shell (distances squashed to zero), an arc that never
+// reaches the top (taken at minus infinity), an arc tangent to a face, an exit at the phonon's feet, more
+// than half a circle ahead, straight and vertical rays -- the lane takes the reference's construction.
+// Travel time: v along the arc is v0 + 2 a R [X.d sin th + (R - X.u)(1 - cos th)], and with t = tan(th / 2)
+//     time = Int R dth / v = (1 / sqrt(-a c)) atanh( 2 R sqrt(-a c) t / (v0 + 2 a R (X.d) t) )
+// (the discriminant of the quadratic under the integral is -4 a c R^2 whatever the ray: every ray circle
+// is orthogonal to the sphere v = 0).
+struct SphFast {
+  double t, sn, cs, omc;   // tan(th/2), sin th, cos th, 1 - cos th of the exit
+  double aP;               // a * 2 R X.d: the travel time's denominator is v0 + aP t
+  double vel;
+  int face;
+  bool ok;
+};
+constexpr double kLocEpsCSph = 1e-10;
+constexpr double kLocTmaxSph = 50.0;   // exits up to 177.7 degrees ahead (t = tan(th / 2)); beyond: the reference's construction
+R3D_HD SphFast sph_fast_exit(const CellSph& c, V3 ec, const Phonon& p, TetLocal& L) {
+  SphFast F;
+  const V3 X = p.loc - ec;
+  const double r2 = mag2(X);
+  F.vel = c.c + c.a * r2;
+  const V3 g = (2.0 * c.a) * X;
+  L.gd = dot(g, p.dir);
+  L.w = g - L.gd * p.dir;
+  L.m2 = mag2(L.w);
+  L.iw = frsqrt(L.m2);
+  L.R = F.vel * L.iw;
+  L.U = (L.R * L.iw) * L.w;
+  const double twoR = 2.0 * L.R;
+  const double Pt = twoR * dot(X, p.dir);
+  const double XU = dot(X, L.U), R2 = L.R * L.R;
+  const double Mt = 2.0 * (XU - R2);
+  F.aP = c.a * Pt;
+  // The margins of the certificate, in the reference's own terms (measured: tests/test_face_filter.py).  It places
+  // a face's crossing by the cosine (S^2 + R^2 - rho^2) / (2 S R) of its angle from the arc's bottom, S = the
+  // distance of the arc's centre from the Earth's: the numerator is good to 1e-16 of its largest term, so the
+  // angle is good to 1e-16 (S^2 + R^2 + rho^2) / (2 S R) over its SINE, and 1 - cosine^2 = disc / (2 R S)^2 here
+  // (whether the arc reaches the face at all is the same quantity's sign): with |disc| >= 1e-10 (S^2 + R^2 + r^2)^2
+  // the reference's angles are good to ~1e-10 (several roundings go into that cosine), a hundredth of the margins
+  // on t.  And its arc radius comes from 1 - sqrt(1 + 4 G^2 |a| c), which loses digits as the ray nears the
+  // vertical: the lost share is R^2 / zero_rad2, held to 1e6 (rays within ~1e-3 of the vertical take the
+  // reference's construction, as the exactly vertical ones must).
+  const double S2 = (r2 - 2.0 * XU) + R2;
+  const double sc = (S2 + R2) + r2;
+  const double eR2 = kLocEpsCSph * (sc * sc);
+  // (a < 0: graded shells only -- uniform ones have straight rays, a > 0 is refused when the model is built)
+  LaneMask good = lm(L.R > 0.0) & lm(c.a < 0.0) & lm(R2 <= 1e6 * c.zero_rad2);
+  double tq[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const double rad = c.radius[i];                       // signed: +top, -bottom
+    const double h = i == 0 ? rad * rad - r2 : r2 - rad * rad;
+    const double P = i == 0 ? Pt : -Pt, M = i == 0 ? Mt : -Mt;
+    const double k = 2.0 * M + h;
+    const double disc = P * P - h * k;
+    const LaneMask Dpos = lm(disc > eR2), Dneg = lm(disc < -eR2);
+    const double S = disc * frsqrt1(disc);
+    const bool fwd = P >= 0.0;
+    const double q = fwd ? P + S : P - S;
+    const double num = fwd ? h : q, den = fwd ? q : k;
+    const double t = num * frcp1(den);
+    const LaneMask Tpos = lm(t >= kLocEpsT), Tneg = lm(t <= -kLocEpsT);
+    const LaneMask inside = lm(h >= 0.0) | lm(h >= kLocTau * P);
+    // (the top: an arc that never reaches it is the reference's "minus infinity" case -- not ours)
+    good = good & (i == 0 ? Dpos : (Dneg | Dpos)) & (Dneg | (Tpos | Tneg)) & inside;
+    tq[i] = lm_lane(Dpos & Tpos) ? t : 2.0 * kLocTmaxSph;
+  }
+  F.t = fmin(tq[0], tq[1]);
+  F.face = tq[1] < tq[0] ? 1 : 0;
+  const double other = fmax(tq[0], tq[1]);
+  good = good & lm(F.t <= kLocTmaxSph) & lm(other - F.t >= kLocEpsT);
+  const double inv = frcp(1.0 + F.t * F.t);
+  F.sn = (2.0 * F.t) * inv, F.omc = F.t * F.sn, F.cs = 1.0 - F.omc;
+  F.ok = lm_lane(good);
+  return F;
+}
+// reference SphereShell::AdvanceLength_Variant_RD2 (media.cpp:913-957) + Phonon::Move in the local form: the leg
+// ends at arc angle th ahead, (sn, cs, omc, t) = (sin th, cos th, 1 - cos th, tan(th / 2)).
+R3D_HD void sph_advance_local(const CellSph& c, const TetLocal& L, const SphFast& F, Phonon& p, double len, double sn,
+                              double cs, double omc, double t) {
+  const V3 nl = p.loc + ((L.R * sn) * p.dir + (-omc) * L.U);
+  const V3 nd = cs * p.dir + (-sn * L.iw) * L.w;
+  const double nac = -c.a * c.c;
+  const double isq = frsqrt(nac);                       // 1 / sqrt(-a c)
+  const double y = ((2.0 * L.R) * (nac * isq) * t) * frcp(F.vel + F.aP * t);
+  const double time = isq * atanh_lean(y);
+  p.path += len, p.t += time, p.recent += time;
+  p.loc = nl;
+  p.dir = nd;
+  p.lamp += c.att * time;
+  p.moves += 1;
+}
+
+// The whole shell move by the reference's construction, for the lanes whose local form did not certify (what
+// step_move did for every lane until round 5): arc, search, free path, advance.
+R3D_HD TetSlowOut sph_move_reference_inline(const CellSph* cp, V3 ec, Phonon p, double u_free, double mfp) {
+  const CellSph c = *cp;
+  TetSlowOut o;
+  o.fate = FATE_ALIVE, o.scatters = 0;
+  const SphArc sarc = sph_arc(c, ec, p);
+  const SphExit sexit = sph_exit(c, sarc, p);
+  o.face = sexit.face;
+  if (sexit.len == pos_inf()) {  // phonons.cpp:595-598
+    o.fate = FATE_TIMEOUT, o.p = p;
+    return o;
+  }
+  double scatlen = pos_inf();
+  if (!((1.0 - u_free) * mfp >= sexit.len)) scatlen = -log_lean(u_free) * mfp;
+  const bool scatters = scatlen < sexit.len;
+  const double len = scatters ? scatlen : sexit.len;
+  double s1 = sexit.sx, c1 = sexit.cx;  // a boundary leg ends at the exit point itself
+  if (scatters || !sexit.on_arc) {
+    double sd, cd;                      // scatter leg (or a squashed one): rotate by len / R
+    rotation(len * frcp(sarc.radius), &sd, &cd);
+    s1 = sarc.s0 * cd + sarc.c0 * sd, c1 = sarc.c0 * cd - sarc.s0 * sd;
+  }
+  sph_advance(c, sarc, p, len, s1, c1);
+  o.p = p, o.scatters = scatters ? 1 : 0;
+  return o;
 }
 
 // ============================================================== interfaces ==

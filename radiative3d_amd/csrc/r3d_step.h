@@ -34,6 +34,9 @@
 #ifndef R3D_TET_LOCAL
 #define R3D_TET_LOCAL 1
 #endif
+#ifndef R3D_SPH_LOCAL
+#define R3D_SPH_LOCAL 1
+#endif
 #ifndef R3D_TET_EARLY_MFP
 #define R3D_TET_EARLY_MFP 0
 #endif
@@ -354,6 +357,45 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
       p = o.p, e.face = o.face, scatters = o.scatters != 0;
     }
 #endif
+  } else if constexpr (KIND == CELL_SPH && R3D_SPH_LOCAL != 0) {
+    // The shell move in local form (r3d_physics.h sph_fast_exit), certified as the tetra's; the other lanes -- straight
+    // and vertical rays, starts outside the shell, tangent arcs, exits at the phonon's feet -- take the reference's.
+    bool slow;
+    e.len = 0.0, scatters = false;
+    const V3 ec = v3(a.earth_center[0], a.earth_center[1], a.earth_center[2]);
+    {
+      TetLocal L;
+      const SphFast F = sph_fast_exit(c, ec, p, L);
+      slow = !F.ok;
+      e.face = F.face;
+      if (!slow) {
+        e.len = L.R * two_atan(F.t, F.sn, F.cs);
+        double scatlen = pos_inf();
+        if (!((1.0 - u_free) * mfp >= e.len)) scatlen = -log_lean(u_free) * mfp;
+        scatters = scatlen < e.len;
+        double len = e.len, sn = F.sn, cs = F.cs, omc = F.omc, t = F.t;
+        if (any_lanes(scatters)) {
+          if (scatters) {                       // scatter leg: the arc angle is len / R (up to 178 degrees: inside the exit's)
+            len = scatlen;
+            rotation(len * frcp(L.R), &sn, &cs);
+            // 1 - cos th and tan(th / 2) without cancellation, either side of 90 degrees
+            const bool near = cs > 0.0;
+            const double ih = frcp(near ? 1.0 + cs : sn);
+            omc = near ? (sn * sn) * ih : 1.0 - cs;
+            t = near ? sn * ih : omc * ih;
+          }
+        }
+        sph_advance_local(c, L, F, p, len, sn, cs, omc, t);
+      }
+    }
+    if (any_lanes(slow)) {
+      if (slow) {
+        R3D_COUNT_SLOW_MOVE();
+        const TetSlowOut o = sph_move_reference_inline(&cell_rec<KIND>(T, p.cell, p.type), ec, p, u_free, mfp);
+        if (o.fate != FATE_ALIVE) return o.fate;
+        p = o.p, e.face = o.face, scatters = o.scatters != 0;
+      }
+    }
   } else {
   SphArc sarc;
   SphExit sexit;

@@ -159,6 +159,7 @@ extern "C" void r3d_emul_sample_cdf(const double* cdf, uint64_t n, uint32_t bits
 //   2 starts on / near an edge or a vertex    3 directions aimed at an edge or a vertex (ties)
 //   4 starts outside a face by 1e-17 .. 1e-7 R, moving in or out (retrograde micro-steps)
 //   5 sliver cells (faces meeting at shallow angles)   6 arcs tangent to a face (strong gradients)
+//   7 strongly graded cells 1e3 .. 1e5 from the origin, starts on a face moving in
 // out[0] cases, out[1] certified, out[2] certified and face differs, out[3] certified, same face, arc
 // lengths differ by more than tol * R, out[4] the reference gave no exit (len = inf) among the certified, out[5]
 // (with an oracle) certified cases on which the engine's sine-space search and the oracle's differ;
@@ -197,6 +198,10 @@ extern "C" void r3d_emul_face_filter(int mode, uint64_t n, uint64_t seed, double
     V3 x[4];
     for (;;) {
       for (int k = 0; k < 4; k++) x[k] = v3(10 * g.u(), 10 * g.u(), 10 * g.u());
+      if (mode == 7) {   // a cell far from the origin (strongly graded: the arc's radius is much less than |loc|)
+        const V3 off = g.logu(1e3, 1e5) * rnd_unit(g);
+        for (int k = 0; k < 4; k++) x[k] = x[k] + off;
+      }
       if (mode == 5) {
         const V3 nn = unit(cross(x[1] - x[0], x[2] - x[0]));
         const V3 c3 = (1.0 / 3.0) * (x[0] + x[1] + x[2]);
@@ -219,7 +224,7 @@ extern "C" void r3d_emul_face_filter(int mode, uint64_t n, uint64_t seed, double
     const V3 centre = 0.25 * (x[0] + x[1] + x[2] + x[3]);
     // velocity: 5 at the centre, gradient of any direction; arc radius from ~the cell's size to 1e5 of it
     const V3 gd = rnd_unit(g);
-    const double gm = (mode == 6) ? 5.0 / g.logu(12.0, 60.0) : 5.0 / g.logu(20.0, 1e6);   // (velocity > 0 throughout the cell)
+    const double gm = (mode == 6 || mode == 7) ? 5.0 / g.logu(12.0, 60.0) : 5.0 / g.logu(20.0, 1e6);   // (velocity > 0 throughout the cell)
     c.g[0] = gm * gd.x, c.g[1] = gm * gd.y, c.g[2] = gm * gd.z;
     c.v0 = 5.0 - dot(v3(c.g), centre);
     c.inv_gmag = 1.0 / gm;
@@ -233,7 +238,7 @@ extern "C" void r3d_emul_face_filter(int mode, uint64_t n, uint64_t seed, double
     for (int k = 0; k < 4; k++) sum += (w[k] = -std::log(1.0 - g.u()));
     for (int k = 0; k < 4; k++) w[k] /= sum;
     const int f0 = (int)(g.next() & 3), f1 = (f0 + 1 + (int)(g.next() % 3)) & 3;
-    if (mode == 1 || mode == 4) w[f0] = 0;                     // on face f0 (corner f0 has no weight)
+    if (mode == 1 || mode == 4 || mode == 7) w[f0] = 0;        // on face f0 (corner f0 has no weight)
     if (mode == 2) {
       w[f0] = 0, w[f1] = (g.u() < 0.5) ? 0.0 : g.logu(1e-16, 1e-6);   // on / near the edge shared by f0 and f1
       if (g.u() < 0.3) w[(f1 + 1) & 3 == f0 ? (f1 + 2) & 3 : (f1 + 1) & 3] = g.logu(1e-16, 1e-6);   // near a vertex
@@ -243,7 +248,7 @@ extern "C" void r3d_emul_face_filter(int mode, uint64_t n, uint64_t seed, double
     for (int k = 0; k < 4; k++) p.loc = p.loc + (w[k] / sum) * x[k];
     p.dir = rnd_unit(g);
     const V3 nf0 = v3(c.n[f0]);
-    if (mode == 1 || mode == 2) {   // moving in through f0 (any angle, grazing included)
+    if (mode == 1 || mode == 2 || mode == 7) {   // moving in through f0 (any angle, grazing included)
       if (dot(nf0, p.dir) > 0) p.dir = p.dir - (2.0 * dot(nf0, p.dir)) * nf0;
       if (g.u() < 0.2) {             // grazing: mostly along the face
         V3 tang = unit(cross(nf0, rnd_unit(g)));
@@ -302,6 +307,99 @@ extern "C" void r3d_emul_face_filter(int mode, uint64_t n, uint64_t seed, double
       first_bad[5] = L.R, first_bad[6] = F.t;
       for (int f = 0; f < 4; f++) first_bad[7 + f] = c.d[f] - dot(v3(c.n[f]), p.loc);
       for (int f = 0; f < 4; f++) first_bad[11 + f] = dot(v3(c.n[f]), p.dir);
+    }
+  }
+}
+
+// ---- the shell move's two searches side by side (tests/test_face_filter.py) -------------------------------
+// Random shells v = a r^2 + c (a < 0, velocity 3 .. 9 growing 0.1 .. 30 % from top to bottom, top radius 1000 .. 6371,
+// thickness 5 .. 2000) about the origin; the local form (sph_fast_exit) and the reference's construction
+// (sph_arc / sph_exit) both run; where the local form certifies they must agree.  mode:
+//   0 interior starts, any direction        1 on the top face (to rounding, either side), moving in
+//   2 on the bottom face, moving in (up)    3 near the bottom, nearly horizontal (arcs tangent to the bottom face)
+//   4 outside either face by 1e-17 .. 1e-7 of the radius, moving in or out
+//   5 nearly vertical rays                  6 thin shells with strong gradients (legs of many degrees)
+// out[] / dev[] as r3d_emul_face_filter.
+typedef int (*shell_search_fn)(double a, double c0, double r_top, double r_bottom, const double loc[3], const double dir[3], double* len);
+extern "C" void r3d_emul_shell_filter(int mode, uint64_t n, uint64_t seed, double tol, uint64_t* out, double* dev,
+                                      double* first_bad, shell_search_fn oracle) {
+  SplitMix g{seed * 0x9E3779B97F4A7C15ull + 77u + (uint64_t)mode};
+  for (int i = 0; i < 6; i++) out[i] = 0;
+  dev[0] = dev[1] = 0.0;
+  for (uint64_t it = 0; it < n; it++) {
+    const double rt = 1000.0 + 5371.0 * g.u();
+    const double thick = (mode == 6) ? g.logu(2.0, 60.0) : std::fmin(g.logu(5.0, 2000.0), 0.8 * rt);
+    const double rb = rt - thick;
+    const double vt = 3.0 + 6.0 * g.u();
+    const double vb = vt * (1.0 + ((mode == 6) ? g.logu(0.05, 0.6) : g.logu(1e-3, 0.3)));
+    CellSph c;
+    std::memset(&c, 0, sizeof c);
+    c.a = (vt - vb) / (rt * rt - rb * rb);
+    c.c = vt - c.a * rt * rt;
+    c.zero_rad2 = -c.c / c.a;
+    c.att = -0.01;
+    c.radius[0] = rt, c.radius[1] = -rb;
+    Phonon p;
+    std::memset(&p, 0, sizeof p);
+    p.pc = 1.0;
+    const V3 up = rnd_unit(g);
+    double r = rb + thick * g.u();
+    if (mode == 1) r = rt;
+    if (mode == 2) r = rb;
+    if (mode == 3) r = rb + thick * g.logu(1e-12, 1e-2);
+    if (mode == 4) r = (g.u() < 0.5) ? rt * (1.0 + g.logu(1e-17, 1e-7)) : rb * (1.0 - g.logu(1e-17, 1e-7));
+    p.loc = r * up;
+    if ((mode == 1 || mode == 2) && g.u() < 0.5) p.loc = (1.0 + g.sym() * g.logu(1e-17, 1e-13)) * p.loc;
+    p.dir = rnd_unit(g);
+    const double vert = dot(p.dir, up);
+    if (mode == 1 && vert > 0) p.dir = p.dir - (2.0 * vert) * up;      // down into the shell
+    if (mode == 2 && vert < 0) p.dir = p.dir - (2.0 * vert) * up;      // up into the shell
+    if ((mode == 1 || mode == 2) && g.u() < 0.2) {                     // grazing entries
+      const V3 tang = unit(cross(up, rnd_unit(g)));
+      p.dir = unit(tang + ((mode == 1 ? -1.0 : 1.0) * g.logu(1e-9, 1e-1)) * up);
+    }
+    if (mode == 3) {
+      const V3 tang = unit(cross(up, rnd_unit(g)));
+      p.dir = unit(tang + (g.sym() * g.logu(1e-8, 2e-1)) * up);
+    }
+    if (mode == 4 && g.u() < 0.5) {   // moving in
+      const double vv = dot(p.dir, up);
+      if ((r > rt) == (vv > 0)) p.dir = p.dir - (2.0 * vv) * up;
+    }
+    if (mode == 5) {
+      const V3 tang = unit(cross(up, rnd_unit(g)));
+      p.dir = unit((g.u() < 0.5 ? 1.0 : -1.0) * up + g.logu(1e-12, 1e-2) * tang);
+    }
+    out[0]++;
+    TetLocal L;
+    const SphFast F = sph_fast_exit(c, v3(0, 0, 0), p, L);
+    if (!F.ok) continue;
+    out[1]++;
+    const double len_loc = L.R * two_atan(F.t, F.sn, F.cs);
+    const SphArc A = sph_arc(c, v3(0, 0, 0), p);
+    const SphExit E = sph_exit(c, A, p);
+    double len_ref = E.len;
+    int face_ref = E.face;
+    bool bad = false;
+    if (oracle) {
+      const double loc[3] = {p.loc.x, p.loc.y, p.loc.z}, dir[3] = {p.dir.x, p.dir.y, p.dir.z};
+      double len_o = 0;
+      const int face_o = oracle(c.a, c.c, rt, rb, loc, dir, &len_o);
+      if (face_o != face_ref || !(std::fabs(len_o - len_ref) <= tol * L.R)) out[5]++;
+      face_ref = face_o, len_ref = len_o;
+    }
+    if (!(len_ref < pos_inf())) out[4]++, bad = true;
+    else if (face_ref != F.face) out[2]++, bad = true;
+    else {
+      const double d = std::fabs(len_loc - len_ref);
+      if (!(d <= tol * L.R)) out[3]++, bad = true;
+      if (d / L.R > dev[0]) dev[0] = d / L.R;
+      if (d / std::fmax(std::fabs(len_ref), 1e-300) > dev[1]) dev[1] = d / std::fmax(std::fabs(len_ref), 1e-300);
+    }
+    if (bad && first_bad && out[2] + out[3] + out[4] == 1) {
+      first_bad[0] = (double)it, first_bad[1] = F.face, first_bad[2] = face_ref, first_bad[3] = len_loc, first_bad[4] = len_ref;
+      first_bad[5] = L.R, first_bad[6] = F.t, first_bad[7] = rt, first_bad[8] = rb, first_bad[9] = r, first_bad[10] = dot(p.dir, up);
+      first_bad[11] = c.a, first_bad[12] = c.c;
     }
   }
 }

@@ -1,4 +1,4 @@
-"""The tetra move's two boundary searches side by side (round 5).
+"""The tetra and the spherical-shell move's two boundary searches side by side (round 5).
 
 `tet_fast_exit` (csrc/r3d_physics.h) finds the first exit of the ray arc from quantities measured at the
 phonon and CERTIFIES its answer by margins; where it does not certify, the lane takes the reference's own
@@ -15,7 +15,11 @@ import pytest
 import emul_ffi as E
 from oracle import oracle_ffi as O
 
-MODES = {0: "interior starts", 1: "starts on a face, moving in (grazing included)", 2: "starts on / near an edge or a vertex",
+SHELL_MODES = {0: "interior starts", 1: "on the top face, moving in (grazing included)", 2: "on the bottom face, moving in",
+               3: "near the bottom, nearly horizontal (arcs tangent to the bottom face)", 4: "outside either face by 1e-17 .. 1e-7 of its radius",
+               5: "nearly vertical rays", 6: "thin shells with strong gradients"}
+MODES = {7: "strongly graded cells far from the origin, starts on a face",
+         0: "interior starts", 1: "starts on a face, moving in (grazing included)", 2: "starts on / near an edge or a vertex",
          3: "aimed at an edge or a vertex", 4: "outside a face by 1e-17 .. 1e-7 R (retrograde micro-steps)",
          5: "sliver cells (faces meeting at shallow angles)", 6: "strong gradients: arcs bending along a face"}
 TOL = 1e-9   # arc lengths agree to TOL * R (R: the arc's radius); observed: 7e-11
@@ -33,8 +37,32 @@ def run(mode, n, seed, with_oracle=True):
                 engine_search_vs_oracle=out[5], dev_over_R=dev[0], first=list(first))
 
 
+def run_shell(mode, n, seed, with_oracle=True):
+    """The spherical shell's local move (sph_fast_exit) against SphereShell::GetPathToBoundary as the engine's
+    sph_arc / sph_exit and the oracle's r3d_oracle_shell_search have it (media.cpp:668-757, media_cellface.cpp:717-748)."""
+    L = E.lib()
+    L.r3d_emul_shell_filter.restype = None
+    L.r3d_emul_shell_filter.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]
+    fn = C.cast(O.lib().r3d_oracle_shell_search, C.c_void_p) if with_oracle else None
+    out, dev, first = (C.c_uint64 * 6)(), (C.c_double * 2)(), (C.c_double * 16)()
+    L.r3d_emul_shell_filter(mode, n, seed, TOL, out, dev, first, fn)
+    return dict(cases=out[0], certified=out[1], face_differs=out[2], length_differs=out[3], reference_has_no_exit=out[4],
+                engine_search_vs_oracle=out[5], dev_over_R=dev[0], first=list(first))
+
+
+@pytest.mark.parametrize("mode,n,least", [(0, 3_000_000, 0.99), (1, 400_000, 0.8), (2, 400_000, 0.8), (3, 400_000, 0.5), (4, 400_000, 0.3),
+                                          (5, 1_000_000, 0.1), (6, 400_000, 0.99)])
+def test_certified_shell_exit_is_the_references_exit(mode, n, least):
+    r = run_shell(mode, n, seed=20261004 + mode)
+    assert r["cases"] == n and r["certified"] >= least * n and r["certified"] >= 100_000, (SHELL_MODES[mode], r)
+    assert r["face_differs"] == 0 and r["reference_has_no_exit"] == 0, (SHELL_MODES[mode], r)
+    assert r["length_differs"] == 0 and r["dev_over_R"] <= TOL, (SHELL_MODES[mode], r)
+    assert r["engine_search_vs_oracle"] == 0, (SHELL_MODES[mode], r)
+
+
 @pytest.mark.parametrize("mode,n", [(0, 10_000_000), (1, 400_000), (2, 400_000), (3, 200_000), (4, 300_000),
-                                    (5, 200_000), (6, 200_000)])
+                                    (5, 200_000), (6, 200_000), (7, 200_000)])
 def test_certified_exit_is_the_references_exit(mode, n):
     r = run(mode, n, seed=20261004 + mode)
     assert r["cases"] == n
@@ -60,7 +88,8 @@ def test_benchmark_grids_take_the_local_form(models):
     histories are the oracle's (tests/test_emul_vs_oracle.py holds that history by history); the upthrust
     grid, whose mislinked faces make 4 % of the histories INVALID in the reference too, sends a fifth of its
     moves to the reference's construction -- which is what it is there for."""
-    for name, n, lo, hi in [("crustpinch", 3000, 0.0, 1e-4), ("crustpinch_vids", 1000, 0.0, 1e-4), ("upthrust", 1000, 0.05, 0.5)]:
+    for name, n, lo, hi in [("crustpinch", 3000, 0.0, 1e-4), ("crustpinch_vids", 1000, 0.0, 1e-4), ("upthrust", 1000, 0.05, 0.5),
+                            ("sphere", 200, 0.0, 1e-4), ("toysphere_vids", 200, 0.0, 1e-4)]:
         E.lib().r3d_emul_slow_moves(1)
         res = E.run(models(name), n)
         slow = E.lib().r3d_emul_slow_moves(1)

@@ -47,11 +47,12 @@ extern "C" __global__ void floor_move_sph(const CellSph* cells, Phonon* ps, doub
   rng_init(rng, (uint64_t)i);
   const CellSph c = cells[2 * p.cell + p.type];
   const double u = rng_draw(rng, rng_key(seed));
-  const SphArc A = sph_arc(c, v3(0, 0, 0), p);
-  const SphExit e = sph_exit(c, A, p);
-  if ((1.0 - u) * mfp >= e.len) {
-    sph_advance(c, A, p, e.len, e.sx, e.cx);
-    p.cell = e.face == 0 ? c.nbr[0] : c.nbr[1];
+  TetLocal L;
+  const SphFast F = sph_fast_exit(c, v3(0, 0, 0), p, L);
+  const double len = L.R * two_atan(F.t, F.sn, F.cs);
+  if ((1.0 - u) * mfp >= len && F.ok) {
+    sph_advance_local(c, L, F, p, len, F.sn, F.cs, F.omc, F.t);
+    p.cell = F.face == 0 ? c.nbr[0] : c.nbr[1];
   }
   ps[i] = p;
 }
