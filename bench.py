@@ -41,7 +41,7 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0
 N_SIMD = 256 * 4
 MAX_CLOCK_GHZ = 2.4
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 # BASELINE.json `configs`, as stated: the histories of ONE job of each configuration (configs 3-5 are
