@@ -338,8 +338,22 @@ class DeviceVolume:
     def allgather_frames_(self, chunk_elems=1 << 28):
         """After reduce_scatter_frames_: every owner broadcasts its frames, every rank ends with the
         job's whole grid (for callers that want it everywhere; not part of the job's reduction)."""
-        if not self._group() or self.owned is None:
+        if not self._group():
             return self
+        # Every rank must enter the broadcasts or none: after reduce_(dst) the destination holds everything
+        # (owned None) while the others hold scratch (owned ()) -- the ranks would part ways and the ones that
+        # went on would wait for ever.  So the ranks first agree on what state they are in, with one small
+        # all-reduce, and a job that is not in the by-frame state everywhere gets an error on EVERY rank.
+        state = 0 if self.owned is None else (2 if self.owned == () else 1)
+        seen = torch.zeros(3, dtype=torch.int64, device=self.counters.device)
+        seen[state] = 1
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        n_all, n_frames, n_scratch = (int(v) for v in seen.tolist())
+        if n_scratch or (n_all and n_frames):
+            raise RuntimeError("allgather_frames_ needs every rank's grid reduced by frame (reduce_scatter_frames_): "
+                               f"{n_frames} ranks hold frames, {n_all} hold a whole grid, {n_scratch} hold scratch of a reduce_")
+        if n_frames == 0:
+            return self          # nothing was reduced by frame anywhere: every rank's own counts, as they stand
         world = dist.get_world_size()
         for owner in range(world):
             for b, e in self._segments(*self.frame_range(owner, world)):

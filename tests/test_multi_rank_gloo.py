@@ -222,6 +222,11 @@ def _frames_worker(rank, world, port, n, out_dir):
     else:
         with pytest.raises(RuntimeError, match="scratch"):
             r.total()
+    # ... and allgather_frames_ after it is an error on EVERY rank (the destination holds a whole grid, the others
+    # scratch: entering the broadcasts from some ranks only would hang the job), not a deadlock
+    with pytest.raises(RuntimeError, match="needs every rank's grid reduced by frame"):
+        r.allgather_frames_()
+    assert fresh().allgather_frames_().owned is None          # nothing reduced by frame anywhere: a no-op, everywhere
     # saturation and the 2^31 switch-over, by frame: one frame per rank at world 2, cells chosen per owner
     tiny = dict(origin=(0, 0, 0), cell_size=(1, 1, 1), dims=(2, 1, 1), n_frames=world, frame_dt=1.0)
     for mode in ("sparse", "dense"):
