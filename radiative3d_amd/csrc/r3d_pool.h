@@ -323,6 +323,15 @@ constexpr int kKeepersWord = 7;   // PoolCtl::word[kKeepersWord]: waves that kee
 #ifndef R3D_PRODUCTION_FINALS
 #define R3D_PRODUCTION_FINALS 1
 #endif
+// A reflection / transmission or scattering batch hands ALL its slots to MOVE: with R3D_POOL_CHAIN_MOVE the wave that
+// served it serves that move itself, next -- no hand-off, no scheduling, no take (the slots' state is in LDS as for a
+// hand-off and the move reads it back).
+#ifndef R3D_POOL_CHAIN_MOVE
+#define R3D_POOL_CHAIN_MOVE 2
+#endif
+#ifndef R3D_POOL_CHAIN_REFILL
+#define R3D_POOL_CHAIN_REFILL 0
+#endif
 #ifndef R3D_TET_REFILL_PAIRS
 #define R3D_TET_REFILL_PAIRS 0
 #endif
@@ -591,7 +600,13 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   typedef const __attribute__((address_space(4))) KArgs* KernArgs;
   KernArgs args = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();   // (KArgs is the kernels' only parameter)
   // the drain (kTailBatch above): the lanes that keep their slot, and the phase they all want next
+  constexpr bool kChainMove = R3D_POOL_CHAIN_MOVE != 0 && (!TAIL || R3D_POOL_CHAIN_MOVE > 1);
+  constexpr int kChainFlag = 8;   // (above the queue numbers 0 .. Q_NUM - 1)
+  // ... and a refill whose slots all got a history: in the layered kernel only (the tetra and the shell kernel spill
+  // 13-40 registers under it: their moves leave no room for the spray's values beside them)
+  constexpr bool kChainRefill = kChainMove && R3D_POOL_CHAIN_REFILL != 0 && KIND == CELL_CYL;
   bool held = false;
+  unsigned k_chain = 0;   // (wave-uniform) slots of the batch just served that all want MOVE next and stay with this wave
   bool ids_out = false;   // (wave-uniform) the id counter was seen exhausted
   int dest = Q_FREE;
   unsigned id = 0;
@@ -606,11 +621,19 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #endif
     const unsigned long long held_m = TAIL ? ballot(held) : 0ull;
     const bool was_held = held_m != 0ull;
+    // (kernels with a tail: a batch chained on to its move travels as held lanes whose `dest` carries kChainFlag;
+    //  it is not one of the tail's keepers)
+    bool was_kept = was_held;
     if (was_held) {
       // ---- kept lanes: they all want the same phase ----
       q = __builtin_amdgcn_readlane(dest, __ffsll((long long)held_m) - 1);
+      if (kChainMove) was_kept = (q & kChainFlag) == 0, q &= kChainFlag - 1;
       act = held;
       k = (unsigned)__popcll(held_m);
+    } else if (kChainMove && !TAIL && k_chain) {
+      // ---- the batch this wave has just served (R/T or scattering): on to its move, in the same lanes ----
+      q = Q_MOVE, k = (unsigned)__builtin_amdgcn_readfirstlane((int)k_chain), act = lane < k;
+      k_chain = 0;
     } else {
       // ---- choose a queue: a full batch of a minor phase first (they all feed MOVE), then a
       //      refill, then MOVE; with no full batch anywhere, the fullest queue ----
@@ -981,14 +1004,14 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         const int d0 = __builtin_amdgcn_readlane(dest, __ffsll((long long)alive_m) - 1);
         keep_lanes = !any_lane(alive && dest != d0);   // they agree on what comes next
       }
-      if (keep_lanes && !was_held) {   // one more wave that keeps lanes: only while enough others serve the queues
+      if (keep_lanes && !was_kept) {   // one more wave that keeps lanes: only while enough others serve the queues
         uint32_t n = 0;
         if (lane == 0) n = atomicAdd(&ctl.word[kKeepersWord], 1u);
         if ((uint32_t)__builtin_amdgcn_readfirstlane((int)n) >= (uint32_t)kPoolWaves - kTailServers) {
           if (lane == 0) atomicSub(&ctl.word[kKeepersWord], 1u);
           keep_lanes = false;
         }
-      } else if (was_held && !keep_lanes) {
+      } else if (was_kept && !keep_lanes) {
         if (lane == 0) atomicSub(&ctl.word[kKeepersWord], 1u);
       }
     }
@@ -1000,11 +1023,16 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       if (any_lane(ended)) q_push_all(ctl, rings, rcap, rlog, lane, ended, Q_FREE, id);
       held = act && dest != Q_FREE;
       // (kept lanes sit in the wave's low lanes or anywhere: a phase only looks at `act`)
-    } else if (!was_held && (q == Q_RT || q == Q_SCATTER))
-      q_push_one(ctl, rings, rcap, rlog, Q_MOVE, lane, k, id);   // (all on to MOVE; a batch fresh from a queue sits in lanes 0 .. k-1)
+    } else if (!was_held && (q == Q_RT || q == Q_SCATTER || (kChainRefill && q == Q_FREE && !any_lane(act && dest != Q_MOVE)))) {
+      // (all on to MOVE -- every R/T and scattering batch, and a refill whose slots all got a history; a batch fresh
+      //  from a queue sits in lanes 0 .. k-1)
+      if (kChainMove && !TAIL) k_chain = (unsigned)__builtin_amdgcn_readfirstlane((int)k);   // served by this wave next: see the top of the loop
+      else if (kChainMove) held = act, dest = act ? (Q_MOVE | kChainFlag) : dest;            // ... as held lanes, in the kernels with a tail
+      else q_push_one(ctl, rings, rcap, rlog, Q_MOVE, lane, k, id);
+    }
     else q_push_all(ctl, rings, rcap, rlog, lane, act, dest, id);
     if constexpr (TAIL) {
-      if (!keep_lanes) held = false;
+      if (!keep_lanes && !(kChainMove && !was_held && ballot(held && (dest & kChainFlag) != 0))) held = false;
     }
 #ifdef R3D_PRIO_NARROW
     R3D_PRIO_LOW();
