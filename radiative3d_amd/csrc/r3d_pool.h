@@ -204,12 +204,16 @@ __device__ __forceinline__ uint32_t pool_collect_pairs(const KArgs& a, const Tab
                                                        const uint16_t* lds_items /* or null: a.grid.items */,
                                                        unsigned lane, uint32_t& lane_catches, const BinCache& bc) {
   const uint32_t cnt = k1 - k0;
+#if R3D_COLLECT_DPP
+  const uint32_t incl = wave_scan_add(cnt);   // inclusive prefix sum over the wave (r3d_wave.h: no LDS round trips)
+#else
   uint32_t incl = cnt;   // inclusive prefix sum over the wave
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const uint32_t y = __shfl_up(incl, off);
     if (lane >= (unsigned)off) incl += y;
   }
+#endif
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   const uint32_t excl = incl - cnt;
   V3 dopm = p.dir;
@@ -224,11 +228,27 @@ __device__ __forceinline__ uint32_t pool_collect_pairs(const KArgs& a, const Tab
   for (uint32_t base = 0; base < total; base += 64u) {
     const uint32_t j = base + lane;
     uint32_t src = 0;   // smallest lane whose inclusive sum exceeds j
+#if R3D_COLLECT_DPP
+    {
+      // Who owns pair j?  Every arrival whose range STARTS inside this pass's window of 64 pairs sends its lane number
+      // to the lane of the pair it starts at (one forward permute; every such lane has its own target: arrivals without
+      // candidates do not take part); all other lanes send the owner of the window's first pair, src0, to lane 0 -- the
+      // same value from all of them --; a running maximum over the lanes then gives every pair its owner (owners ascend
+      // with the pairs).  One crossbar round trip and six data-parallel instructions where the bisection over the
+      // prefix sums took six dependent round trips.
+      const uint32_t src0 = (uint32_t)__popcll(ballot(incl <= base));   // first lane whose inclusive sum exceeds `base`
+      const int pos = (int)excl - (int)base;
+      const bool starts = cnt != 0u && pos > 0 && pos < 64;
+      const uint32_t mark = (uint32_t)__builtin_amdgcn_ds_permute((starts ? pos : 0) << 2, (int)((starts ? lane : src0) + 1u));
+      src = wave_scan_max(mark) - 1u;
+    }
+#else
 #pragma unroll
     for (uint32_t step = 32u; step; step >>= 1) {
       const uint32_t v = (uint32_t)__shfl((int)incl, (int)(src + step - 1u));
       if (v <= j) src += step;
     }
+#endif
     const bool valid = j < total;
     src = valid ? src : lane;
     const uint32_t k = (uint32_t)__shfl((int)k0, (int)src) + (j - (uint32_t)__shfl((int)excl, (int)src));
@@ -328,6 +348,14 @@ constexpr int kKeepersWord = 7;   // PoolCtl::word[kKeepersWord]: waves that kee
 // hand-off and the move reads it back).
 #ifndef R3D_POOL_CHAIN_MOVE
 #define R3D_POOL_CHAIN_MOVE 2
+#endif
+// The collection phase's prefix sum and pair-to-arrival map on data-parallel primitives (r3d_wave.h wave_scan_*) instead
+// of cross-lane fetches through the LDS crossbar.
+#ifndef R3D_COLLECT_DPP
+#define R3D_COLLECT_DPP 1
+#endif
+#ifndef R3D_POOL_CHAIN_COLLECT
+#define R3D_POOL_CHAIN_COLLECT 1
 #endif
 #ifndef R3D_POOL_CHAIN_REFILL
 #define R3D_POOL_CHAIN_REFILL 0
@@ -604,6 +632,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   constexpr int kChainFlag = 8;   // (above the queue numbers 0 .. Q_NUM - 1)
   // ... and a refill whose slots all got a history: in the layered kernel only (the tetra and the shell kernel spill
   // 13-40 registers under it: their moves leave no room for the spray's values beside them)
+  constexpr bool kChainCollect = kChainMove && R3D_POOL_CHAIN_COLLECT != 0;
   constexpr bool kChainRefill = kChainMove && R3D_POOL_CHAIN_REFILL != 0 && KIND == CELL_CYL;
   bool held = false;
   unsigned k_chain = 0;   // (wave-uniform) slots of the batch just served that all want MOVE next and stay with this wave
@@ -631,8 +660,10 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       act = held;
       k = (unsigned)__popcll(held_m);
     } else if (kChainMove && !TAIL && k_chain) {
-      // ---- the batch this wave has just served (R/T or scattering): on to its move, in the same lanes ----
-      q = Q_MOVE, k = (unsigned)__builtin_amdgcn_readfirstlane((int)k_chain), act = lane < k;
+      // ---- the batch this wave has just served (R/T or scattering: on to its move; a collection all of whose
+      //      arrivals are reflected: on to that solve), in the same lanes; k_chain = slots | queue << 8 ----
+      const unsigned kc = (unsigned)__builtin_amdgcn_readfirstlane((int)k_chain);
+      q = (int)(kc >> 8), k = kc & 0xFFu, act = lane < k;
       k_chain = 0;
     } else {
       // ---- choose a queue: a full batch of a minor phase first (they all feed MOVE), then a
@@ -997,6 +1028,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #endif
     R3D_PRIO_HIGH();
     bool keep_lanes = false;   // (wave-uniform) this batch's slots stay with the wave
+    bool chain_set = false;    // (wave-uniform; kernels with a tail) ... as a chained batch: `held` was set for it below
     if constexpr (TAIL) {
       const bool alive = act && dest != Q_FREE;
       const unsigned long long alive_m = ballot(alive);
@@ -1023,16 +1055,20 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       if (any_lane(ended)) q_push_all(ctl, rings, rcap, rlog, lane, ended, Q_FREE, id);
       held = act && dest != Q_FREE;
       // (kept lanes sit in the wave's low lanes or anywhere: a phase only looks at `act`)
-    } else if (!was_held && (q == Q_RT || q == Q_SCATTER || (kChainRefill && q == Q_FREE && !any_lane(act && dest != Q_MOVE)))) {
+    } else if (kChainCollect && !was_kept && q == Q_COLLECT && k == 64u && !any_lane(act && dest != Q_RT)) {
+      // (a full collection batch whose arrivals are all reflected -- a free surface: every one of them --: its solve next)
+      if (!TAIL) k_chain = (unsigned)__builtin_amdgcn_readfirstlane((int)(k | ((unsigned)Q_RT << 8)));
+      else held = act, dest = act ? (Q_RT | kChainFlag) : dest, chain_set = true;
+    } else if (!was_kept && (q == Q_RT || q == Q_SCATTER || (kChainRefill && q == Q_FREE && !any_lane(act && dest != Q_MOVE)))) {
       // (all on to MOVE -- every R/T and scattering batch, and a refill whose slots all got a history; a batch fresh
-      //  from a queue sits in lanes 0 .. k-1)
-      if (kChainMove && !TAIL) k_chain = (unsigned)__builtin_amdgcn_readfirstlane((int)k);   // served by this wave next: see the top of the loop
-      else if (kChainMove) held = act, dest = act ? (Q_MOVE | kChainFlag) : dest;            // ... as held lanes, in the kernels with a tail
+      //  from a queue, or chained, sits in lanes 0 .. k-1)
+      if (kChainMove && !TAIL) k_chain = (unsigned)__builtin_amdgcn_readfirstlane((int)(k | ((unsigned)Q_MOVE << 8)));   // served by this wave next: see the top of the loop
+      else if (kChainMove) held = act, dest = act ? (Q_MOVE | kChainFlag) : dest, chain_set = true;   // ... as held lanes, in the kernels with a tail
       else q_push_one(ctl, rings, rcap, rlog, Q_MOVE, lane, k, id);
     }
     else q_push_all(ctl, rings, rcap, rlog, lane, act, dest, id);
     if constexpr (TAIL) {
-      if (!keep_lanes && !(kChainMove && !was_held && ballot(held && (dest & kChainFlag) != 0))) held = false;
+      if (!keep_lanes && !chain_set) held = false;
     }
 #ifdef R3D_PRIO_NARROW
     R3D_PRIO_LOW();

@@ -24,6 +24,29 @@ __device__ __forceinline__ bool any_lane(bool c) { return __builtin_amdgcn_ballo
 __device__ __forceinline__ unsigned rank_in(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
+// Inclusive scans over the wave's 64 lanes on the vector unit's data-parallel primitives (row shifts within rows of 16,
+// then the row broadcasts of this architecture): six instructions, no trip through the LDS crossbar -- a scan by
+// __shfl_up is six DEPENDENT ds_bpermute round trips, 300-400 cycles each behind the other waves' slot traffic.
+// (All 64 lanes must be active.)
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {   // (of non-negative values: the identity is 0)
+  auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+  return v;
+}
 __device__ __forceinline__ double bcast(double v, int src) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
