@@ -297,17 +297,21 @@ class DeviceVolume:
         dev = self.counters.device
         pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
         n_dev = torch.zeros(1, dtype=torch.int64, device=dev)
-        ends = []   # ends[o] = pairs written (or merely counted) once owner o's frames are compacted
+        # ends[o] = pairs written (or merely counted) once owner o's frames are compacted.  Kept ON THE DEVICE until the
+        # ranks' counts have been exchanged: one read-back for the whole reduction, not one per owner (N host
+        # synchronisations inside the timed region, serial in N)
+        ends_dev = torch.zeros(world, dtype=torch.int64, device=dev)
         for owner in range(world):
             if owner != rank:   # (this rank's own frames stay where they are)
                 for b, e in self._segments(*self.frame_range(owner, world)):
                     self._compact(b, e, pairs, n_dev, cap)
-            ends.append(int(n_dev.item()))
-        t1 = self._clock()
-        counts = torch.tensor([ends[o] - (ends[o - 1] if o else 0) for o in range(world)], dtype=torch.int64, device=dev)
+            ends_dev[owner:owner + 1] = n_dev
+        counts = ends_dev - torch.cat([ends_dev.new_zeros(1), ends_dev[:-1]])
         matrix = [torch.zeros_like(counts) for _ in range(world)]
         dist.all_gather(matrix, counts)                       # matrix[src][dst] = pairs src has for dst
-        matrix = torch.stack(matrix).cpu()
+        host = torch.cat([torch.stack(matrix).reshape(-1), ends_dev]).cpu()   # (the one read-back)
+        matrix, ends = host[:world * world].reshape(world, world), [int(v) for v in host[world * world:].tolist()]
+        t1 = self._clock()
         if int(matrix.sum(1).max().item()) > cap:             # (every rank sees the same matrix: one decision)
             self.timing["sparse_refused"] = f"{int(matrix.sum(1).max().item())} pairs on some rank, capacity {cap}"
             return False

@@ -655,6 +655,35 @@ def test_node_sums_the_shards_on_the_device_through_rccl(engines):
         Node(e.model, [0, 99])
 
 
+def test_production_finals_buffer_rules(engines):
+    """r3d_engine_set_production_finals: while a buffer is attached a launch whose ids it does not cover is refused
+    (the kernel indexes the buffer by the history id itself), it cannot be attached or detached while histories are
+    carried over, records never written say so (fate 255), and detaching restores the plain run."""
+    e = engines("halfspace")
+    buf = DeviceResult(e.model, "cuda:0")
+    e.set_production_finals(1000, 500)
+    with pytest.raises(RuntimeError, match="does not cover this launch's ids"):
+        e.run(10, first_id=990)
+    with pytest.raises(RuntimeError, match="does not cover this launch's ids"):
+        e.run(10, first_id=1495)
+    e.run(100, first_id=1200)
+    fin = e.production_finals(0, 500)
+    assert all(f.fate == 255 for f in fin[:200]) and all(f.fate in (1, 2, 3) for f in fin[200:300]) and all(f.fate == 255 for f in fin[300:])
+    with pytest.raises(RuntimeError, match="range beyond the buffer"):
+        e.production_finals(400, 200)
+    e.run_device(50, 1300, 5, *buf.pointers(), carry="carry")
+    torch.cuda.synchronize()
+    if e.carry_pending:
+        with pytest.raises(RuntimeError, match="carried over"):
+            e.set_production_finals(0, 0)
+    e.run_device(0, 0, 5, *buf.pointers(), carry="final")
+    torch.cuda.synchronize()
+    e.set_production_finals(0, 0)
+    with pytest.raises(RuntimeError, match="no production finals attached"):
+        e.production_finals(0, 1)
+    e.run(10, first_id=990)                                            # any ids again
+
+
 def test_run_device_rejects_unknown_carry_words_and_keeps_launch_ids_in_step(engines):
     e = engines("halfspace")
     buf = DeviceResult(e.model, "cuda:0")

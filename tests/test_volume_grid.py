@@ -263,3 +263,43 @@ def test_grids_of_one_process_reduced_by_frame_through_the_c_abi(models):
         reduce_volumes_by_frame([engines[0], engines[0]])
     for e in engines + [bare]:
         e.close()
+
+
+@pytest.mark.gpu
+def test_a_grid_too_full_for_its_pairs_fails_before_anything_is_added(models):
+    """r3d_volume_reduce_by_frame counts first and modifies second: when one engine's non-zero cells in the other owners'
+    frames exceed its pair buffer (a sixteenth of the grid), the call fails with EVERY grid as it was -- including the
+    owners that an earlier, fitting source would already have added its pairs to (the round-4 form did add them)."""
+    import torch
+    from radiative3d_amd import Engine
+    from radiative3d_amd.model import reduce_volumes_by_frame
+    m = models("crustpinch", 4, VIDEO)
+    small = dict(origin=(-200.0, -600.0, -130.0), cell_size=(80.0, 80.0, 35.0), dims=(16, 15, 4), n_frames=12, frame_dt=30.0)
+    cells = 2 * 12 * 4 * 15 * 16
+    engines, bufs = [], []
+    for r in range(3):
+        e = Engine(m)
+        buf = torch.zeros(cells, dtype=torch.int32, device="cuda:0")
+        e.set_volume_buffer(counters=buf, **small)
+        engines.append(e), bufs.append(buf)
+    bufs[0][::97] = 3                    # source 0: a few pairs, they fit
+    bufs[1][:] = 1                       # source 1: every cell -- two thirds of the grid against room for a sixteenth
+    bufs[2][::29] = 2
+    before = [b.clone() for b in bufs]
+    with pytest.raises(RuntimeError, match="engine 1 is too full for the pair buffer.*no grid has been modified"):
+        reduce_volumes_by_frame(engines)
+    for b, want in zip(bufs, before):
+        assert torch.equal(b, want)
+    bufs[1].zero_()
+    bufs[1][1::89] = 7                   # now everything fits: the reduction goes through and adds up
+    want = (before[0].long() + bufs[1].long() + before[2].long())
+    frames, sat = reduce_volumes_by_frame(engines)
+    fc = 4 * 15 * 16
+    for g in range(3):
+        for t in range(2):
+            lo, hi = (t * 12 + frames[g]) * fc, (t * 12 + frames[g + 1]) * fc
+            assert torch.equal(bufs[g][lo:hi].long(), want[lo:hi]), (g, t)
+    assert sat == 0
+    for e in engines:
+        e.detach_volume()
+        e.close()
