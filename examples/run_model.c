@@ -30,10 +30,25 @@ int main(int argc, char** argv) {
   memset(&res, 0, sizeof res);
   res.energy = (double*)calloc(bins ? bins * R3D_N_ENERGY : 1, sizeof(double));
   res.counts = (uint64_t*)calloc(bins ? bins * R3D_N_COUNT : 1, sizeof(uint64_t));
-  if (r3d_run_model(d, r3dh_num_phonons(m), 0, r3dh_seed(m), n_gpus, &res)) {
+  /* a node: one engine per device, kept for as many runs as the host wants; the shards' blocks are summed on the
+   * devices (RCCL) and read once (r3d_run_model(d, n, 0, seed, n_gpus, &res) is this in one call) */
+  int devices[64];
+  if (n_gpus < 1 || n_gpus > 64) {
+    fprintf(stderr, "N_GPUS must be 1 .. 64\n");
+    return 2;
+  }
+  for (int g = 0; g < n_gpus; g++) devices[g] = g;
+  r3d_node* node = r3d_node_create(d, devices, n_gpus);
+  if (!node) {
+    fprintf(stderr, "node: %s\n", r3d_last_error());
+    return 1;
+  }
+  if (r3d_node_run(node, r3dh_num_phonons(m), 0, r3dh_seed(m), &res)) {
     fprintf(stderr, "run: %s\n", r3d_last_error());
     return 1;
   }
+  printf("shards: %d (summed by %s)\n", r3d_node_size(node), r3d_node_reduction(node));
+  r3d_node_destroy(node);
   char trace[1024];
   snprintf(trace, sizeof trace, "%s/seis_traces_asc.dat", outdir);
   const char* summary = r3dh_write_outputs(m, &res, outdir, trace, NULL);
