@@ -655,6 +655,61 @@ def test_node_sums_the_shards_on_the_device_through_rccl(engines):
         Node(e.model, [0, 99])
 
 
+@pytest.mark.parametrize("name,per_launch", [("crustpinch", 150_000), ("lopnor", 150_000), ("sphere_deep", 120_000)])
+def test_histories_that_lived_in_the_chain_step_kernel_end_with_the_oracles_records(engines, name, per_launch):
+    """The chain-step kernel -- the code object the headline is measured on -- carries no final-record code (it cost that
+    kernel 3.5 %).  Its per-history work is witnessed through the histories it hands on: four step launches that together
+    bring more histories than the pool has slots (262 144), so that the later launches run for real -- histories move,
+    scatter, reflect and END inside step kernels to make room --, and the quarter of a million still in flight at the
+    end are finished by the drain kernel, which writes their records.  Every one of those records -- positions, times,
+    path lengths, move counts of histories that spent most of their moves in step kernels -- must be the oracle's."""
+    e = engines(name)
+    n = 4 * per_launch
+    first, seed = 50_000_000, 0xBEEF
+    # Times and path lengths: 1e-9 relative, as everywhere -- except the whole-Earth shells, 1e-8.  The engine's shell move
+    # is the local form (good to rounding); the oracle's is the reference's construction, whose arc lengths are good to
+    # ~1e-11 of the arc's RADIUS (tests/test_face_filter.py `dev_over_R`), and a steep ray's radius reaches 1e6 km: a
+    # history that bounces up and down 170 times ends 4e-9 of its 50 000 km from the oracle's record (2 of these 60 000
+    # pass 1e-9; none passes 5e-9).  Integer fields -- fate, type, moves -- are exact: no history forks.
+    rtol = 1e-8 if name == "sphere_deep" else 1e-9
+    e.set_production_finals(first, n)
+    total = DeviceResult(e.model, "cuda:0")
+    for k in range(4):
+        e.run_device(per_launch, first + k * per_launch, seed, *total.pointers(), carry="carry")
+    torch.cuda.synchronize()
+    assert e.carry_pending
+    e.run_device(0, 0, seed, *total.pointers(), carry="final")
+    torch.cuda.synchronize()
+    got = total.to_result()
+    assert got.events["generated"] == n and got.n_lost + got.n_timeout + got.n_invalid == n
+    mine = e.production_finals(0, n)
+    e.set_production_finals(0, 0)
+    written = [i for i in range(n) if mine[i].fate != 255]
+    assert 100_000 < len(written) < n - 100_000, len(written)        # the drain finished many; step kernels finished many too
+    # (the oracle on the written histories only, in runs of consecutive ids)
+    differ, checked = [], 0
+    # group consecutive indices
+    runs, start, prev = [], written[0], written[0]
+    for i in written[1:]:
+        if i != prev + 1:
+            runs.append((start, prev + 1))
+            start = i
+        prev = i
+    runs.append((start, prev + 1))
+    # the oracle is a scalar program (~3e4 histories/s): a sample of the runs, 60 000 histories at most
+    budget = 60_000
+    for lo, hi in runs:
+        if budget <= 0:
+            break
+        hi = min(hi, lo + budget)
+        _, want = O.run(e.model, hi - lo, first + lo, seed, trace=True)
+        differ += [first + lo + j for j in range(hi - lo) if production_finals_differ(mine[lo + j], want[j], rtol)]
+        checked += hi - lo
+        budget -= hi - lo
+    assert checked >= 20_000, checked
+    assert not differ, f"{name}: {len(differ)} of {checked} records of histories carried through step launches differ from the oracle: ids {differ[:20]}"
+
+
 def test_production_finals_buffer_rules(engines):
     """r3d_engine_set_production_finals: while a buffer is attached a launch whose ids it does not cover is refused
     (the kernel indexes the buffer by the history id itself), it cannot be attached or detached while histories are
