@@ -777,13 +777,23 @@ int r3d_node_run(r3d_node* nd, uint64_t n, uint64_t first_id, uint64_t seed, r3d
   if (!nd->comms.empty()) {
     // one grouped reduce per buffer, in stream order behind each shard's kernel: the sums land on devices[0]
     R3D_NCCL_OK(ncclGroupStart());
-    for (int g = 0; g < N; g++) {
+    ncclResult_t first_bad = ncclSuccess;   // (a call that fails inside the group must not leave the group open)
+    auto note = [&](ncclResult_t r) {
+      if (r != ncclSuccess && first_bad == ncclSuccess) first_bad = r;
+    };
+    for (int g = 0; g < N && first_bad == ncclSuccess; g++) {
       r3d_engine* e = nd->engines[g];
-      if (ne) R3D_NCCL_OK(ncclReduce(e->d_energy.p, g == 0 ? nd->sum_energy.p : nullptr, ne, ncclDouble, ncclSum, 0, nd->comms[g], e->stream));
-      if (nc) R3D_NCCL_OK(ncclReduce(e->d_counts.p, g == 0 ? nd->sum_counts.p : nullptr, nc, ncclUint64, ncclSum, 0, nd->comms[g], e->stream));
-      R3D_NCCL_OK(ncclReduce(e->d_scalars.p, g == 0 ? nd->sum_scalars.p : nullptr, R3D_N_SCALARS, ncclUint64, ncclSum, 0, nd->comms[g], e->stream));
+      DeviceGuard on(e->device);   // (each rank's calls with its own device current)
+      // (the receive buffer only means something on the root; the other ranks name their own block, in place)
+      if (ne) note(ncclReduce(e->d_energy.p, g == 0 ? nd->sum_energy.p : e->d_energy.p, ne, ncclDouble, ncclSum, 0, nd->comms[g], e->stream));
+      if (nc) note(ncclReduce(e->d_counts.p, g == 0 ? nd->sum_counts.p : e->d_counts.p, nc, ncclUint64, ncclSum, 0, nd->comms[g], e->stream));
+      note(ncclReduce(e->d_scalars.p, g == 0 ? nd->sum_scalars.p : e->d_scalars.p, R3D_N_SCALARS, ncclUint64, ncclSum, 0, nd->comms[g], e->stream));
     }
-    R3D_NCCL_OK(ncclGroupEnd());
+    note(ncclGroupEnd());
+    if (first_bad != ncclSuccess) {
+      (void)wait_all();
+      return g_error = std::string("r3d_node_run: the RCCL reduce failed: ") + ncclGetErrorString(first_bad), 1;
+    }
     if (wait_all()) return 1;
     R3D_ON_DEVICE(nd->devices[0]);
     if (ne) R3D_HIP_OK(hipMemcpy(he.data(), nd->sum_energy.p, ne * sizeof(double), hipMemcpyDeviceToHost));
