@@ -398,6 +398,85 @@ R3D_HD TetFast tet_fast_exit(const CellTet& c, const Phonon& p, TetLocal& L) {
   F.ok = lm_lane(good);
   return F;
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// The same search by FOUR LANES PER HISTORY (the drain of a launch: r3d_pool.h kQuad).  What a drain waits for is the
+// serial chain of its longest histories, served three or four lanes to a wave, and alone on a SIMD a wave issues an
+// instruction every ~8 cycles whatever its lanes do: the chain is the move's instruction count.  So the idle lanes
+// take a face each: the four lanes of a quad hold the SAME history (position, direction, cell record), lane f of the
+// quad evaluates face f -- the per-face arithmetic of tet_fast_exit, to the letter --, the four exits are exchanged
+// within the quad (data-parallel quad permutes: no LDS), and every lane finishes the search on all four as
+// tet_fast_exit does: same values in, same exit out, in all four lanes.  The certificate holds for the quad if it
+// holds for each of its faces.
+__device__ __forceinline__ double quad_lane_value(double v, int which) {   // lane `which` (0..3) of this lane's quad
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  int rl, rh;
+  switch (which) {   // (the permutation is part of the instruction)
+    case 0: rl = __builtin_amdgcn_mov_dpp(lo, 0x00, 0xf, 0xf, true), rh = __builtin_amdgcn_mov_dpp(hi, 0x00, 0xf, 0xf, true); break;
+    case 1: rl = __builtin_amdgcn_mov_dpp(lo, 0x55, 0xf, 0xf, true), rh = __builtin_amdgcn_mov_dpp(hi, 0x55, 0xf, 0xf, true); break;
+    case 2: rl = __builtin_amdgcn_mov_dpp(lo, 0xAA, 0xf, 0xf, true), rh = __builtin_amdgcn_mov_dpp(hi, 0xAA, 0xf, 0xf, true); break;
+    default: rl = __builtin_amdgcn_mov_dpp(lo, 0xFF, 0xf, 0xf, true), rh = __builtin_amdgcn_mov_dpp(hi, 0xFF, 0xf, 0xf, true); break;
+  }
+  return __hiloint2double(rh, rl);
+}
+__device__ __forceinline__ TetFast tet_fast_exit_quad(const CellTet& c, const V3 n, const double dpl, const Phonon& p, TetLocal& L) {
+  // (n, dpl: this lane's face of the record, read by the caller with the record -- a lane-indexed read of memory; picked
+  //  out of the register copy it becomes a table in scratch)
+  const V3 g = v3(c.g);
+  const double vel = dot(p.loc, g) + c.v0;
+  L.gd = dot(g, p.dir);
+  L.w = g - L.gd * p.dir;
+  L.m2 = mag2(L.w);
+  L.iw = frsqrt(L.m2);
+  L.R = vel * L.iw;
+  L.U = (L.R * L.iw) * L.w;
+  const double eR2 = kLocEpsC * (L.R * L.R + mag2(p.loc));
+  double my_tq;
+  LaneMask face_good;
+  {
+    const double h = dpl - dot(n, p.loc);
+    const double r = dot(n, p.dir);
+    const double M = dot(n, L.U);
+    const double P = L.R * r;
+    const double k = 2.0 * M + h;
+    const double P2 = P * P;
+    const double disc = P2 - h * k;
+    const LaneMask Dpos = lm(disc > eR2), Dneg = lm(disc < -eR2);
+    const double S = disc * frsqrt1(disc);
+    const bool fwd = P >= 0.0;
+    const double q = fwd ? P + S : P - S;
+    const double num = fwd ? h : q, den = fwd ? q : k;
+    const double t = num * frcp1(den);
+    const LaneMask Tpos = lm(t >= kLocEpsT), Tneg = lm(t <= -kLocEpsT);
+    const LaneMask inside = lm(h >= 0.0) | lm(h >= kLocTau * P);
+    face_good = (Dneg | (Dpos & (Tpos | Tneg))) & inside;
+    my_tq = lm_lane(Dpos & Tpos) ? t : kLocNone;
+  }
+  // a quad is good if its four faces are: bit 4j <- AND of bits 4j .. 4j+3, then spread back over the quad
+  LaneMask gq = face_good & (face_good >> 1);
+  gq = gq & (gq >> 2) & 0x1111111111111111ull;
+  gq = gq | (gq << 1);
+  gq = gq | (gq << 2);
+  LaneMask good = lm(L.R > 0.0) & gq;
+  double tq[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) tq[i] = quad_lane_value(my_tq, i);
+  TetFast F;
+  const double t01 = fmin(tq[0], tq[1]), t23 = fmin(tq[2], tq[3]);
+  const int f01 = tq[1] < tq[0] ? 1 : 0, f23 = tq[3] < tq[2] ? 3 : 2;
+  F.t = fmin(t01, t23);
+  F.face = t23 < t01 ? f23 : f01;
+  const double lim = F.t + kLocEpsT;
+  const LaneMask n0 = lm(tq[0] < lim), n1 = lm(tq[1] < lim), n2 = lm(tq[2] < lim), n3 = lm(tq[3] < lim);
+  const LaneMask tie = (n0 & n1) | (n2 & n3) | ((n0 | n1) & (n2 | n3));
+  const double inv = frcp(1.0 + F.t * F.t);
+  F.sn = (2.0 * F.t) * inv, F.omc = F.t * F.sn, F.cs = 1.0 - F.omc;
+  const double c0 = (L.m2 * L.iw) * c.inv_gmag, s0 = -L.gd * c.inv_gmag;
+  const double c1 = c0 * F.cs - s0 * F.sn;
+  good = lm_andnot(good, tie) & lm(F.t <= 1.0) & lm(c0 >= kLocKappa) & lm(c1 >= kLocKappa);
+  F.ok = lm_lane(good);
+  return F;
+}
+#endif
 // th = 2 atan(t) for the exit's t = tan(th / 2) in (0, 1]; (sn, cs) its sine and cosine.  A tetra leg spans a
 // fraction of a degree in a gently graded model: the Maclaurin series through t^13 when every lane has
 // t <= 1/16 (next term t^14 / 15: 1e-18 relative); else the general routine on (sn, cs).

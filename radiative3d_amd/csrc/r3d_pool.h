@@ -354,6 +354,13 @@ constexpr int kKeepersWord = 7;   // PoolCtl::word[kKeepersWord]: waves that kee
 #ifndef R3D_COLLECT_DPP
 #define R3D_COLLECT_DPP 1
 #endif
+// The drain's kept histories four lanes each in the tetra move (the MOVE phase below, kQuad; r3d_physics.h
+// tet_fast_exit_quad): a drain is its longest history's instruction chain at ONE wave's issue rate, with 3-4 of the wave's
+// 64 lanes alive, so the idle lanes take a face of the boundary search each.  A lone NSCP history 3.06 -> 2.95 us per
+// move, flush 4.2 -> 3.8 ms, the literal 1e7 job 12.0 -> 11.9 ms (same-call A/B); results equal, face for face.
+#ifndef R3D_POOL_QUAD_DRAIN
+#define R3D_POOL_QUAD_DRAIN 1
+#endif
 #ifndef R3D_POOL_CHAIN_COLLECT
 #define R3D_POOL_CHAIN_COLLECT 1
 #endif
@@ -632,6 +639,8 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   constexpr int kChainFlag = 8;   // (above the queue numbers 0 .. Q_NUM - 1)
   // ... and a refill whose slots all got a history: in the layered kernel only (the tetra and the shell kernel spill
   // 13-40 registers under it: their moves leave no room for the spray's values beside them)
+  // the drain's kept lanes four to a history (tetra cells; not in the diagnostic kernel, whose report stream is per lane)
+  constexpr bool kQuad = TAIL && !TRACE && KIND == CELL_TET && R3D_POOL_QUAD_DRAIN != 0;
   constexpr bool kChainCollect = kChainMove && R3D_POOL_CHAIN_COLLECT != 0;
   constexpr bool kChainRefill = kChainMove && R3D_POOL_CHAIN_REFILL != 0 && KIND == CELL_CYL;
   bool held = false;
@@ -811,6 +820,28 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       uint32_t meta = 0, nbr0 = 0;
       int fate = FATE_ALIVE, reason = 0;
       uint64_t hid = 0;
+      // The drain's kept lanes, four lanes to a history (kQuad): the k <= 16 kept slots are spread over the wave,
+      // history j onto lanes 4j .. 4j+3; all four lanes load the slot's state and run the move -- the same values in
+      // every lane of a quad -- except that the boundary search's four faces are one lane's each
+      // (r3d_physics.h tet_fast_exit_quad).  Lane 4j leads: it alone counts, stores and hands the slot on.
+      bool quad = false;    // (wave-uniform)
+      bool lead = true;
+      unsigned fl = 0u;
+      if constexpr (kQuad) {
+        quad = was_kept && k <= 16u;
+        if (quad) {
+          unsigned long long hm = held_m;
+          unsigned qid = 0u;
+          for (unsigned j = 0; j < k; j++) {   // (wave-uniform: at most sixteen rounds of scalar work)
+            const int src = __ffsll((long long)hm) - 1;
+            hm &= hm - 1ull;
+            const unsigned sid = (unsigned)__builtin_amdgcn_readlane((int)id, src);
+            qid = (lane >> 2) == j ? sid : qid;
+          }
+          id = qid, act = (lane >> 2) < k, fl = lane & 3u, lead = fl == 0u;
+          dest = act ? Q_FREE : dest;
+        }
+      }
       bool live = act;   // still moving in registers
       if (act) {
         load_state(id, p, rng, meta, nbr0);
@@ -824,9 +855,10 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         Pending ev;
         ev.vel = 0.0, ev.face = -1, ev.flags = 0u, ev.nbr = -1;
         bool leaving = false;
-        LaneStats st = {0, 0, 0, 0, 0, 0, 0, 0};
+        LaneStats st = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (kQuad) st.quiet = (quad && !lead) ? 1u : 0u;
         if (live) {
-          fate = step_move<KIND>(a, T, p, rng, st, &reason, ev);
+          fate = step_move<KIND, kQuad>(a, T, p, rng, st, &reason, ev, quad, fl);
           leaving = true;
           if (fate != FATE_ALIVE) {
             dest = Q_FREE;
@@ -848,8 +880,8 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
           report(st.reflect != 0u, 2, p, hid);    // REF
           report(st.transfer != 0u, 4, p, hid);   // CEL
         }
-        n_iter += count(st.iterations != 0u), n_transfer += count(st.transfer != 0u), n_reflect += count(st.reflect != 0u);
-        if (a.vol) n_volout += count(st.vol_out != 0u);
+        n_iter += count(lead && st.iterations != 0u), n_transfer += count(lead && st.transfer != 0u), n_reflect += count(lead && st.reflect != 0u);
+        if (a.vol) n_volout += count(lead && st.vol_out != 0u);
         live = light;
         const unsigned n_live = (unsigned)__popcll(ballot(live));
         // a full batch goes on while most of its lanes can (the others' slots are wanted by the
@@ -862,7 +894,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         if (lane == 0) atomicAdd(&s_stats[0][7], 1ull), atomicAdd(&s_stats[1][7], (unsigned long long)(n_live));
 #endif
         if (last && live) dest = Q_MOVE;
-        if (leaving || (last && live)) {
+        if ((leaving || (last && live)) && lead) {
           const bool keep = dest != Q_FREE;   // (a history that ended leaves nothing to keep)
           if (keep) {
             store_state(id, p, rng, meta_pack(p.type, dest == Q_MOVE ? -1 : ev.face, dest == Q_MOVE ? 0u : ev.flags, dest));
@@ -873,6 +905,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         }
         if (last) break;
       }
+      if (kQuad) act = act && lead;   // (the helpers' work is done: the leaders hand the slots on)
       const bool died = act && dest == Q_FREE;
       finish(died, fate, reason, p, hid, (TRACE && died) ? pu[U_ID * F + id].c : 0u, id);
     } else if (q == Q_COLLECT) {
@@ -927,7 +960,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
         }
       }
       const bool light = act && dest == Q_MOVE;
-      LaneStats st = {0, 0, 0, 0, 0, 0, 0, 0};
+      LaneStats st = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       if (light) step_event<KIND, EV_BEND>(a, T, p, rng, st, ev, (int)nbr);
       if (TRACE) {
         report(st.reflect != 0u, 2, p, hid);    // REF
@@ -950,7 +983,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       Rng rng;
       uint32_t meta = 0, nbr = 0;
       uint64_t hid = 0;
-      LaneStats st = {0, 0, 0, 0, 0, 0, 0, 0};
+      LaneStats st = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       if (act) {
         load_state(id, p, rng, meta, nbr);
 #ifndef R3D_PRIO_NARROW

@@ -59,6 +59,7 @@ template <> struct CellOf<CELL_SPH> { using type = CellSph; };
 struct LaneStats {
   uint32_t iterations, scatter, collect, n_catch, reflect, transfer, rtsolve;
   uint32_t vol_out;   // SCT / REF events outside an attached event grid (r3d_result.events[R3D_EV_VOLUME_OUT])
+  uint32_t quiet;     // this lane only helps another lane's history along (r3d_pool.h kQuad): it leaves no mark in the grid
 };
 
 // Where the step finds its tables (pointers may be LDS or HBM).
@@ -239,7 +240,7 @@ R3D_HD void volume_count(const KArgs& a, const Phonon& p, LaneStats& st) {
   }
   const size_t idx = ((((size_t)p.type * a.vol_frames + (size_t)f) * a.vol_dim[2] + (size_t)z) *
                           a.vol_dim[1] + (size_t)y) * a.vol_dim[0] + (size_t)x;
-  R3D_ADD_U32(a.vol + idx, 1u);
+  if (!st.quiet) R3D_ADD_U32(a.vol + idx, 1u);
 }
 
 // ---- one loop iteration, in two halves --------------------------------------
@@ -255,9 +256,11 @@ struct Pending {
 // free-path draw, advance + Move.  Returns FATE_ALIVE to continue with
 // step_event(), else the fate; *reason gets the invalid-reason slot
 // (include/r3d.h R3D_INV_*) when FATE_INVALID.
-template <int KIND>
+// QUAD (device, tetra, the kernels with a tail): when `quad` holds -- wave-uniform -- the four lanes of a quad carry the
+// same history and share its boundary search, lane `fl` of the quad taking face `fl` (r3d_physics.h tet_fast_exit_quad).
+template <int KIND, bool QUAD = false>
 R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng, LaneStats& st,
-                     int* reason, Pending& ev) {
+                     int* reason, Pending& ev, bool quad = false, unsigned fl = 0u) {
   using Cell = typename CellOf<KIND>::type;
   // phonons.cpp:549-552
   if (p.t > a.ttl) return FATE_TIMEOUT;
@@ -281,6 +284,13 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
   // other waves' slot traffic), eight times a move.
   using CellHere = const Cell;
   CellHere c = cell_rec<KIND>(T, p.cell, p.type);
+#if defined(__HIP_DEVICE_COMPILE__)
+  V3 quad_n = v3(0, 0, 0);
+  double quad_d = 0;
+  if constexpr (QUAD && KIND == CELL_TET) {
+    if (quad) quad_n = v3(cell_rec<KIND>(T, p.cell, p.type).n[fl]), quad_d = cell_rec<KIND>(T, p.cell, p.type).d[fl];
+  }
+#endif
   R3D_SCHED_FENCE();   // (the loads above, THEN the draw: left to itself the scheduler puts the draw first)
   // The move's one uniform (for the free path, below) is drawn here: it depends on nothing, and
   // its hundred integer instructions fill the wait for the cell record, which everything else
@@ -315,7 +325,12 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
     e.len = 0.0, scatters = false;
     {
       TetLocal L;
-      const TetFast F = tet_fast_exit(c, p, L);
+      TetFast F;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (QUAD && quad) F = tet_fast_exit_quad(c, quad_n, quad_d, p, L);
+      else
+#endif
+        F = tet_fast_exit(c, p, L);
       slow = !F.ok;
       e.face = F.face;
       if (!slow) {

@@ -31,7 +31,7 @@ static void run_kind(const KArgs& a, uint64_t n, uint64_t first_id, uint64_t see
   for (uint64_t i = 0; i < n; i++) {
     Phonon p;
     Rng rng;
-    LaneStats st = {0, 0, 0, 0, 0, 0, 0, 0};
+    LaneStats st = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     rng_init(rng, first_id + i);
     spray(a, p, rng);
     out->events[R3D_EV_GENERATED]++;
