@@ -39,6 +39,10 @@ if REPO not in sys.path:
 
 # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 HBM_PEAK_GBS = 8000.0
+# What the chip delivers in RANDOM 64-byte sectors from a table of GBs (tools/microbench/hbm_gather.hip, recorded in
+# profiles/r05/hbm_gather.log: 51.2 G sectors/s at 12, 16 or 32 waves per CU, 1 to 8 fetches in flight per lane): the
+# bound of the table look-ups (take-off spray, scattering), which read one sector per fetch.
+HBM_GATHER_PEAK_GBS = 3280.0
 N_SIMD = 256 * 4
 MAX_CLOCK_GHZ = 2.4
 PROFILE_ROUND = "r05"
@@ -539,7 +543,9 @@ def main():
                 "hbm": {"bytes_per_launch": traffic,
                         "GBps": traffic / (avg_step_ms * 1e-3) / 1e9 if traffic else None,
                         "frac_of_peak": traffic / (avg_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
-                        "peak_GBps": HBM_PEAK_GBS, "source": rec_path}})
+                        "peak_GBps": HBM_PEAK_GBS,
+                        "frac_of_gather_peak": traffic / (avg_step_ms * 1e-3) / 1e9 / HBM_GATHER_PEAK_GBS if traffic else None,
+                        "gather_peak_GBps": HBM_GATHER_PEAK_GBS, "source": rec_path}})
         else:
             roofline.update({"achieved": None, "peak": N_SIMD * MAX_CLOCK_GHZ, "unit": "G SIMD-cycles/s",
                              "frac": None, "traffic": None, "counters": f"none ({why_not}: {rec_path})"})
