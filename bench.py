@@ -128,6 +128,13 @@ def phase_floor(ev, cell_kind):
     return {"per_history": sum(terms.values()), "by_term": terms, "per_event": {"move": move, **{k: v[k] for k in v if not k.startswith("move_")}}}, rel, None
 
 
+def ta_busy(rec):
+    try:
+        return rec["counters"]["TA_TA_BUSY_sum"]["mean_per_step_launch"] / (256.0 * rec["GRBM_GUI_ACTIVE"] / 8.0)
+    except (KeyError, TypeError, ZeroDivisionError):
+        return None
+
+
 def kernel_source_hash(csrc=None):
     """sha256 over the traversal kernel's code, its launch geometry and build flags: what the recorded
     counters are keyed by.  Comments and white space do not count (a reworded comment leaves the machine
@@ -540,6 +547,10 @@ def main():
                 # what one history costs in lane-instructions (falls when instructions are removed; frac does not)
                 "valu_lane_insts_per_history": rec["SQ_INSTS_VALU"] * 64.0 * rec["lane_activity"] / n
                 if rec.get("lane_activity") and rec.get("SQ_INSTS_VALU") else None,
+                # the texture addressers' busy share of a step launch (TA_TA_BUSY_sum over 256 units x the launch's cycles):
+                # a 64-lane gather costs the unit ~48 cycles whatever its width, and the tetra kernel's cell records
+                # (twelve 16-byte gathers a move) keep it busier than the vector unit
+                "ta_busy": ta_busy(rec),
                 "hbm": {"bytes_per_launch": traffic,
                         "GBps": traffic / (avg_step_ms * 1e-3) / 1e9 if traffic else None,
                         "frac_of_peak": traffic / (avg_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
