@@ -3,6 +3,8 @@
 //   mode 0: every lane its own random record (the traversal's cell-record fetch)
 //   mode 1: the four lanes of a quad read the four 16-byte quarters of ONE 64-byte line (16 lines / instruction)
 //   mode 2: all lanes the same record (broadcast)
+//   mode 3: twelve consecutive lanes read the twelve 16-byte pieces of ONE 192-byte record (five records / instruction)
+//   mode 4: sixteen consecutive lanes read sixteen consecutive 16-byte pieces (256 bytes) of one record (four / instruction)
 // Records live in a table of `ncell` x `rec` bytes (L2-resident for the sizes of interest).
 // Output: ns per load instruction per CU at 12 waves / CU (the traversal's occupancy).
 #include <hip/hip_runtime.h>
@@ -21,11 +23,13 @@ __global__ __launch_bounds__(768) void gather(const uint32_t* __restrict__ table
     uint32_t r = idx[(h >> 8) & 0xFFFFu];
     if (mode == 2) r = __builtin_amdgcn_readfirstlane(r);
     if (mode == 1) r = __shfl(r, lane & ~3u);
-    const uint32_t* p = table + (size_t)r * rec_dwords + (mode == 1 ? (lane & 3u) * 4u : 0u);
+    if (mode == 3) r = __shfl(r, (lane / 12u) * 12u);
+    if (mode == 4) r = __shfl(r, lane & ~15u);
+    const uint32_t* p = table + (size_t)r * rec_dwords + (mode == 1 ? (lane & 3u) * 4u : mode == 3 ? (lane % 12u) * 4u : mode == 4 ? (lane & 15u) * 4u : 0u);
     typedef uint32_t vec __attribute__((ext_vector_type(W)));
     vec v[NL];
 #pragma unroll
-    for (int k = 0; k < NL; k++) v[k] = *reinterpret_cast<const vec*>(p + k * (mode == 1 ? 16 : W));
+    for (int k = 0; k < NL; k++) v[k] = *reinterpret_cast<const vec*>(p + k * (mode == 1 ? 16 : mode >= 3 ? 0 : W));
 #pragma unroll
     for (int k = 0; k < NL; k++) acc += (double)v[k][0];
     h ^= (uint32_t)acc;
@@ -64,7 +68,7 @@ int main(int argc, char** argv) {
            name, rec_bytes, mode, ms, ms * 1e6 / instr_per_cu, ms * 1e6 / instr_per_cu * 2.4, ms * 1e6 / (12.0 * iters));
   };
   printf("%d CUs, table of %d records\n", cus, ncell);
-  for (int mode = 0; mode < 3; mode++) {
+  for (int mode = 0; mode < 5; mode++) {
     run("16 x dwordx4 (256-B record)", gather<16, 4>, 16, 256, mode);
     run("12 x dwordx4 (192-B record)", gather<12, 4>, 12, 192, mode);
     run(" 8 x dwordx4 (128-B record)", gather<8, 4>, 8, 128, mode);
