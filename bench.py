@@ -551,7 +551,8 @@ def main():
                 # a 64-lane gather costs the unit ~48 cycles whatever its width, and the tetra kernel's cell records
                 # (twelve 16-byte gathers a move) keep it busier than the vector unit
                 "ta_busy": ta_busy(rec),
-                # which of the two units is the busier one for this workload (at the recorded launch time), and its share
+                # which of the two units is the busier one for this workload (at the recorded launch time), and its share -- occupancies,
+                # not proofs of a bound: a sixth fewer gathers did not shorten the NSCP launch
                 "binding": "texture addresser" if (ta_busy(rec) or 0.0) > (rec.get("valu_busy") or 0.0) else "vector issue",
                 "binding_busy": max(ta_busy(rec) or 0.0, rec.get("valu_busy") or 0.0),
                 "hbm": {"bytes_per_launch": traffic,
