@@ -39,6 +39,10 @@ HOST_HDR := $(wildcard $(HOSTDIR)/*.hpp) include/r3d.h include/r3d_host.h
 ENGINE_SRC := $(CSRC)/r3d_engine.hip $(CSRC)/r3d_tables_build.hip $(CSRC)/r3d_kernels_kind.hip $(CSRC)/r3d_volume.hip
 ENGINE_HDR := $(wildcard $(CSRC)/*.h) include/r3d.h
 OBJDIR   := build/obj
+
+# (the default goal is the first target of the file: it has to come before the generated object rules)
+.PHONY: default all host engine repro oracle cli clean
+default: all
 # engine_objects(tag, extra flags): the six objects of one engine build
 define engine_objects
 $(OBJDIR)/$(1)_engine.o: $(CSRC)/r3d_engine.hip $(ENGINE_HDR)
@@ -64,8 +68,6 @@ engine_objs = $(OBJDIR)/$(1)_engine.o $(OBJDIR)/$(1)_tables.o $(OBJDIR)/$(1)_vol
 $(eval $(call engine_objects,main,))
 $(eval $(call engine_objects,repro,-DR3D_REPRODUCIBLE -ffp-contract=off))
 
-.PHONY: default all host engine repro oracle cli clean
-default: all
 all: host engine repro oracle cli
 
 host: $(LIBDIR)/libr3d_host.so

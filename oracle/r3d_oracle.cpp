@@ -694,36 +694,22 @@ void rt_coefs_sh(RT& r) {
   r.prob[T_SH] = rho2 * b2 * r.coso[T_SH].real() * std::norm(at);
 }
 
-// Phonon::Refraction_FullRT, phonons.cpp:429-476, with CellFace::GetRTBasis
-// (media_cellface.cpp:122-149) and the RTCoef chooser (rtcoef.cpp:406-588).
-void refraction_full_rt(Ctx& c, Phonon& p, int face_idx) {
-  const r3d_model_desc& m = *c.m;
-  const r3d_cell& cell = m.cells[p.cell];
-  const r3d_face& f = cell.faces[face_idx];
-  c.out->events[R3D_EV_RTSOLVE]++;
-  double u_pol, u_out;   // the event's two uniforms (philox.h: one block)
-  draw_pair(c, u_pol, u_out);
+// The event on a prepared interface (media, normal, no_transmit set): everything of Phonon::Refraction_FullRT
+// (phonons.cpp:429-476) after CellFace::GetRTBasis -- the basis vectors, ChooseSPolType, GetCoefs, Choose and the chosen
+// ray (rtcoef.cpp:406-588).  Returns true if the ray is transmitted; *margin (if asked for): how far the outcome draw
+// was from the nearest partial sum, as a fraction of the total.
+bool rt_event_core(RT& r, Phonon& p, double u_pol, double u_out, int* choice_out = nullptr, double* margin = nullptr,
+                   double* pol_margin = nullptr) {
   V dir = from_angles(p.theta, p.phi);
-  RT r;
-  r.no_transmit = false;
-  r.fnorm = face_normal(m, f, face_idx, p.loc);
   r.fpara = in_plane_unit_perp(r.fnorm, dir);
   r.fparash = cross(r.fnorm, r.fpara);
   r.sini = dot(r.fpara, dir);
-  r.rhoR = density_at(m, cell, p.loc);
-  r.velR[0] = velocity_at(m, cell, p.loc, 0), r.velR[1] = velocity_at(m, cell, p.loc, 1);
-  if (f.flags & R3D_FACE_ADJOIN) {
-    const r3d_cell& o = m.cells[f.neighbor];
-    r.rhoT = density_at(m, o, p.loc);
-    r.velT[0] = velocity_at(m, o, p.loc, 0), r.velT[1] = velocity_at(m, o, p.loc, 1);
-  } else {  // free surface emulated by a vanishing medium
-    r.rhoT = 0.0, r.velT[0] = r.velT[1] = 1e-12, r.no_transmit = true;
-  }
   enum { IN_P, IN_SH, IN_SV } intype = IN_P;
   if (p.type == R3D_RAY_S) {  // ChooseSPolType, rtcoef.cpp:406-422
     double shfrac = dot(direction_of_motion(p), r.fparash);
     shfrac *= shfrac;
     intype = (u_pol <= shfrac) ? IN_SH : IN_SV;
+    if (pol_margin) *pol_margin = std::fabs(u_pol - shfrac);
   }
   switch (intype) {  // GetCoefs, rtcoef.cpp:76-97
     case IN_P: r.defchoice = R_P, rt_coefs_psv(r, true); break;
@@ -742,12 +728,21 @@ void refraction_full_rt(Ctx& c, Phonon& p, int face_idx) {
       choice = i;
       break;
     }
-  if (total == 0 || (total - total) != 0) choice = r.defchoice;
+  if (margin) {
+    *margin = 1.0;
+    for (int i = 0; i < RT_NUM - 1; i++)
+      if (r.prob[i] != 0 || i == 0) *margin = std::min(*margin, std::fabs(ran - PI_[i]) / total);
+  }
+  if (total == 0 || (total - total) != 0) {
+    choice = r.defchoice;
+    if (margin) *margin = 1.0;
+  }
   if (r.no_transmit) {
     if (choice == T_P) choice = R_P;
     if (choice == T_SV) choice = R_SV;
     if (choice == T_SH) choice = R_SH;
   }
+  if (choice_out) *choice_out = choice;
   const bool reflected = (choice == R_P || choice == R_SV || choice == R_SH);
   // GetChosenRayDirection, rtcoef.cpp:529-548
   double comp_para = r.sino[choice], comp_norm = r.coso[choice].real();
@@ -763,7 +758,31 @@ void refraction_full_rt(Ctx& c, Phonon& p, int face_idx) {
     else dopm = cross(r.fparash, outdir);
     p.pol = std::atan2(dot(dopm, phi_hat_s2(p.phi)), dot(dopm, theta_hat_s2(p.theta, p.phi)));
   }
-  if (!reflected) p.cell = f.neighbor;  // InsertInto, phonons.cpp:494-502
+  return !reflected;
+}
+
+// Phonon::Refraction_FullRT, phonons.cpp:429-476, with CellFace::GetRTBasis
+// (media_cellface.cpp:122-149) and the RTCoef chooser (rtcoef.cpp:406-588).
+void refraction_full_rt(Ctx& c, Phonon& p, int face_idx) {
+  const r3d_model_desc& m = *c.m;
+  const r3d_cell& cell = m.cells[p.cell];
+  const r3d_face& f = cell.faces[face_idx];
+  c.out->events[R3D_EV_RTSOLVE]++;
+  double u_pol, u_out;   // the event's two uniforms (philox.h: one block)
+  draw_pair(c, u_pol, u_out);
+  RT r;
+  r.no_transmit = false;
+  r.fnorm = face_normal(m, f, face_idx, p.loc);
+  r.rhoR = density_at(m, cell, p.loc);
+  r.velR[0] = velocity_at(m, cell, p.loc, 0), r.velR[1] = velocity_at(m, cell, p.loc, 1);
+  if (f.flags & R3D_FACE_ADJOIN) {
+    const r3d_cell& o = m.cells[f.neighbor];
+    r.rhoT = density_at(m, o, p.loc);
+    r.velT[0] = velocity_at(m, o, p.loc, 0), r.velT[1] = velocity_at(m, o, p.loc, 1);
+  } else {  // free surface emulated by a vanishing medium
+    r.rhoT = 0.0, r.velT[0] = r.velT[1] = 1e-12, r.no_transmit = true;
+  }
+  if (rt_event_core(r, p, u_pol, u_out)) p.cell = f.neighbor;  // InsertInto, phonons.cpp:494-502
 }
 
 // Phonon::Refraction_Bend, phonons.cpp:311-405
@@ -1058,6 +1077,29 @@ void r3d_oracle_rt_probs(double rho1, double a1, double b1, double rho2, double 
   else if (intype == 1) rt_coefs_sh(r);
   else rt_coefs_psv(r, false);
   for (int i = 0; i < 6; i++) probs[i] = r.prob[i];
+}
+
+// Known-answer hook for tests: ONE reflection / transmission event on a bare interface -- media[6] = rho, alpha, beta of
+// the reflection side, then of the transmission side (ignored without a neighbour: the free surface's vanishing medium,
+// media_cellface.cpp:122-149), the face's outward unit normal, the phonon as the reference carries it (theta, phi,
+// polarisation angle, type), the event's two uniforms.
+//   -> out[8] = type, theta, phi, pol, transmitted (0 / 1), choice (R_P .. T_SH), margin of the outcome draw (fraction of
+//      the weights' total), margin of the SH / SV draw (1 for a P ray)
+void r3d_oracle_rt_event(const double media[6], int has_neighbor, const double normal[3], double theta, double phi,
+                         double pol, int type, double u_pol, double u_out, double out[8]) {
+  RT r;
+  r.no_transmit = false;
+  r.fnorm = mk(normal);
+  r.rhoR = media[0], r.velR[0] = media[1], r.velR[1] = media[2];
+  if (has_neighbor) r.rhoT = media[3], r.velT[0] = media[4], r.velT[1] = media[5];
+  else r.rhoT = 0.0, r.velT[0] = r.velT[1] = 1e-12, r.no_transmit = true;
+  Phonon p;
+  p.theta = theta, p.phi = phi, p.pol = pol, p.type = type;
+  int choice = 0;
+  double margin = 1.0, pol_margin = 1.0;
+  const bool crossed = rt_event_core(r, p, u_pol, u_out, &choice, &margin, &pol_margin);
+  out[0] = p.type, out[1] = p.theta, out[2] = p.phi, out[3] = p.pol, out[4] = crossed ? 1 : 0, out[5] = choice;
+  out[6] = margin, out[7] = pol_margin;
 }
 
 // Known-answer hooks for tests: one leg of ray geometry in a given cell.

@@ -870,122 +870,104 @@ enum { R_P, R_SV, R_SH, T_P, T_SV, T_SH, RT_NUM };
 // random outcome -> new type, direction, polarisation.  Reference
 // Phonon::Refraction_FullRT (phonons.cpp:429-476), CellFace::GetRTBasis
 // (media_cellface.cpp:122-149), RTCoef (rtcoef.cpp:30-588).
-// Returns true if the phonon crossed into the neighbour.
 //
 // The outcome is chosen from weights w_k = rho_k v_k Re(cos_k) |A_k|^2.  Every
 // amplitude is a numerator over the same determinant (D for P-SV, a+b for SH),
 // and the chooser (rtcoef.cpp:436-475) only compares u * sum(w) with partial
 // sums, so the common 1/|D|^2 is dropped: the weights here are |D|^2 times the
-// reference's, which selects the same outcome with ~4 reciprocals instead of
-// ~20 fp64 divisions.  A vanishing or non-finite determinant gives the
-// reference a NaN total and hence its default choice; that case is tested
-// explicitly.
-// Outcome weights of one interface for incidence sine `sini` and incident type
-// `intype` (0 P, 1 SH, 2 SV): w[k] = |det|^2 x the reference's mProb[k]
-// (rtcoef.cpp:207-278, :107-198, :289-393); det2 = |determinant|^2.  Outcome order R_P, R_SV,
-// R_SH, T_P, T_SV, T_SH (rtcoef.hpp:79-87).  (Only the weights leave this function: the sine and
-// cosine of the one outgoing ray that is chosen are formed afterwards, rt_ray() -- carrying all six
-// pairs through the solve cost two dozen registers.)
-R3D_HD void rt_weights(const Iface& f, double sini, int intype, double w[RT_NUM], double& det2) {
+// reference's, which selects the same outcome.  A vanishing or non-finite
+// determinant gives the reference a NaN total and hence its default choice;
+// that case is tested explicitly.
+//
+// THE SOLVE IN SLOWNESS FORM (round 6).  The reference forms sin_k = v_k p, cos_k = sqrt(1 - sin_k^2)
+// (complex beyond the critical angle) and then only ever uses cos_k / v_k; that quotient is the ray's
+// VERTICAL SLOWNESS sqrt(1 / v_k^2 - p^2), purely real or purely imaginary, taken here in one step from
+// p^2 = sin^2(i) / v_in^2 -- neither the incidence sine nor p itself is ever needed, only their squares
+// (every numerator that carries p enters through its squared modulus), and the incident ray's own slowness is
+// |cos i| / v_in with cos i = n.d at hand from the geometry: three roots where the reference takes four of
+// them and a root for the sine.  The two incidence types of the P-SV system are ONE set of formulas in
+// (own type, other type) velocities -- exchanging the P and the S slownesses exchanges E with F and G with
+// H and leaves D alone (rtcoef.cpp:107-198 read side by side) -- so the velocities are selected once, ahead of
+// the arithmetic, and the four weights put in the reference's order afterwards; the SH system (rtcoef.cpp:
+// 207-278) works from the same two S slownesses and is evaluated beside it, so a batch that mixes P, SV and
+// SH lanes runs one instruction stream.  The Aki-Richards parameters in the form a = (rho2 - rho1) - d p^2,
+// b = rho2 - d p^2, c = rho1 + d p^2, d = 2 (mu2 - mu1) (rtcoef.cpp:336-343 multiplied out).
+//
+// What comes out beside the weights: the real part of each outgoing ray's vertical slowness and its
+// velocity, so that the chosen ray's direction cosine v Re(slowness) needs no second root.
+struct RtWeights {
+  double w[4];     // chooser order with the entries that are zero by construction left out:
+                   //   P / SV incidence: R_P, R_SV, T_P, T_SV;  SH incidence: R_SH, 0, T_SH, 0
+  double det2;     // |determinant|^2 the weights are scaled by
+  // Re(vertical slowness) and velocity of the four outgoing rays: [0] reflected / [1] transmitted, own type (the
+  // incident ray's) and other type
+  double zr_own[2], zr_oth[2], v_own[2], v_oth[2];
+  double iv_in;    // 1 / the incident ray's velocity
+};
+// m2 = sin^2(i), acn = |cos i|; intype 0 P, 1 SH, 2 SV.
+R3D_HD RtWeights rt_weights_slowness(const Iface& f, double m2, double acn, int intype) {
   const double rho1 = f.rhoR, rho2 = f.rhoT;
   const double a1 = f.vR[0], a2 = f.vT[0], b1 = f.vR[1], b2 = f.vT[1];
+  const bool in_p = (intype == 0), sh = (intype == 1), sv = (intype == 2);
+  // own: the incident ray's type, oth: the other one (for SH: own = S; what the P-SV block makes of it is not looked at)
+  const double own1 = in_p ? a1 : b1, oth1 = in_p ? b1 : a1, own2 = in_p ? a2 : b2, oth2 = in_p ? b2 : a2;
+  // (an S velocity is 0 in a fluid: its reciprocal is not a number then, nor is anything below, and the
+  //  chooser falls back to the default outcome -- as the reference does with its division by zero)
+  const double iv = frcp(own1);
+  const double psq = m2 * (iv * iv);        // horizontal slowness squared
+  const double x1 = acn * iv;               // the incident ray's own vertical slowness (real)
+  const double io1 = frcp(oth1), ix2 = frcp(own2), io2 = frcp(oth2);
+  const Cx y1 = sqrt_real(io1 * io1 - psq), x2 = sqrt_real(ix2 * ix2 - psq), y2 = sqrt_real(io2 * io2 - psq);
+  R3D_SCHED_FENCE();
+  const double mu1 = rho1 * (b1 * b1), mu2 = rho2 * (b2 * b2);
+  const double d = 2.0 * (mu2 - mu1), dp = d * psq;
+  const double a = (rho2 - rho1) - dp, b = rho2 - dp, c = rho1 + dp;
+  // E = b x1 + c x2, F = b y1 + c y2, G = a - d x1 y2, H = a - d x2 y1, D = E F + G H p^2
+  const double bx1 = b * x1;
+  const Cx cx2 = c * x2;
+  const Cx E = cx(bx1 + cx2.re, cx2.im), T1 = cx(bx1 - cx2.re, -cx2.im);
+  const Cx F = b * y1 + c * y2;
+  const Cx dxy = (d * x1) * y2;
+  const Cx G = cx(a - dxy.re, -dxy.im), T2 = cx(a + dxy.re, dxy.im);
+  const Cx H = a - d * (x2 * y1);
+  const Cx D = E * F + (G * H) * psq;
+  const Cx same = T1 * F - (T2 * H) * psq;            // same-type reflection (numerator)
+  const Cx conv = (a * b) + (c * d) * (x2 * y2);      // converted reflection, without its factor -2 p v_in x1
+  const double four_cn2 = 4.0 * (acn * acn);
+  const double k_rs = (rho1 * own1) * acn;            // rho v Re(cos) of the incident ray's own type
+  const double k_t = ((rho1 * rho1) * rho2) * four_cn2;
+  const double w_rs = k_rs * norm(same);
+  const double w_rc = ((rho1 * y1.re) * (four_cn2 * psq)) * norm(conv);
+  const double w_ts = (k_t * x2.re) * norm(F);
+  const double w_tc = ((k_t * y2.re) * psq) * norm(H);
+  // SH: a = mu1 x1, b = mu2 x2; R = (a - b) / (a + b), T = 2 a / (a + b)
+  const double ash = mu1 * x1;
+  const Cx bsh = mu2 * x2;
+  const double w_rsh = k_rs * norm(cx(ash - bsh.re, bsh.im));
+  const double w_tsh = (mu2 * x2.re) * (4.0 * (ash * ash));
+  RtWeights o;
+  o.det2 = sh ? norm(cx(ash + bsh.re, bsh.im)) : norm(D);
+  // (SH lanes: the P-SV block's numbers are finite -- the "other" velocities of an S ray are P velocities -- and left out)
+  const double s_rs = sh ? w_rsh : w_rs, s_ts = sh ? w_tsh : w_ts, s_rc = sh ? 0.0 : w_rc, s_tc = sh ? 0.0 : w_tc;
+  o.w[0] = sv ? s_rc : s_rs, o.w[1] = sv ? s_rs : s_rc, o.w[2] = sv ? s_tc : s_ts, o.w[3] = sv ? s_ts : s_tc;
+  o.zr_own[0] = x1, o.zr_own[1] = x2.re, o.zr_oth[0] = y1.re, o.zr_oth[1] = y2.re;
+  o.v_own[0] = own1, o.v_own[1] = own2, o.v_oth[0] = oth1, o.v_oth[1] = oth2;
+  o.iv_in = iv;
+  return o;
+}
+// The same as the six weights of the reference's table (rtcoef.hpp:79-87: R_P, R_SV, R_SH, T_P, T_SV, T_SH), from the
+// incidence sine: w[k] = |det|^2 x the reference's mProb[k].  (The --rtcoef-test mission and the tests; the kernel
+// goes through rt_event.)
+R3D_HD void rt_weights(const Iface& f, double sini, int intype, double w[RT_NUM], double& det2) {
+  const double m2 = sini * sini;
+  const RtWeights o = rt_weights_slowness(f, m2, fsqrt(fmax(0.0, 1.0 - m2)), intype);
 #pragma unroll
   for (int i = 0; i < RT_NUM; i++) w[i] = 0;
-  if (intype == 1) {  // GetCoefs_SH, rtcoef.cpp:207-278
-    const double s2 = (b2 * frcp(b1)) * sini;   // (b1: the S velocity where an S ray is travelling -- a plain number)
-    const Cx cj1 = sqrt_real(1.0 - sini * sini);
-    const Cx cj2 = sqrt_real(1.0 - s2 * s2);
-    const Cx a = (rho1 * b1) * cj1, b = (rho2 * b2) * cj2;
-    det2 = norm(a + b);
-    w[R_SH] = rho1 * b1 * cj1.re * norm(a - b);
-    w[T_SH] = rho2 * b2 * cj2.re * (4.0 * norm(a));
-  } else {  // GetCoefs_PSV, rtcoef.cpp:107-198, :289-393
-    // (Written for a small register footprint: the velocities, densities and reciprocals are
-    //  folded into the four vertical slownesses, four real prefactors and a, b, c, d as early as
-    //  possible, and the numerators are formed one outcome at a time.)
-    const bool in_p = (intype == 0);
-    double kRP, kRS, kTP, kTS;       // rho v Re(cos) x the velocity-ratio factors of rtcoef.cpp:150-186
-    Cx ci1, ci2, cj1, cj2;           // vertical slownesses cos / v of the four outgoing rays
-    double a, b, c, d, pp, psq, t_in;
-    {
-      // (P velocities are plain numbers -- a free surface's far side has 1e-12 --; an S velocity is 0 in a fluid, and its reciprocal's infinity is meant)
-      const double ia1 = frcp(a1), ia2 = frcp(a2), ib1 = 1.0 / b1, ib2 = 1.0 / b2;
-      pp = sini * (in_p ? ia1 : ib1);  // horizontal slowness
-      psq = pp * pp;
-      const double sTP = a2 * pp, sTS = b2 * pp, sRS = b1 * pp, sRP = a1 * pp;   // the outgoing rays' sines
-      const Cx cTP = sqrt_real(1.0 - sTP * sTP);
-      const Cx cTS = sqrt_real(1.0 - sTS * sTS);
-      const Cx cRS = sqrt_real(1.0 - sRS * sRS);
-      const Cx cRP = sqrt_real(1.0 - sRP * sRP);
-      ci1 = ia1 * cRP, ci2 = ia2 * cTP, cj1 = ib1 * cRS, cj2 = ib2 * cTS;
-      kRP = rho1 * a1 * cRP.re * (in_p ? 1.0 : ia1 * ia1);
-      kRS = rho1 * b1 * cRS.re * (in_p ? ib1 * ib1 : 1.0);
-      kTP = rho2 * a2 * cTP.re * (ia2 * ia2);
-      kTS = rho2 * b2 * cTS.re * (ib2 * ib2);
-      const double b1s = b1 * b1, b2s = b2 * b2;
-      const double t1 = rho1 * (1. - 2. * b1s * psq), t2 = rho2 * (1. - 2. * b2s * psq);
-      const double t3 = 2. * rho1 * b1s, t4 = 2. * rho2 * b2s;
-      a = t2 - t1, b = t2 + t3 * psq, c = t1 + t4 * psq, d = t4 - t3;
-      t_in = rho1 * (in_p ? a1 : b1);
-      R3D_SCHED_FENCE();
-    }
-    const Cx E = b * ci1 + c * ci2, F = b * cj1 + c * cj2;
-    const Cx G = a - (d * ci1) * cj2, H = a - (d * ci2) * cj1;
-    {
-      const Cx D = E * F + (G * H) * psq;
-      det2 = norm(D);
-    }
-    const Cx inc = in_p ? ci1 : cj1;                    // the incident wave's own vertical slowness
-    const double v_in = in_p ? a1 : b1;
-    R3D_SCHED_FENCE();
-    {
-      const Cx conv = ((-2.0 * pp * v_in) * inc) * ((a * b) + ((c * d) * ci2) * cj2);   // converted reflection
-      const Cx same = in_p ? (b * ci1 - c * ci2) * F - ((a + (d * ci1) * cj2) * H) * psq
-                           : (b * cj1 - c * cj2) * E - ((a + (d * ci2) * cj1) * G) * psq;   // same-type reflection
-      w[R_P] = kRP * norm(in_p ? same : conv);
-      w[R_SV] = kRS * norm(in_p ? conv : same);
-    }
-    R3D_SCHED_FENCE();
-    {
-      const Cx T1 = (2.0 * t_in) * inc;
-      const Cx nTP = in_p ? T1 * F : (T1 * G) * pp;
-      w[T_P] = kTP * norm(nTP);
-      const Cx nTS = in_p ? (T1 * H) * pp : T1 * E;
-      w[T_SV] = kTS * norm(nTS);
-    }
-    R3D_SCHED_FENCE();
-  }
-}
-// Sine and real cosine of outgoing ray `choice` (Snell: sine = outgoing velocity x the horizontal
-// slowness; the same expressions the weights were formed from).
-R3D_HD void rt_ray(const Iface& f, double sini, int intype, int choice, double& sn, double& cr) {
-  // (selected pairwise from scalars: a chain of selects over the arrays becomes a look-up table
-  //  in scratch memory)
-  const double a1 = f.vR[0], b1 = f.vR[1], a2 = f.vT[0], b2 = f.vT[1];
-  const bool out_p = (choice == R_P) | (choice == T_P), out_t = choice >= T_P;
-  const double v_in = (intype == 0) ? a1 : b1;
-  const double v_p = out_t ? a2 : a1, v_s = out_t ? b2 : b1;
-  const double v_out = out_p ? v_p : v_s;
-  if (intype == 1) {   // (b2 / b1) sini as in rt_weights; the reflected SH ray keeps the incidence sine
-    sn = (choice == R_SH) ? sini : (b2 * frcp(b1)) * sini;
-    cr = sqrt_real(1.0 - sn * sn).re;
-  } else {
-    const double pp = sini * frcp(v_in);
-    sn = v_out * pp;
-    cr = sqrt_real(1.0 - sn * sn).re;
-  }
+  if (intype == 1) w[R_SH] = o.w[0], w[T_SH] = o.w[2];
+  else w[R_P] = o.w[0], w[R_SV] = o.w[1], w[T_P] = o.w[2], w[T_SV] = o.w[3];
+  det2 = o.det2;
 }
 
-// The solve in two halves, so that a caller short of registers can let go of everything but a
-// few words between them: rt_choose() draws the incident S polarisation type and the outcome
-// (all the random numbers, the weights, the chooser of rtcoef.cpp:436-475); rt_apply() turns the
-// chosen outcome into the new type, direction and polarisation from the SAME phonon and interface
-// (the interface basis and Snell's sine are simply formed again: same inputs, same arithmetic,
-// same values).
-struct RtChoice {
-  int choice;    // R_P .. T_SH, after the no-transmit fold
-  int intype;    // 0 P, 1 SH, 2 SV
-};
 // The event's uniforms (the S-polarisation draw only for S phonons, then the outcome draw: order and
 // count of draws are the reference's, rtcoef.cpp:414, :447), PINNED where this is called: they depend
 // on nothing that has to be fetched, so a caller draws them while the interface's records are on
@@ -996,98 +978,111 @@ R3D_HD void rt_draws(const Phonon& p, Rng& rng, RngKey key, double& u_pol, doubl
   asm volatile("" : "+v"(u_pol), "+v"(u_out));
 #endif
 }
+
+// The event in two halves, so that a caller short of registers can let go of everything but four words between
+// them: rt_choose() decides the incident S ray's polarisation kind (ChooseSPolType, rtcoef.cpp:406-422), forms the
+// weights and draws the outcome (the chooser of rtcoef.cpp:436-475); rt_apply() turns the chosen ray into the new
+// type, direction and polarisation from the SAME phonon and face normal (GetChosenRayDirection /
+// GetChosenParticleDOM, rtcoef.cpp:529-588; the tangential part of the direction and the normal of the plane of
+// incidence are simply formed again: same inputs, same arithmetic, same values).
+//
+// The reference forms unit axes fpara (in the plane of incidence, along the face) and fparash (normal to that
+// plane) and writes out = sin(o) fpara + (+-cos(o)) fnorm with sin(o) = v_out p.  None of the axes needs
+// normalising: sin(i) fpara IS the tangential part of the direction, dt = d - (n.d) n, so out = (v_out / v_in) dt
+// +- cos(o) n; and w = n x d = sin(i) fparash serves for the SH fraction -- (pdom.fparash)^2 >= u is
+// (pdom.w)^2 >= u |w|^2 -- and for the outgoing particle motion, whose scale the projection onto (theta^, phi^)
+// divides away.  Normal incidence (w = 0) takes the reference's substitute axis (geom_r3.cpp:146-171).
+struct RtChoice {
+  int code;      // bit 0: the outgoing ray is an S ray; bit 1: reflected; bit 2: the incident ray counted as SH
+  double kt;     // sin(o) / sin(i) = v_out / v_in
+  double cz;     // Re(cos(o)) >= 0: 0 beyond the critical angle
+};
+// n x d, or the reference's substitute axis where that vanishes; w2 = its squared length (m2 = sin^2(i) unless substituted)
+R3D_HD V3 rt_plane_normal(V3 n, V3 d, double m2, double& w2) {
+  V3 w = cross(n, d);
+  w2 = m2;                                         // |n x d|^2 = |d - (n.d) n|^2
+  if (any_lanes(is_zero(w))) {
+    if (is_zero(w)) {
+      w = cross(n, v3(1, 0, 0));
+      if (is_zero(w)) w = cross(n, v3(0, 1, 0));
+      w2 = mag2(w);
+    }
+  }
+  return w;
+}
 R3D_HD RtChoice rt_choose(const Phonon& p, Iface f, double u_pol, double u_out) {
-  const V3 fnorm = f.normal;
-  const V3 fpara = in_plane_unit_perp(fnorm, p.dir);
-  const double sini = dot(fpara, p.dir);
+  const double cn = dot(f.normal, p.dir);
+  const double m2 = mag2(p.dir - cn * f.normal);   // sin^2(i)
   bool no_transmit = false;
   if (!f.has_neighbor) {  // free surface: vanishing medium on the far side
     f.rhoT = 0.0, f.vT[0] = f.vT[1] = 1e-12;
     no_transmit = true;
   }
   int intype = 0;  // 0 P, 1 SH, 2 SV
-  if (p.type == RAY_S) {  // ChooseSPolType, rtcoef.cpp:406-422
-    const V3 fparash = cross(fnorm, fpara);
-    double sh = dot(direction_of_motion(p), fparash);
-    intype = (u_pol <= sh * sh) ? 1 : 2;
-  }
-  double w[RT_NUM], det2;
-  R3D_SCHED_FENCE();
-  rt_weights(f, sini, intype, w, det2);
-  R3D_SCHED_FENCE();
-  const int defchoice = intype == 0 ? R_P : intype == 1 ? R_SH : R_SV;   // GetCoefs, rtcoef.cpp:76-97
-  // Choose, rtcoef.cpp:436-475
-  double cum[RT_NUM];
-  cum[0] = w[0];
-#pragma unroll
-  for (int i = 1; i < RT_NUM; i++) cum[i] = cum[i - 1] + w[i];
-  const double total = cum[RT_NUM - 1];
-  const double ran = u_out * total;
-  int choice = RT_NUM - 1;
-#pragma unroll
-  for (int i = RT_NUM - 2; i >= 0; i--)
-    if (ran <= cum[i]) choice = i;   // ends on the FIRST i with ran <= cum[i]
-  if (total == 0 || (total - total) != 0 || !(det2 > 0) || (det2 - det2) != 0) choice = defchoice;
-  if (no_transmit && choice >= T_P) choice -= 3;  // T_x -> R_x
-  return RtChoice{choice, intype};
-}
-// The chosen outcome applied: new type, direction, polarisation (GetChosenRayDirection /
-// GetChosenParticleDOM, rtcoef.cpp:529-588).  fnorm: the face normal; v_in: the incident ray's velocity
-// at the crossing point; v_out: the chosen ray's, on the side it ends up on.  Returns true if the
-// phonon crossed into the neighbour.
-//
-// The reference forms unit axes fpara (in the plane of incidence, along the face) and fparash (normal
-// to that plane) and writes out = sin(o) fpara + (+-cos(o)) fnorm with sin(o) = v_out p, p = sin(i) / v_in.
-// As in bend(): sin(i) fpara IS the tangential part of the direction, dt = d - (n.d) n, so
-// out = (v_out / v_in) dt +- cos(o) n needs neither axis, no division by sin(i) and nothing of the
-// interface but the two velocities; and w = n x d = sin(i) fparash serves for the particle motion, its
-// scale divided away by the projection onto (theta^, phi^).  Normal incidence (w = 0) takes the
-// reference's substitute axis (geom_r3.cpp:146-171).  (The first form of this function re-derived the
-// whole interface -- four velocities, two densities -- and both unit axes: 350 instructions, now 150.)
-R3D_HD bool rt_apply(Phonon& p, V3 fnorm, double v_in, double v_out, RtChoice ch) {
-  const int choice = ch.choice;
-  const bool reflected = choice < T_P;
-  const double cn = dot(fnorm, p.dir);
-  const V3 dt = p.dir - cn * fnorm;
-  const double m2 = mag2(dt);                      // sin^2(i)
-  const double r = v_out * frcp(v_in);
-  const double so2 = (r * r) * m2;                 // sin^2 of the outgoing angle
-  // real part of the outgoing cosine (0 beyond the critical angle: sqrt_real), and the reference's
-  // clamp of the sine at 1 (rtcoef.cpp:541): the tangential part then has unit length
-  const bool beyond = so2 > 1.0;
-  double comp_norm = beyond ? 0.0 : fsqrt(1.0 - so2);
-  const double kt = beyond ? frsqrt(m2) : r;
-  if (reflected) comp_norm = -comp_norm;
-  const V3 out = kt * dt + comp_norm * fnorm;
-  p.type = (choice == R_P || choice == T_P) ? RAY_P : RAY_S;
   if (p.type == RAY_S) {
-    V3 w = cross(fnorm, p.dir);                    // sin(i) fparash
-    if (is_zero(w)) {
-      w = cross(fnorm, v3(1, 0, 0));
-      if (is_zero(w)) w = cross(fnorm, v3(0, 1, 0));
-    }
+    double w2;
+    const V3 w = rt_plane_normal(f.normal, p.dir, m2, w2);
+    const double sh = dot(direction_of_motion(p), w);
+    intype = (u_pol * w2 <= sh * sh) ? 1 : 2;
+  }
+  R3D_SCHED_FENCE();
+  const RtWeights o = rt_weights_slowness(f, m2, fabs(cn), intype);
+  R3D_SCHED_FENCE();
+  // Choose, rtcoef.cpp:436-475 (the partial sums of the six-entry table with its zero entries left out: the same values)
+  const double c0 = o.w[0], c1 = c0 + o.w[1], c2 = c1 + o.w[2], total = c2 + o.w[3];
+  const double ran = u_out * total;
+  int idx = 3;
+  if (ran <= c2) idx = 2;
+  if (ran <= c1) idx = 1;
+  if (ran <= c0) idx = 0;   // ends on the FIRST entry with ran <= its partial sum
+  // GetCoefs' default (rtcoef.cpp:76-97): reflected, same type
+  if (total == 0 || (total - total) != 0 || !(o.det2 > 0) || (o.det2 - o.det2) != 0) idx = (intype == 2) ? 1 : 0;
+  if (no_transmit && idx >= 2) idx -= 2;  // T_x -> R_x
+  const bool reflected = idx < 2;
+  // the chosen ray among the four: entries 1 / 3 are the converted ray for P and SH incidence, entries 0 / 2 for SV
+  const bool conv = ((idx & 1) != 0) != (intype == 2);
+  const double zr = reflected ? (conv ? o.zr_oth[0] : o.zr_own[0]) : (conv ? o.zr_oth[1] : o.zr_own[1]);
+  const double vo = reflected ? (conv ? o.v_oth[0] : o.v_own[0]) : (conv ? o.v_oth[1] : o.v_own[1]);
+  // outgoing type: entry 0 / 2 is a P ray for P and SV incidence, entry 1 / 3 an S ray; SH stays S
+  const bool out_s = (intype == 1) || ((idx & 1) != 0);
+  RtChoice ch;
+  ch.code = (out_s ? 1 : 0) | (reflected ? 2 : 0) | (intype == 1 ? 4 : 0);
+  ch.kt = vo * o.iv_in;
+  ch.cz = vo * zr;
+  // the reference's clamp of the outgoing sine at 1 (rtcoef.cpp:541): the tangential part then has unit length
+  // (only a default choice can pick such a ray)
+  if (any_lanes((ch.kt * ch.kt) * m2 > 1.0)) {
+    if ((ch.kt * ch.kt) * m2 > 1.0) ch.kt = frsqrt(m2), ch.cz = 0.0;
+  }
+  return ch;
+}
+// Returns true if the phonon crossed into the neighbour.
+R3D_HD bool rt_apply(Phonon& p, V3 n, RtChoice ch) {
+  const bool out_s = (ch.code & 1) != 0, reflected = (ch.code & 2) != 0, sh = (ch.code & 4) != 0;
+  const double cn = dot(n, p.dir);
+  const V3 dt = p.dir - cn * n;
+  const V3 out = ch.kt * dt + (reflected ? -ch.cz : ch.cz) * n;
+  p.type = out_s ? RAY_S : RAY_P;
+  if (out_s) {
+    double w2;
+    const V3 w = rt_plane_normal(n, p.dir, 0.0, w2);
     V3 dopm;
-    if (choice == T_SH || choice == R_SH) dopm = w;
-    else if (choice == R_SV) dopm = cross(out, w);
-    else dopm = cross(w, out);
+    if (sh) dopm = w;                              // SH stays SH
+    else if (reflected) dopm = cross(out, w);      // R_SV
+    else dopm = cross(w, out);                     // T_SV
     set_pol(p, dopm, out);
   }
   p.dir = out;
   return !reflected;
 }
-// The two velocities rt_apply wants, from a whole interface (the one-call form below).
-R3D_HD bool rt_apply(Phonon& p, Iface f, RtChoice ch) {
-  if (!f.has_neighbor) f.vT[0] = f.vT[1] = 1e-12;
-  const double v_in = f.vR[ch.intype == 0 ? 0 : 1];
-  const bool out_p = (ch.choice == R_P) | (ch.choice == T_P), out_t = ch.choice >= T_P;
-  const double v_p = out_t ? f.vT[0] : f.vR[0], v_s = out_t ? f.vT[1] : f.vR[1];
-  return rt_apply(p, f.normal, v_in, out_p ? v_p : v_s, ch);
+R3D_HD bool rt_event(Phonon& p, const Iface& f, double u_pol, double u_out) {
+  const RtChoice ch = rt_choose(p, f, u_pol, u_out);
+  return rt_apply(p, f.normal, ch);
 }
 R3D_HD bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
   double u_pol, u_out;
   rt_draws(p, rng, key, u_pol, u_out);
-  const RtChoice ch = rt_choose(p, f, u_pol, u_out);
-  return rt_apply(p, f, ch);
+  return rt_event(p, f, u_pol, u_out);
 }
 
 // Snell bending without mode conversion across a weak velocity step

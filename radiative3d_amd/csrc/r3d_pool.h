@@ -996,16 +996,13 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #ifdef R3D_ABLATE_RT
           step_event<KIND, EV_RT>(a, T, p, rng, st, ev, (int)nbr);
 #else
-          // the solve in two halves with nothing but the choice, the draw counter and the slot
+          // the solve in two halves with nothing but the choice (four words), the draw counter and the slot
           // number carried across (everything else is read again from the slot and the tables):
           // what is live while the weights are formed decides whether three waves fit a SIMD
           const RtChoice ch = rt_event_choose<KIND>(a, T, p, rng, st, ev, (int)nbr);
           const uint32_t draws = rng.k;
           asm volatile("" ::: "memory");   // (the second half must not reuse the first half's loads)
           load_state(id, p, rng, meta, nbr);
-#ifndef R3D_PRIO_NARROW
-        R3D_PRIO_LOW();
-#endif
           rng.k = draws;
           Pending ev2;
           ev2.vel = 0.0, ev2.face = (int)((meta >> 1) & 7u) - 1, ev2.flags = (meta >> 8) & 0xFFu, ev2.nbr = -1;

@@ -537,16 +537,19 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
   (void)adjoin;   // (only the timing-only R3D_ABLATE_RT build reads it here)
   bool crossed;
   if (PART != EV_LIGHT && PART != EV_BEND && (PART == EV_RT || (fl & F_REFLECT) || (fl & F_DISCON))) {
-    const Iface f = rt_interface<KIND>(a, T, p, ev, nbr);
     st.rtsolve++;
 #ifdef R3D_ABLATE_RT   // timing-only developer build: specular bounce / coin-flip transmission
     {
+      const Iface f = rt_interface<KIND>(a, T, p, ev, nbr);
       double dn = dot(f.normal, p.dir);
       crossed = adjoin && (rng_draw(rng, rng_key(a.seed)) < 0.5);
       if (!crossed) p.dir = p.dir - (2.0 * dn) * f.normal;
     }
 #else
-    crossed = full_rt(p, f, rng, rng_key(a.seed));
+    // (the event's uniforms first: they wait for nothing, the interface's records have to be fetched)
+    double u_pol, u_out;
+    rt_draws(p, rng, rng_key(a.seed), u_pol, u_out);
+    crossed = rt_event(p, rt_interface<KIND>(a, T, p, ev, nbr), u_pol, u_out);
 #endif
   } else if (PART == EV_RT) {
     crossed = true;   // (not reached)
@@ -584,14 +587,13 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
 
 // The reflection / transmission event in two calls (see rt_choose / rt_apply in r3d_physics.h):
 // a caller short of registers -- the pool kernel at three waves per SIMD -- draws the outcome, lets
-// go of everything but the two words of the choice, reloads the phonon and applies it.  Together
+// go of everything but the four words of the choice, reloads the phonon and applies it.  Together
 // they are step_event<KIND, EV_RT>.
 template <int KIND>
 R3D_HD RtChoice rt_event_choose(const KArgs& a, const Tables<KIND>& T, const Phonon& p, Rng& rng, LaneStats& st,
                                 const Pending& ev, int nbr) {
   st.rtsolve++;
-  // (measured and kept out: the six tetra records' fields read by value ahead of the draws, as the
-  //  move does with its record -- +-0: the solve is long enough to cover its own fetches)
+  // (the event's uniforms first: they wait for nothing, the interface's records have to be fetched)
   double u_pol, u_out;
   rt_draws(p, rng, rng_key(a.seed), u_pol, u_out);
   return rt_choose(p, rt_interface<KIND>(a, T, p, ev, nbr), u_pol, u_out);
@@ -599,13 +601,8 @@ R3D_HD RtChoice rt_event_choose(const KArgs& a, const Tables<KIND>& T, const Pho
 template <int KIND>
 R3D_HD void rt_event_apply(const KArgs& a, const Tables<KIND>& T, Phonon& p, LaneStats& st, const Pending& ev,
                            int nbr, RtChoice ch) {
-  // what is read again of the tables: the face normal and two velocities -- the incident ray's and
-  // the chosen ray's, in the cell it ends up in (a choice folded to a reflection stays in this one)
-  const bool out_p = (ch.choice == R_P) | (ch.choice == T_P), out_t = ch.choice >= T_P;
-  const V3 fnorm = cell_face_normal(cell_rec<KIND>(T, p.cell, p.type), ev.face, p.loc);
-  const double v_in = velocity_in<KIND>(T, p.cell, p.loc, p.type);
-  const double v_out = velocity_in<KIND>(T, out_t ? nbr : p.cell, p.loc, out_p ? RAY_P : RAY_S);
-  const bool crossed = rt_apply(p, fnorm, v_in, v_out, ch);
+  // what is read again of the tables: the face normal
+  const bool crossed = rt_apply(p, cell_face_normal(cell_rec<KIND>(T, p.cell, p.type), ev.face, p.loc), ch);
   if (crossed) {
     p.cell = nbr, st.transfer++;
   } else {

@@ -403,3 +403,144 @@ extern "C" void r3d_emul_shell_filter(int mode, uint64_t n, uint64_t seed, doubl
     }
   }
 }
+
+// ---- the reflection / transmission event on random bare interfaces: the engine's slowness-form solve (r3d_physics.h
+//      rt_choose / rt_apply) beside the oracle's restatement of RTCoef (oracle/r3d_oracle.cpp r3d_oracle_rt_event),
+//      the same interface, phonon and uniforms for both.
+// mode: 0 solid on solid, moderate contrasts; 1 free surface; 2 incidence within 1e-12 .. 1e-2 of a critical angle of one
+//       of the outgoing rays; 3 grazing incidence, cos(i) = 1e-6 .. 1e-2; 4 nearly identical media; 5 a fluid (beta = 0)
+//       on either side: the reference's default outcome; 6 contrasts up to 1e3; 7 near-normal incidence, sin(i) = 1e-9 ..
+//       1e-3; 8 along the normal exactly (the reference's substitute axis, geom_r3.cpp:146-171)
+// Two places where the REFERENCE's formulation is the ill-conditioned side, and the comparison allows what it loses:
+//   * it takes cos(i) as sqrt(1 - sin(i)^2), good to 1.1e-16 / cos(i) (absolutely), where the engine has n.d itself: the
+//     weights (which carry cos(i)) then differ by 1e-16 / cos(i)^2 of themselves, the reflected direction by 1e-16 / cos(i);
+//   * its axis normal to the plane of incidence is unit(n x d), good to 1e-16 / sin(i): so is the SH fraction an S ray's
+//     polarisation draw is compared with, and the outgoing polarisation.
+// out[0] cases, [1] outcomes that differ (type or side), [2] of those: with both draws further than the margin from their
+//       thresholds, [3] directions off by more than the tolerance, [4] polarisations off by more than the tolerance,
+//       [5] transmitted, [6] outgoing S rays, [7] incident S rays counted as SH
+// dev[0] largest direction error, dev[1] largest polarisation error (radians) x sin(theta) of the outgoing ray, over the
+//       cases with equal outcome
+typedef void (*rt_event_fn)(const double media[6], int has_neighbor, const double normal[3], double theta, double phi,
+                            double pol, int type, double u_pol, double u_out, double out[8]);
+extern "C" void r3d_emul_rt_events(int mode, uint64_t n, uint64_t seed, double tol, double margin, uint64_t* out,
+                                   double* dev, double* first_bad /* 16 doubles or null */, rt_event_fn oracle) {
+  SplitMix g{seed * 0x2545F4914F6CDD1Dull + 977u * (uint64_t)mode};
+  for (int i = 0; i < 8; i++) out[i] = 0;
+  dev[0] = dev[1] = 0.0;
+  for (uint64_t it = 0; it < n; it++) {
+    double media[6];
+    int has_nbr = 1;
+    auto medium = [&](double* m) {
+      m[1] = 1.5 + 11.5 * g.u();              // alpha
+      m[2] = m[1] / (1.45 + 0.7 * g.u());     // beta
+      m[0] = 1.0 + 5.0 * g.u();               // rho
+    };
+    medium(media), medium(media + 3);
+    if (mode == 1) has_nbr = 0;
+    if (mode == 4) {
+      const double e = g.logu(1e-10, 1e-2);
+      for (int k = 0; k < 3; k++) media[3 + k] = media[k] * (1.0 + e * g.sym());
+    }
+    if (mode == 5) {
+      if (g.u() < 0.5) media[5] = 0.0;
+      else media[2] = 0.0;
+    }
+    if (mode == 6) {
+      const double f = g.logu(1.0, 1e3);
+      const bool up = g.u() < 0.5;
+      for (int k = 0; k < 3; k++) media[3 + k] = up ? media[k] * f * (0.5 + g.u()) : media[k] / f * (0.5 + g.u());
+    }
+    int type = g.u() < 0.5 ? RAY_P : RAY_S;
+    if (mode == 5 && media[2] == 0.0) type = RAY_P;   // (no S ray travels in a fluid)
+    // (mode 8: +z is the one normal whose (theta, phi) give the unit vector back exactly)
+    const V3 nrm = mode == 8 ? v3(0, 0, 1) : rnd_unit(g);
+    // incidence: the sine of the angle to the normal
+    double sini = std::sqrt(g.u());
+    if (mode == 2) {
+      // a critical angle of one of the other rays: v_k sin(i) / v_in = 1
+      const double v_in = media[type == RAY_P ? 1 : 2];
+      double vk[4] = {media[1], media[2], media[4], media[5]};
+      double s_crit = 2.0;
+      for (int tries = 0; tries < 8 && !(s_crit < 1.0); tries++) s_crit = v_in / vk[(int)(4 * g.u()) & 3];
+      if (s_crit < 1.0) sini = s_crit * (1.0 + g.logu(1e-12, 1e-2) * (g.u() < 0.5 ? 1.0 : -1.0));
+      if (!(sini < 1.0)) sini = s_crit;
+    }
+    if (mode == 3) sini = std::sqrt(1.0 - std::pow(g.logu(1e-6, 1e-2), 2));   // grazing
+    if (mode == 7) sini = g.logu(1e-9, 1e-3);                                  // near normal
+    if (mode == 8) sini = 0.0;                                                 // along the normal exactly
+    // a direction with that incidence: normal cos(i) + tangent sin(i)
+    V3 tng = cross(nrm, rnd_unit(g));
+    while (mag2(tng) < 1e-6) tng = cross(nrm, rnd_unit(g));
+    tng = (1.0 / std::sqrt(mag2(tng))) * tng;
+    V3 dir = std::sqrt(std::fmax(0.0, 1.0 - sini * sini)) * nrm + sini * tng;
+    if (mode == 8) dir = nrm;
+    // the reference's phonon carries (theta, phi): both sides start from the direction those angles give
+    const double theta = std::acos(std::fmax(-1.0, std::fmin(1.0, dir.z))), phi = std::atan2(dir.y, dir.x);
+    dir = v3(std::sin(theta) * std::cos(phi), std::sin(theta) * std::sin(phi), std::cos(theta));
+    if (!(dot(nrm, dir) > 0.0)) {   // (rounding turned a grazing ray away from the face: not an arrival)
+      it--;
+      continue;
+    }
+    const double pol = kPi * g.sym();
+    const double u_pol = 1.0 - g.u(), u_out = 1.0 - g.u();   // (0, 1]
+    Phonon p;
+    p.t = p.path = p.recent = p.lamp = 0.0, p.loc = v3(0, 0, 0), p.cell = 0, p.moves = 0;
+    p.dir = dir, p.pc = std::cos(pol), p.ps = std::sin(pol), p.type = type;
+    Iface f;
+    f.normal = nrm, f.has_neighbor = has_nbr != 0;
+    f.rhoR = media[0], f.vR[0] = media[1], f.vR[1] = media[2];
+    f.rhoT = media[3], f.vT[0] = media[4], f.vT[1] = media[5];
+    const RtChoice ch = rt_choose(p, f, u_pol, u_out);
+    const bool crossed = rt_apply(p, f.normal, ch);
+    double o[8];
+    const double nn[3] = {nrm.x, nrm.y, nrm.z};
+    oracle(media, has_nbr, nn, theta, phi, pol, type, u_pol, u_out, o);
+    out[0]++;
+    out[5] += crossed ? 1 : 0, out[6] += p.type == RAY_S ? 1 : 0, out[7] += (ch.code & 4) ? 1 : 0;
+    bool bad = false;
+    // what the reference's own formulation is good to at this incidence (above)
+    const double ci = dot(nrm, dir), si = std::sqrt(mag2(cross(nrm, dir)));
+    const double lost_w = 4e-16 / (ci * ci), lost_dir = 4e-16 / ci, lost_axis = si > 0 ? 4e-16 / si : 0.0;
+    if ((int)o[0] != p.type || (o[4] != 0.0) != crossed) {
+      out[1]++;
+      if (o[6] > margin + lost_w && o[7] > margin + lost_axis) out[2]++, bad = true;
+    } else if (((ch.code & 4) != 0) != ((int)o[5] == 2 || (int)o[5] == 5) && p.type == RAY_S && type == RAY_S &&
+               !(o[7] > margin + lost_axis)) {
+      // (the polarisation draw sat on its threshold and fell the other way: SH one side, SV the other -- same ray, the
+      //  particle motion a quarter turn apart; counted with the differing outcomes)
+      out[1]++;
+    } else {
+      const V3 od = v3(std::sin(o[1]) * std::cos(o[2]), std::sin(o[1]) * std::sin(o[2]), std::cos(o[1]));
+      const double dd = std::sqrt(mag2(p.dir - od));
+      if (!(dd <= tol + lost_dir)) out[3]++, bad = true;
+      if (dd > dev[0]) dev[0] = dd;
+      if (p.type == RAY_S) {
+        // (the polarisation angle is defined about the direction: both as unit vectors in the (theta^, phi^) plane)
+        const double dp = std::sqrt((p.pc - std::cos(o[3])) * (p.pc - std::cos(o[3])) + (p.ps - std::sin(o[3])) * (p.ps - std::sin(o[3])));
+        // a ray along the pole has no azimuth of its own: phi = atan2(0, 0) on one side, the limit on the other; near
+        // the pole the (theta^, phi^) frame turns by (error of the direction) / sin(theta)
+        const double st = std::sqrt(od.x * od.x + od.y * od.y);
+        if (st > 1e-6) {
+          if (!(dp <= tol + (lost_dir + lost_axis) / st)) out[4]++, bad = true;
+          if (dp * st > dev[1]) dev[1] = dp * st;
+        }
+      }
+    }
+    if (bad && first_bad && first_bad[4] == 0.0) {
+      first_bad[0] = (double)it, first_bad[1] = type, first_bad[2] = sini, first_bad[3] = has_nbr;
+      for (int k = 0; k < 6; k++) first_bad[4 + k] = media[k];
+      first_bad[10] = o[5], first_bad[11] = ch.code, first_bad[12] = o[6], first_bad[13] = u_out, first_bad[14] = u_pol, first_bad[15] = pol;
+    }
+  }
+}
+// rt_weights for one interface and incidence sine: w[0..5] the six weights, w[6] the squared determinant they carry
+extern "C" void r3d_emul_rt_weights(const double media[6], double sini, int intype, double* w) {
+  Iface f;
+  f.normal = v3(0, 0, 1), f.has_neighbor = true;
+  f.rhoR = media[0], f.vR[0] = media[1], f.vR[1] = media[2];
+  f.rhoT = media[3], f.vT[0] = media[4], f.vT[1] = media[5];
+  double det2;
+  rt_weights(f, sini, intype, w, det2);
+  w[6] = det2;
+}

@@ -72,8 +72,7 @@ extern "C" __global__ void floor_rt(const CellTet* cells, const RhoLin* rho, Pho
   f.vT[0] = cell_velocity(cells[2 * nbr], p.loc, 0), f.vT[1] = cell_velocity(cells[2 * nbr + 1], p.loc, 1);
   f.rhoR = dot(p.loc, v3(rho[p.cell].g)) + rho[p.cell].c, f.rhoT = dot(p.loc, v3(rho[nbr].g)) + rho[nbr].c;
   f.has_neighbor = true;
-  const RtChoice ch = rt_choose(p, f, u_pol, u_out);
-  const bool crossed = rt_apply(p, f, ch);
+  const bool crossed = rt_event(p, f, u_pol, u_out);
   p.cell = crossed ? nbr : p.cell;
   ps[i] = p;
 }
