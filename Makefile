@@ -91,8 +91,8 @@ $(LIBDIR)/libr3d_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -shared -pthread -o $@ $(HOST_SRC)
 
-# (librccl: the shards' result blocks are summed on the devices, r3d_node_run in csrc/r3d_engine.hip)
-RCCL_LIBS ?= -L/opt/rocm/lib -lrccl
+# (librccl is bound at first use, csrc/r3d_rccl.h: the copy already in the process if there is one)
+RCCL_LIBS ?= -ldl
 $(LIBDIR)/libr3d_hip.so: $(call engine_objs,main)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=gfx950 -shared -pthread -o $@ $(call engine_objs,main) $(RCCL_LIBS)

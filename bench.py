@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0
 HBM_GATHER_PEAK_GBS = 3280.0
 N_SIMD = 256 * 4
 MAX_CLOCK_GHZ = 2.4
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 # BASELINE.json `configs`, as stated: the histories of ONE job of each configuration (configs 3-5 are
@@ -255,8 +255,10 @@ def envelope_agreement(gpu_mom, cpu_mom, n_gpu, n_cpu, min_count=25):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    # (defaults: a timed region of two seconds or more on every configuration's step launch of 7-60 ms, so that a
+    #  sampler that looks at the GPU every few seconds sees the run; the whole default run stays within a few minutes)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="crustpinch",
                     choices=["halfspace", "crustpinch", "lopnor", "sphere", "crustpinch_volume"])
     ap.add_argument("--histories", type=int, default=None, help="histories per GPU per step (default: per config)")
@@ -292,10 +294,28 @@ def rendezvous_only(args, rank, world):
     t = torch.ones(1, dtype=torch.int64)
     dist.all_reduce(t)
     if rank == 0:
-        print(json.dumps({"n_gpus": dist.get_world_size(), "ranks_seen": int(t.item()), "rendezvous": "ok"}),
-              flush=True)
+        emit({"n_gpus": dist.get_world_size(), "ranks_seen": int(t.item()), "rendezvous": "ok"})
     dist.barrier()
     dist.destroy_process_group()
+
+
+_JSON_OUT = None
+
+
+def claim_stdout():
+    """Keep file descriptor 1 for the JSON line alone: the model builder (C++, radiative3d_amd/host) and the GPU
+    runtime write their banners to stdout, so everything else that goes there is sent to stderr from here on."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(line):
+    out = _JSON_OUT or sys.stdout
+    out.write(json.dumps(line) + "\n")
+    out.flush()
 
 
 def main():
@@ -306,6 +326,7 @@ def main():
         # called directly: start the ranks here, before anything touches a GPU
         sys.exit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
+    claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -320,7 +341,7 @@ def main():
     import torch
     import torch.distributed as dist
     from radiative3d_amd import Engine, Model
-    from radiative3d_amd.parallel import DeviceResult, DeviceVolume, shard_range
+    from radiative3d_amd.parallel import Comm, DeviceResult, DeviceVolume, shard_range
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
@@ -352,8 +373,18 @@ def main():
     engine = Engine(model, device=local_rank)
     t_upload = time.perf_counter() - t0
     note(f"{args.config}: model built in {t_build:.1f} s, tables in HBM after {t_upload:.1f} s")
-    result = DeviceResult(model, device)     # this rank's running total; the job's after the one all-reduce
-    step_res = DeviceResult(model, device)   # (--reduce-per-step only)
+    # The bins are reduced by the PRODUCT's communicator (r3d_comm_*: the code `./main --devices` reduces with); the
+    # torch.distributed group carries its id, the barriers and the small gathers of this program.  Should the library's
+    # communicator not form, the run goes on with torch.distributed's all-reduce and says so in `collective`.
+    comm, comm_note = None, None
+    if launched:
+        try:
+            comm = Comm.form(device)
+        except RuntimeError as exc:
+            comm_note = str(exc)
+            note(f"r3d_comm: {exc}; the bins go through torch.distributed")
+    result = DeviceResult(model, device, comm)     # this rank's running total; the job's after the one all-reduce
+    step_res = DeviceResult(model, device, comm)   # (--reduce-per-step only)
     volume = None
     if wl["volume"]:
         volume = DeviceVolume(engine, device=device, **wl["volume"])
@@ -445,7 +476,7 @@ def main():
                           "phases_rank_0": {k: v for k, v in volume.timing.items() if k != "mode"}}
     step_ms = [ms for ms in (engine.kernel_ms(k) for k in step_launches) if ms >= 0]   # (the 64 most recent)
     flush_ms = [ms for ms in (engine.kernel_ms(k) for k in flush_launches) if ms >= 0]
-    per_rank = None
+    per_rank, roster = None, None
     if launched:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -458,6 +489,10 @@ def main():
         dist.all_gather(everyone, mine)
         per_rank = [dict(zip(("step_ms_min", "step_ms_max", "step_ms_mean", "flush_ms"),
                              (round(float(v), 4) for v in row))) for row in everyone]
+        # who took part, as the devices themselves report it
+        me = comm.describe() if comm is not None else {"rank": rank, "device": local_rank, "device_uuid": str(getattr(torch.cuda.get_device_properties(device), "uuid", ""))}
+        roster = [None] * world
+        dist.all_gather_object(roster, {"rank": me["rank"], "device": me["device"], "device_uuid": me["device_uuid"]})
         if volume is not None:   # every rank's own time in the grid's reduction, and what it put on the wire
             mine = torch.tensor([volume_reduce_s, float(volume.timing.get("bytes_sent") or 0)],
                                 dtype=torch.float64, device=device)
@@ -521,30 +556,45 @@ def main():
         # ---- what bounds the kernel (recorded counters, measured time) ----
         rec, rec_path, why_not = recorded_counters(args.config, args.toa_degree, n)
         b_hist = algorithmic_bytes_per_history(ev, model.n_toa, model.n_seismometers, model.desc.cell_kind)
+        floor, floor_path, floor_why_not = phase_floor(ev, model.desc.cell_kind)
+        lane_peak = N_SIMD * MAX_CLOCK_GHZ * 16.0      # G lane-instructions/s: 1024 SIMDs x 16 lanes a clock x 2.4 GHz
         roofline = {
             "bound": "valu",
             "kernel": f"pool_kernel<{kind_name}>", "kernel_ms_step_avg": avg_step_ms,
             "kernel_ms_flush": flush_ms, "kernel_ms_per_step_incl_flush": kernel_ms_per_step,
             "note": "the traversal is fp64 vector code with divergent gathers; no MFMA, 4-16 % of HBM peak (the hbm object). "
-                    "achieved = VALU-busy SIMD-cycles per second of a step launch (SQ_ACTIVE_INST_VALU x 4 "
-                    "cycles, recorded per launch by rocprofv3 --pmc, / this run's measured launch time); "
-                    "peak = 1024 SIMDs x 2.4 GHz",
+                    "achieved = USEFUL lane-instructions per second of a step launch: the static vector-instruction count of "
+                    "each phase's common path (floor, below) x this run's own event counts / this run's measured launch "
+                    "time; peak = 1024 SIMDs x 16 lanes a clock x 2.4 GHz; frac = useful_frac = achieved / peak.  How busy "
+                    "the vector unit was whatever it executed -- useful or queue / slot / tally code, full or masked "
+                    "lanes -- is valu_busy (SQ_ACTIVE_INST_VALU x 4 cycles, recorded per launch by rocprofv3 --pmc, / "
+                    "this run's measured launch time / (1024 SIMDs x 2.4 GHz))",
+            "achieved": None, "peak": lane_peak, "unit": "G lane-instructions/s", "frac": None, "useful_frac": None,
             "events_per_history": {k: round(v, 4) for k, v in ev.items()},
         }
+        if floor is not None:
+            useful = floor["per_history"] * n / (avg_step_ms * 1e-3) / 1e9
+            roofline.update({"achieved": useful, "frac": useful / lane_peak, "useful_frac": useful / lane_peak})
+            roofline["floor_lane_insts_per_history"] = floor["per_history"]
+            roofline["floor"] = {"source": floor_path, "by_term": floor["by_term"], "valu_insts_per_event": floor["per_event"],
+                                 "note": "static v_* counts of each phase's common path (tools/microbench/phase_floor.hip) x this run's "
+                                         "event counts: no queue / slot / tally code, no rare branch, no light face event"}
+        else:
+            roofline["floor_lane_insts_per_history"] = None
+            roofline["floor"] = f"none ({floor_why_not}: {floor_path})"
         if rec is not None:
             busy_cycles = 4.0 * rec["SQ_ACTIVE_INST_VALU"]
-            achieved = busy_cycles / (avg_step_ms * 1e-3) / 1e9
-            peak = N_SIMD * MAX_CLOCK_GHZ
+            busy = busy_cycles / (avg_step_ms * 1e-3) / 1e9 / (N_SIMD * MAX_CLOCK_GHZ)
             traffic = rec.get("hbm_traffic_bytes_per_launch")
             roofline.update({
-                "achieved": achieved, "peak": peak, "unit": "G SIMD-cycles/s", "frac": achieved / peak,
+                "valu_busy": busy,
                 "traffic": traffic, "counters": "recorded", "counters_source": rec_path,
                 "valu_insts_per_launch": rec.get("SQ_INSTS_VALU"),
                 "valu_busy_at_recorded_clock": rec.get("valu_busy"),
                 "lanes_active_per_valu_inst": rec.get("lane_activity"),
                 # busy x lanes: the share of the chip's lane-issue slots that carried a lane's instruction
-                "lane_weighted_frac": achieved / peak * rec["lane_activity"] if rec.get("lane_activity") else None,
-                # what one history costs in lane-instructions (falls when instructions are removed; frac does not)
+                "lane_weighted_frac": busy * rec["lane_activity"] if rec.get("lane_activity") else None,
+                # what one history costs in lane-instructions (falls when instructions are removed; valu_busy does not)
                 "valu_lane_insts_per_history": rec["SQ_INSTS_VALU"] * 64.0 * rec["lane_activity"] / n
                 if rec.get("lane_activity") and rec.get("SQ_INSTS_VALU") else None,
                 # the texture addressers' busy share of a step launch (TA_TA_BUSY_sum over 256 units x the launch's cycles):
@@ -560,21 +610,14 @@ def main():
                         "frac_of_peak": traffic / (avg_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
                         "peak_GBps": HBM_PEAK_GBS,
                         "frac_of_gather_peak": traffic / (avg_step_ms * 1e-3) / 1e9 / HBM_GATHER_PEAK_GBS if traffic else None,
-                        "gather_peak_GBps": HBM_GATHER_PEAK_GBS, "source": rec_path}})
-        else:
-            roofline.update({"achieved": None, "peak": N_SIMD * MAX_CLOCK_GHZ, "unit": "G SIMD-cycles/s",
-                             "frac": None, "traffic": None, "counters": f"none ({why_not}: {rec_path})"})
-        floor, floor_path, floor_why_not = phase_floor(ev, model.desc.cell_kind)
-        if floor is not None:
-            roofline["floor_lane_insts_per_history"] = floor["per_history"]
-            roofline["floor"] = {"source": floor_path, "by_term": floor["by_term"], "valu_insts_per_event": floor["per_event"],
-                                 "note": "static v_* counts of each phase's common path (tools/microbench/phase_floor.hip) x this run's "
-                                         "event counts: no queue / slot / tally code, no rare branch, no light face event"}
-            if roofline.get("valu_lane_insts_per_history"):
+                        "gather_peak_GBps": HBM_GATHER_PEAK_GBS,
+                        "gather_peak_source": "measured here: tools/microbench/hbm_gather.hip, profiles/r05/hbm_gather.log "
+                                              "(random 64-byte sectors of a 4 GB table)",
+                        "source": rec_path}})
+            if floor is not None and roofline.get("valu_lane_insts_per_history"):
                 roofline["achieved_over_floor"] = roofline["valu_lane_insts_per_history"] / floor["per_history"]
         else:
-            roofline["floor_lane_insts_per_history"] = None
-            roofline["floor"] = f"none ({floor_why_not}: {floor_path})"
+            roofline.update({"valu_busy": None, "traffic": None, "counters": f"none ({why_not}: {rec_path})"})
         contract = {
             "per_history": b_hist, "per_launch": b_hist * n,
             "by_term": contract_terms(ev, model.n_toa, model.n_seismometers, model.desc.cell_kind),
@@ -592,7 +635,14 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{wl['label']}, TOA degree {args.toa_degree}, {n} histories per GPU per step, "
-                                   f"{model.n_seismometers} seismometers x {model.n_bins} bins",
+                                   f"{model.n_seismometers} seismometers x {model.n_bins} bins; `value` is the rate of "
+                                   f"{args.steps} such steps CHAINED (unfinished histories carried into the next step's "
+                                   "launch, one flush launch at the end, inside the timed region); the BASELINE "
+                                   f"configuration as stated -- {JOB_HISTORIES[args.config]} histories over the ranks as one "
+                                   "self-contained launch each + the reduction -- is `job` (`job.value`, strong scaling)"
+                                   if not args.self_contained else
+                                   f"{wl['label']}, TOA degree {args.toa_degree}, {n} histories per GPU per step, "
+                                   f"{model.n_seismometers} seismometers x {model.n_bins} bins; every step a self-contained launch",
                        "name": args.config,
                        "histories_per_gpu_per_step": n, "toa_degree": args.toa_degree,
                        "cells": model.n_cells, "scatterers": model.n_scatterers,
@@ -601,7 +651,14 @@ def main():
                                          "steps chained (unfinished histories carried into the next "
                                          "step's launch, one flush launch at the end, inside the timed region)")},
             "roofline": roofline, "contract_bytes": contract,
-            "collective": {"backend": dist.get_backend() if launched else None,
+            "collective": {"bins": ("r3d_comm_reduce (libr3d_hip.so: one grouped ncclAllReduce of the block's three buffers)"
+                                    if comm is not None else "torch.distributed all_reduce" if launched else None),
+                           "rccl_ranks": comm.describe()["n_ranks"] if comm is not None else None,
+                           "rccl_version": comm.describe()["rccl_version"] if comm is not None else None,
+                           "rccl_library": comm.describe()["library"] if comm is not None else None,
+                           "r3d_comm_error": comm_note,
+                           "ranks": roster if launched else None,
+                           "control_plane": dist.get_backend() if launched else None,
                            "process_group": bool(launched), "per_rank_kernel_ms": per_rank},
             "host": {"model_build_s": round(t_build, 2), "engine_create_s": round(t_upload, 2),
                      "tables": "device-built"},
@@ -613,7 +670,7 @@ def main():
 
         if args.timed_only:
             line["cpu_baseline"] = None
-            print(json.dumps(line), flush=True)
+            emit(line)
         # ---- one self-contained launch of the same size (drains its own stragglers) ----
         if not args.self_contained and not args.timed_only:
             lone = []
@@ -668,8 +725,10 @@ def main():
 
         if n_batches == 0:   # (the CPU leg failed on rank 0: nothing to compare with)
             if rank == 0:
-                print(json.dumps(line), flush=True)
+                emit(line)
             engine.close()
+            if comm is not None:
+                comm.close()
             if launched:
                 dist.barrier()
                 dist.destroy_process_group()
@@ -695,8 +754,10 @@ def main():
     elif rank == 0 and not args.timed_only:
         line["cpu_baseline"] = None
     if rank == 0 and not args.timed_only:
-        print(json.dumps(line), flush=True)
+        emit(line)
     engine.close()
+    if comm is not None:
+        comm.close()
     if launched:
         dist.barrier()
         dist.destroy_process_group()

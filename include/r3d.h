@@ -313,10 +313,15 @@ int r3d_run_model_on(const r3d_model_desc* model, uint64_t n, uint64_t first_id,
  * reduce per buffer (ncclReduce, sum, to devices[0], in stream order behind the kernels: xGMI between
  * the GPUs of a node); the host reads that one block and ADDS it into *out.  This is the reference's
  * "replicas + combine" (scripts/do-parallel.sh:23-29, vis/seisplot/combine.m:26-33: replicas' traces
- * add).  RCCL refuses a communicator that names a device twice: a node whose shards share a device
- * adds the blocks on the host instead -- r3d_node_reduction says which ("rccl" / "host").  Counts and
- * counters equal one engine's run of the same ids exactly, energies to summation order.  If a shard
- * fails nothing is added to *out and the message names shard and device.
+ * add).  The blocks are added on the HOST instead where RCCL has nothing to do or cannot do it: a node
+ * of one shard, shards that share a device (RCCL refuses a communicator that names a device twice), no
+ * usable librccl in the process, a communicator that could not be formed, or one that failed in an
+ * earlier run (it is aborted, never waited for, and that run is summed on the host too) --
+ * r3d_node_reduction says which ("rccl" / "host"), r3d_node_reduction_note why the host.  librccl is
+ * bound at first use: the copy already in the process if there is one (a Python host with torch), else
+ * the loader's search path, else /opt/rocm/lib.  Counts and counters equal one engine's run of the same
+ * ids exactly, energies to summation order.  If a shard fails nothing is added to *out and the message
+ * names shard and device.
  * r3d_node_engine: shard g's engine (to attach an event log or a grid before a run, to read them
  * after); it stays the node's.                                                        */
 typedef struct r3d_node r3d_node;
@@ -325,7 +330,34 @@ int r3d_node_run(r3d_node* node, uint64_t n, uint64_t first_id, uint64_t seed, r
 int r3d_node_size(const r3d_node* node);
 r3d_engine* r3d_node_engine(r3d_node* node, int shard);
 const char* r3d_node_reduction(const r3d_node* node);
+const char* r3d_node_reduction_note(const r3d_node* node);
 void r3d_node_destroy(r3d_node* node);
+
+/* ONE PROCESS PER GPU: the same reduction for a job whose shards are processes (a launcher starts one
+ * rank per device; each rank owns an engine and a result block in HBM, r3d_run_device).  The ranks
+ * form an RCCL communicator through this library -- rank 0 makes the 128-byte id
+ * (r3d_comm_unique_id), the host carries it to the other ranks by whatever channel it has, every rank
+ * calls r3d_comm_create(id, rank, n_ranks, its device) -- and r3d_comm_reduce sums the block's three
+ * buffers over the ranks IN PLACE, in stream order on `stream`: into rank `root`'s buffers
+ * (root >= 0; the other ranks' buffers are then scratch), or into every rank's (root < 0).  It is the
+ * code r3d_node_run reduces with, so a job of N processes and a job of N shards in one process add
+ * their replicas the same way (vis/seisplot/combine.m:26-33).  A reduce that fails aborts the
+ * communicator (never waits on it) and every later call on it fails.  r3d_comm_describe: the size RCCL
+ * itself reports (ncclCommCount), this rank, its device and that device's UUID, the RCCL version and
+ * which library file was bound.                                                        */
+#define R3D_COMM_ID_BYTES 128
+typedef struct r3d_comm r3d_comm;
+typedef struct r3d_comm_info {
+  int32_t n_ranks, rank, device, rccl_version;
+  char device_uuid[40];    /* 32 hex digits */
+  char library[256];
+} r3d_comm_info;
+int r3d_comm_unique_id(unsigned char id[R3D_COMM_ID_BYTES]);
+r3d_comm* r3d_comm_create(const unsigned char id[R3D_COMM_ID_BYTES], int rank, int n_ranks, int device);
+int r3d_comm_reduce(r3d_comm* comm, double* d_energy, uint64_t n_energy, uint64_t* d_counts, uint64_t n_counts,
+                    uint64_t* d_scalars, uint64_t n_scalars, int root, void* stream);
+int r3d_comm_describe(const r3d_comm* comm, r3d_comm_info* info);
+void r3d_comm_destroy(r3d_comm* comm);
 
 /* r3d_run_device for a CHAIN of batches (same engine, same seed, launches in stream
  * order).  A batch ends in a drain phase in which ever fewer lanes still carry a

@@ -176,6 +176,14 @@ def host_lib():
     return _host
 
 
+R3D_COMM_ID_BYTES = 128
+
+
+class CommInfo(C.Structure):   # include/r3d.h r3d_comm_info
+    _fields_ = [("n_ranks", C.c_int32), ("rank", C.c_int32), ("device", C.c_int32), ("rccl_version", C.c_int32),
+                ("device_uuid", C.c_char * 40), ("library", C.c_char * 256)]
+
+
 class EngineOpts(C.Structure):
     """include/r3d.h r3d_engine_opts"""
     _fields_ = [("size", C.c_uint32), ("residency", C.c_int32), ("pool_slots", C.c_uint32),
@@ -270,7 +278,19 @@ def hip_lib(reproducible=False, path=None):
         L.r3d_node_engine.argtypes = [C.c_void_p, C.c_int]
         L.r3d_node_reduction.restype = C.c_char_p
         L.r3d_node_reduction.argtypes = [C.c_void_p]
+        L.r3d_node_reduction_note.restype = C.c_char_p
+        L.r3d_node_reduction_note.argtypes = [C.c_void_p]
         L.r3d_node_destroy.argtypes = [C.c_void_p]
+        L.r3d_comm_unique_id.restype = C.c_int
+        L.r3d_comm_unique_id.argtypes = [C.c_char_p]
+        L.r3d_comm_create.restype = C.c_void_p
+        L.r3d_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.r3d_comm_reduce.restype = C.c_int
+        L.r3d_comm_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                      C.c_int, C.c_void_p]
+        L.r3d_comm_describe.restype = C.c_int
+        L.r3d_comm_describe.argtypes = [C.c_void_p, C.POINTER(CommInfo)]
+        L.r3d_comm_destroy.argtypes = [C.c_void_p]
         L.r3d_run_model_on.restype = C.c_int
         L.r3d_run_model_on.argtypes = [C.POINTER(ModelDesc), C.c_uint64, C.c_uint64, C.c_uint64,
                                        C.POINTER(C.c_int), C.c_int, C.POINTER(Result)]

@@ -17,7 +17,6 @@
 // The product has no CPU path: without a HIP device every entry point fails with an error
 // message.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>   // the shards' blocks are summed on the devices (r3d_node_run)
 
 #include <algorithm>
 #include <cmath>
@@ -35,6 +34,7 @@
 #include "r3d_tables_build.h"
 
 #include "r3d_kernels.h"
+#include "r3d_rccl.h"   // the shards' blocks are summed on the devices (r3d_node_run, r3d_comm_reduce)
 namespace r3d {
 
 // ------------------------------------------------------------------- engine --
@@ -645,35 +645,43 @@ int r3d_run(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed, r3d_res
 
 // ---- a node: one engine per shard, kept alive across runs, the shards' blocks summed ON THE DEVICES ------------
 // (include/r3d.h r3d_node_*).  Each run: every shard's kernel is enqueued on its engine's stream into the engine's
-// own block in HBM; then ONE grouped ncclReduce (sum) per buffer -- f64 energies, u64 counts, u64 counters -- over
-// the shards' streams brings the job's totals to shard 0's device, and the host reads that one block.  This is the
-// reference's "replicas + combine" (scripts/do-parallel.sh:23-29, vis/seisplot/combine.m:26-33) with the combine
-// done by RCCL over xGMI.  RCCL refuses a communicator that names a device twice: such a node (shards sharing a
-// GPU -- tests, or a user who wants it) adds the blocks on the host instead, as r3d_run_model_on always did.
+// own block in HBM; then ONE grouped reduce (sum) per buffer -- f64 energies, u64 counts, u64 counters: reduce_block,
+// r3d_rccl.h -- over the shards' streams brings the job's totals to shard 0's device, and the host reads that one
+// block.  This is the reference's "replicas + combine" (scripts/do-parallel.sh:23-29, vis/seisplot/combine.m:26-33)
+// with the combine done by RCCL over xGMI.  The blocks are added on the HOST instead (r3d_node_reduction says
+// "host") when there is nothing for RCCL to do or it cannot do it: a node of one shard (its block is the job's),
+// shards that share a GPU (RCCL refuses a communicator that names a device twice -- tests, or a user who wants
+// it), no usable librccl, a communicator that could not be formed, or one that failed in an earlier run.
 struct r3d_node {
   std::vector<int> devices;
   std::vector<r3d_engine*> engines;
   std::vector<ncclComm_t> comms;   // empty: host sum
+  std::string host_why;            // why the host sums (when it does)
   DevBuf sum_energy, sum_counts, sum_scalars;   // on devices[0]: where the reduce puts the job's totals
   size_t ne = 0, nc = 0;
   uint64_t runs = 0;
 };
 
-#define R3D_NCCL_OK(call)                                                                     \
-  do {                                                                                        \
-    ncclResult_t r__ = (call);                                                                \
-    if (r__ != ncclSuccess) {                                                                 \
-      g_error = std::string(#call) + ": " + ncclGetErrorString(r__);                          \
-      return fail_value;                                                                      \
-    }                                                                                         \
-  } while (0)
+// A communicator that failed in the middle of a group cannot be waited for (its kernels may be waiting for peers
+// that were never enqueued): every rank's is aborted, which also ends what they have in flight, and the node goes
+// on with the host sum.
+static void node_abort_comms(r3d_node* nd, const std::string& why) {
+  if (const Rccl* R = rccl())
+    for (size_t g = 0; g < nd->comms.size(); g++) {
+      DeviceGuard on(nd->devices[g]);
+      if (nd->comms[g]) (void)R->CommAbort(nd->comms[g]);
+    }
+  nd->comms.clear();
+  nd->host_why = why;
+}
 
 void r3d_node_destroy(r3d_node* nd) {
   if (!nd) return;
-  for (size_t g = 0; g < nd->comms.size(); g++) {
-    DeviceGuard on(nd->devices[g]);
-    (void)ncclCommDestroy(nd->comms[g]);
-  }
+  if (const Rccl* R = rccl())
+    for (size_t g = 0; g < nd->comms.size(); g++) {
+      DeviceGuard on(nd->devices[g]);
+      if (nd->comms[g]) (void)R->CommDestroy(nd->comms[g]);
+    }
   for (r3d_engine* e : nd->engines)
     if (e) r3d_engine_destroy(e);
   DeviceGuard on(nd->devices.empty() ? 0 : nd->devices[0]);   // (the reduced block is freed on its device)
@@ -708,15 +716,22 @@ r3d_node* r3d_node_create(const r3d_model_desc* model, const int* devices, int n
   bool distinct = true;
   for (int g = 0; g < n_devices; g++)
     for (int h = 0; h < g; h++) distinct = distinct && devices[g] != devices[h];
-  if (distinct) {
-    nd->comms.assign(n_devices, nullptr);
-    const ncclResult_t r = ncclCommInitAll(nd->comms.data(), n_devices, devices);
-    if (r != ncclSuccess) {
-      g_error = std::string("ncclCommInitAll: ") + ncclGetErrorString(r);
-      nd->comms.clear();
-      r3d_node_destroy(nd.release());
-      return nullptr;
+  if (n_devices == 1) nd->host_why = "one shard: its block is the job's";
+  else if (!distinct) nd->host_why = "shards share a device";
+  else {
+    std::string why;
+    const Rccl* R = rccl(&why);
+    if (!R) nd->host_why = why;
+    else {
+      nd->comms.assign(n_devices, nullptr);
+      const ncclResult_t r = R->CommInitAll(nd->comms.data(), n_devices, devices);
+      if (r != ncclSuccess) {   // (the job can still be run: the blocks are then added on the host)
+        nd->comms.clear();
+        nd->host_why = std::string("ncclCommInitAll: ") + R->GetErrorString(r);
+      }
     }
+  }
+  if (!nd->comms.empty()) {
     DeviceGuard on(devices[0]);
     if (on.status != hipSuccess || nd->sum_energy.alloc_zero(std::max<size_t>(nd->ne, 1) * sizeof(double)) != hipSuccess ||
         nd->sum_counts.alloc_zero(std::max<size_t>(nd->nc, 1) * sizeof(uint64_t)) != hipSuccess ||
@@ -735,6 +750,7 @@ r3d_engine* r3d_node_engine(r3d_node* nd, int shard) {
   return nd->engines[shard];
 }
 const char* r3d_node_reduction(const r3d_node* nd) { return !nd ? "" : nd->comms.empty() ? "host" : "rccl"; }
+const char* r3d_node_reduction_note(const r3d_node* nd) { return !nd ? "" : nd->host_why.c_str(); }
 
 int r3d_node_run(r3d_node* nd, uint64_t n, uint64_t first_id, uint64_t seed, r3d_result* out) {
   const int fail_value = 1;
@@ -774,32 +790,38 @@ int r3d_node_run(r3d_node* nd, uint64_t n, uint64_t first_id, uint64_t seed, r3d
     }
     return 0;
   };
+  bool summed = false;
   if (!nd->comms.empty()) {
     // one grouped reduce per buffer, in stream order behind each shard's kernel: the sums land on devices[0]
-    R3D_NCCL_OK(ncclGroupStart());
-    ncclResult_t first_bad = ncclSuccess;   // (a call that fails inside the group must not leave the group open)
-    auto note = [&](ncclResult_t r) {
-      if (r != ncclSuccess && first_bad == ncclSuccess) first_bad = r;
-    };
-    for (int g = 0; g < N && first_bad == ncclSuccess; g++) {
-      r3d_engine* e = nd->engines[g];
-      DeviceGuard on(e->device);   // (each rank's calls with its own device current)
-      // (the receive buffer only means something on the root; the other ranks name their own block, in place)
-      if (ne) note(ncclReduce(e->d_energy.p, g == 0 ? nd->sum_energy.p : e->d_energy.p, ne, ncclDouble, ncclSum, 0, nd->comms[g], e->stream));
-      if (nc) note(ncclReduce(e->d_counts.p, g == 0 ? nd->sum_counts.p : e->d_counts.p, nc, ncclUint64, ncclSum, 0, nd->comms[g], e->stream));
-      note(ncclReduce(e->d_scalars.p, g == 0 ? nd->sum_scalars.p : e->d_scalars.p, R3D_N_SCALARS, ncclUint64, ncclSum, 0, nd->comms[g], e->stream));
+    const Rccl& R = *rccl();
+    ncclResult_t bad = R.GroupStart();
+    if (bad == ncclSuccess) {
+      for (int g = 0; g < N && bad == ncclSuccess; g++) {
+        r3d_engine* e = nd->engines[g];
+        DeviceGuard on(e->device);   // (each rank's calls with its own device current)
+        // (the receive buffers only mean something on the root; the other ranks name their own block, in place)
+        bad = reduce_block(R, nd->comms[g], e->stream, 0, e->d_energy.p, g == 0 ? nd->sum_energy.p : e->d_energy.p, ne,
+                           e->d_counts.p, g == 0 ? nd->sum_counts.p : e->d_counts.p, nc,
+                           e->d_scalars.p, g == 0 ? nd->sum_scalars.p : e->d_scalars.p, R3D_N_SCALARS);
+      }
+      const ncclResult_t end = R.GroupEnd();   // (a call that fails inside the group must not leave the group open)
+      if (bad == ncclSuccess) bad = end;
     }
-    note(ncclGroupEnd());
-    if (first_bad != ncclSuccess) {
-      (void)wait_all();
-      return g_error = std::string("r3d_node_run: the RCCL reduce failed: ") + ncclGetErrorString(first_bad), 1;
+    if (bad == ncclSuccess) {
+      if (wait_all()) return 1;
+      R3D_ON_DEVICE(nd->devices[0]);
+      if (ne) R3D_HIP_OK(hipMemcpy(he.data(), nd->sum_energy.p, ne * sizeof(double), hipMemcpyDeviceToHost));
+      if (nc) R3D_HIP_OK(hipMemcpy(hc.data(), nd->sum_counts.p, nc * sizeof(uint64_t), hipMemcpyDeviceToHost));
+      R3D_HIP_OK(hipMemcpy(hs, nd->sum_scalars.p, sizeof hs, hipMemcpyDeviceToHost));
+      summed = true;
+    } else {
+      // Some ranks' reduces may be enqueued and waiting for peers that never will be: nobody waits for them.  The
+      // communicators are aborted (that also ends their kernels), the node sums on the host from now on -- and this
+      // run too: the shards' kernels wrote their own blocks, which a reduce to shard 0's separate buffer left alone.
+      node_abort_comms(nd, std::string("the RCCL reduce failed (") + R.GetErrorString(bad) + "): communicators aborted");
     }
-    if (wait_all()) return 1;
-    R3D_ON_DEVICE(nd->devices[0]);
-    if (ne) R3D_HIP_OK(hipMemcpy(he.data(), nd->sum_energy.p, ne * sizeof(double), hipMemcpyDeviceToHost));
-    if (nc) R3D_HIP_OK(hipMemcpy(hc.data(), nd->sum_counts.p, nc * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    R3D_HIP_OK(hipMemcpy(hs, nd->sum_scalars.p, sizeof hs, hipMemcpyDeviceToHost));
-  } else {
+  }
+  if (!summed) {
     if (wait_all()) return 1;
     std::vector<double> te(std::max<size_t>(ne, 1));
     std::vector<uint64_t> tc(std::max<size_t>(nc, 1));
@@ -823,6 +845,95 @@ int r3d_node_run(r3d_node* nd, uint64_t n, uint64_t first_id, uint64_t seed, r3d
   for (int k = 0; k < R3D_EV_NUM; k++) out->events[k] += hs[3 + R3D_INV_NUM + k];
   nd->runs++;
   return 0;
+}
+
+// ---- one process per GPU: this rank's handle of an RCCL communicator (include/r3d.h r3d_comm_*) ------------------
+struct r3d_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, n_ranks = 0, device = 0;
+  bool broken = false;
+};
+
+int r3d_comm_unique_id(unsigned char id[R3D_COMM_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) == R3D_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  if (!id) return g_error = "null id", 1;
+  std::string why;
+  const Rccl* R = rccl(&why);
+  if (!R) return g_error = why, 1;
+  ncclUniqueId u;
+  const ncclResult_t r = R->GetUniqueId(&u);
+  if (r != ncclSuccess) return g_error = std::string("ncclGetUniqueId: ") + R->GetErrorString(r), 1;
+  std::memcpy(id, &u, sizeof u);
+  return 0;
+}
+
+r3d_comm* r3d_comm_create(const unsigned char id[R3D_COMM_ID_BYTES], int rank, int n_ranks, int device) {
+  if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return g_error = "r3d_comm_create: bad rank or id", nullptr;
+  std::string why;
+  const Rccl* R = rccl(&why);
+  if (!R) return g_error = why, nullptr;
+  DeviceGuard on(device);
+  if (on.status != hipSuccess) return g_error = std::string("r3d_comm_create: device ") + std::to_string(device) + ": " + hipGetErrorString(on.status), nullptr;
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof u);
+  auto c = std::make_unique<r3d_comm>();
+  c->rank = rank, c->device = device;
+  ncclResult_t r = R->CommInitRank(&c->comm, n_ranks, u, rank);
+  if (r != ncclSuccess) return g_error = std::string("ncclCommInitRank: ") + R->GetErrorString(r), nullptr;
+  r = R->CommCount(c->comm, &c->n_ranks);   // (what RCCL itself says the communicator's size is)
+  if (r != ncclSuccess || c->n_ranks != n_ranks) {
+    g_error = "r3d_comm_create: the communicator reports " + std::to_string(c->n_ranks) + " ranks, " + std::to_string(n_ranks) + " were asked for";
+    (void)R->CommAbort(c->comm);
+    return nullptr;
+  }
+  return c.release();
+}
+
+int r3d_comm_reduce(r3d_comm* c, double* d_energy, uint64_t n_energy, uint64_t* d_counts, uint64_t n_counts,
+                    uint64_t* d_scalars, uint64_t n_scalars, int root, void* stream) {
+  if (!c || !c->comm) return g_error = "null communicator", 1;
+  if (c->broken) return g_error = "r3d_comm_reduce: the communicator failed earlier and was aborted", 1;
+  if (root >= c->n_ranks) return g_error = "r3d_comm_reduce: no such root", 1;
+  const Rccl& R = *rccl();
+  DeviceGuard on(c->device);
+  if (on.status != hipSuccess) return g_error = std::string("r3d_comm_reduce: ") + hipGetErrorString(on.status), 1;
+  ncclResult_t bad = R.GroupStart();
+  if (bad == ncclSuccess) {
+    bad = reduce_block(R, c->comm, static_cast<hipStream_t>(stream), root, d_energy, d_energy, n_energy, d_counts, d_counts, n_counts,
+                       d_scalars, d_scalars, n_scalars);
+    const ncclResult_t end = R.GroupEnd();
+    if (bad == ncclSuccess) bad = end;
+  }
+  if (bad != ncclSuccess) {
+    g_error = std::string("r3d_comm_reduce: ") + R.GetErrorString(bad);
+    (void)R.CommAbort(c->comm);   // (what is enqueued may wait for peers for ever: ended here, not waited for)
+    c->comm = nullptr, c->broken = true;
+    return 1;
+  }
+  return 0;
+}
+
+int r3d_comm_describe(const r3d_comm* c, r3d_comm_info* info) {
+  if (!c || !info) return g_error = "null argument", 1;
+  std::memset(info, 0, sizeof *info);
+  const Rccl* R = rccl();
+  info->n_ranks = c->n_ranks, info->rank = c->rank, info->device = c->device;
+  info->rccl_version = R ? R->version : 0;
+  if (R) std::snprintf(info->library, sizeof info->library, "%s", R->where.c_str());
+  hipUUID uuid;
+  if (hipDeviceGetUuid(&uuid, c->device) == hipSuccess)
+    for (int i = 0; i < 16; i++) std::snprintf(info->device_uuid + 2 * i, 3, "%02x", (unsigned)(unsigned char)uuid.bytes[i]);
+  return 0;
+}
+
+void r3d_comm_destroy(r3d_comm* c) {
+  if (!c) return;
+  if (c->comm)
+    if (const Rccl* R = rccl()) {
+      DeviceGuard on(c->device);
+      (void)R->CommDestroy(c->comm);
+    }
+  delete c;
 }
 
 int r3d_run_model_on(const r3d_model_desc* model, uint64_t n, uint64_t first_id, uint64_t seed,

@@ -16,6 +16,7 @@
 #include <iostream>
 #include <sstream>
 #include <thread>
+#include <unistd.h>
 
 #include "../../include/r3d.h"
 #include "../csrc/r3d_physics.h"   // rt_weights(): the --rtcoef-test mission
@@ -122,6 +123,21 @@ void check_grid_job(const GridJob& grid, size_t n_shards) {
   std::remove(probe.c_str());
 }
 
+// File descriptor 1 pointed at stderr for the lifetime of the object (what C libraries underneath write to stdout).
+struct StdoutToStderr {
+  int saved = -1;
+  StdoutToStderr() {
+    std::cout.flush();
+    std::fflush(stdout);
+    saved = dup(1);
+    if (saved >= 0) dup2(2, 1);
+  }
+  ~StdoutToStderr() {
+    std::fflush(stdout);
+    if (saved >= 0) dup2(saved, 1), close(saved);
+  }
+};
+
 // The replacement for Model::RunSimulation()'s loop: a node (include/r3d.h r3d_node_*) shards the id range over
 // the requested devices, one engine per entry, and sums the shards' blocks on the devices (RCCL; on the host when
 // two shards share a device).  With a scatter grid every shard's engine fills its own grid in HBM; the grids are
@@ -149,7 +165,8 @@ void run_simulation(const Model& model, uint64_t n, uint64_t seed, r3d_node* nod
     if (grid.on && r3d_engine_set_volume(e, &grid.desc)) throw Runtime(r3d_last_error());
   }
   if (r3d_node_run(node, n, 0, seed, &total)) throw Runtime(r3d_last_error());
-  std::cout << "|  Shards: " << gpus << " (summed by " << r3d_node_reduction(node) << ")\n";
+  std::cout << "|  Shards: " << gpus << " (summed by " << r3d_node_reduction(node)
+            << (*r3d_node_reduction_note(node) ? std::string(": ") + r3d_node_reduction_note(node) : std::string()) << ")\n";
   if (report_mask)
     for (int g = 0; g < gpus; g++) {   // in shard order: ids ascend across shards
       const uint64_t reported = r3d_event_log_count(engines[g]);
@@ -274,7 +291,12 @@ int main(int argc, char* argv[]) {
       NodeHolder held;
       if (mission.bRunSim || model.DeviceTables()) {
         const std::vector<int> on = mission.bRunSim ? devices : std::vector<int>(1, devices[0]);
-        held.node = r3d_node_create(&model.Desc(), on.data(), (int)on.size());
+        {
+          // (RCCL prints its version banner on stdout when a communicator is formed: this program's stdout is the
+          //  reference's output format, so whatever libraries say while the node is built goes to stderr)
+          StdoutToStderr quiet;
+          held.node = r3d_node_create(&model.Desc(), on.data(), (int)on.size());
+        }
         if (!held.node) throw Runtime(r3d_last_error());
       }
       if (model.DeviceTables()) {   // the tables (and so the MFPs the dump prints) are made in HBM

@@ -229,8 +229,9 @@ def run_model(model, n, first_id=0, seed=0x5EED, n_gpus=1, devices=None):
 
 class Node:
     """r3d_node_*: one engine per entry of `devices`, kept across runs; a run shards the id range over them
-    and sums the shards' blocks on the devices (RCCL ncclReduce to devices[0]; on the host when two shards
-    share a device -- `reduction` says which)."""
+    and sums the shards' blocks on the devices (RCCL ncclReduce to devices[0]; on the host for a node of one
+    shard, when two shards share a device or when RCCL is not to be had -- `reduction` says which,
+    `reduction_note` why)."""
 
     def __init__(self, model, devices, lib=None):
         self.model = model
@@ -243,6 +244,11 @@ class Node:
     @property
     def reduction(self):
         return self._lib.r3d_node_reduction(self._n).decode()
+
+    @property
+    def reduction_note(self):
+        """Why the host adds the shards' blocks, when it does (r3d_node_reduction_note)."""
+        return self._lib.r3d_node_reduction_note(self._n).decode()
 
     def __len__(self):
         return self._lib.r3d_node_size(self._n)

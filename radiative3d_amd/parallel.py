@@ -5,11 +5,18 @@ read-only and every output is a sum, so the job shards with no data-path
 exchange: rank r runs a contiguous id range, and the per-receiver bins and
 counters are summed once at the end -- the same semantics as the reference's
 process-level replicas + `combine` (scripts/do-parallel.sh:23-29,
-vis/seisplot/combine.m:26-33).  The reduction is one all-reduce(SUM) per
-buffer through torch.distributed (backend "nccl" = RCCL over xGMI on the GPU
-node, "gloo" in CPU tests).  The event grid of BASELINE config 5 (10 GB per rank) is reduced BY FRAME
-and sparsely instead (DeviceVolume.reduce_scatter_frames_).
+vis/seisplot/combine.m:26-33).  On GPUs the reduction is the PRODUCT's: the
+ranks form an RCCL communicator through the engine library (`Comm`:
+r3d_comm_create, include/r3d.h) and `DeviceResult.allreduce_` calls
+r3d_comm_reduce -- the code r3d_node_run (one process, N shards: what
+`./main --devices` runs) reduces with; torch.distributed only carries the
+128-byte communicator id to the ranks and the bench's barriers.  Host tensors
+(the gloo tests of the sharding) are summed by torch.distributed's all-reduce.
+The event grid of BASELINE config 5 (10 GB per rank) is reduced BY FRAME and
+sparsely instead (DeviceVolume.reduce_scatter_frames_, torch.distributed point to point).
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
@@ -32,14 +39,74 @@ def allreduce_result_(energy, counts, scalars):
     return energy, counts, scalars
 
 
-class DeviceResult:
-    """Result block resident in HBM (torch tensors are only the allocator and
-    the handle RCCL reduces; the engine writes through raw pointers)."""
+class Comm:
+    """This rank's handle of an RCCL communicator made by the engine library (include/r3d.h r3d_comm_*).
 
-    def __init__(self, model, device):
+    form(device): rank 0 of the torch.distributed group makes the id (r3d_comm_unique_id), the group broadcasts
+    its 128 bytes, every rank calls r3d_comm_create with its own device.  A collective: every rank calls it."""
+
+    def __init__(self, handle, lib):
+        self._c, self._lib = handle, lib
+
+    @classmethod
+    def form(cls, device, lib=None):
+        from . import _ffi
+        L = _ffi.hip_lib(path=lib)
+        rank, world = dist.get_rank(), dist.get_world_size()
+        ident = C.create_string_buffer(_ffi.R3D_COMM_ID_BYTES)
+        status = 0
+        if rank == 0 and L.r3d_comm_unique_id(ident):
+            status = 1
+        # (the id and rank 0's status travel together, so that every rank gives up when rank 0 could not make one)
+        on = torch.device(device) if dist.get_backend() == "nccl" else torch.device("cpu")
+        box = torch.tensor(list(ident.raw) + [status], dtype=torch.uint8, device=on)
+        dist.broadcast(box, src=0)
+        box = box.cpu()
+        if int(box[-1]):
+            raise RuntimeError("r3d_comm_unique_id failed on rank 0" + (": " + L.r3d_last_error().decode() if rank == 0 else ""))
+        ident = C.create_string_buffer(bytes(box[:-1].tolist()), _ffi.R3D_COMM_ID_BYTES)
+        handle = L.r3d_comm_create(ident, rank, world, torch.device(device).index or 0)
+        # every rank learns whether ALL of them have a communicator: a rank without one must not be waited for
+        ok = torch.tensor([1 if handle else 0], dtype=torch.int32, device=on)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if not int(ok.item()):
+            err = "" if handle else L.r3d_last_error().decode()
+            if handle:
+                L.r3d_comm_destroy(handle)
+            raise RuntimeError("r3d_comm_create failed on some rank" + (": " + err if err else ""))
+        return cls(handle, L)
+
+    def describe(self):
+        from . import _ffi
+        info = _ffi.CommInfo()
+        if self._lib.r3d_comm_describe(self._c, C.byref(info)):
+            raise RuntimeError("r3d_comm_describe failed: " + self._lib.r3d_last_error().decode())
+        return {"n_ranks": info.n_ranks, "rank": info.rank, "device": info.device, "rccl_version": info.rccl_version,
+                "device_uuid": info.device_uuid.decode(), "library": info.library.decode()}
+
+    def reduce_(self, energy, counts, scalars, root=-1, stream=None):
+        """Sum the three device buffers over the ranks in place (root < 0: every rank ends with the sums)."""
+        s = stream if stream is not None else torch.cuda.current_stream(energy.device).cuda_stream
+        if self._lib.r3d_comm_reduce(self._c, energy.data_ptr(), energy.numel(), counts.data_ptr(), counts.numel(),
+                                     scalars.data_ptr(), scalars.numel(), root, s):
+            raise RuntimeError("r3d_comm_reduce failed: " + self._lib.r3d_last_error().decode())
+
+    def close(self):
+        if self._c:
+            self._lib.r3d_comm_destroy(self._c)
+            self._c = None
+
+
+class DeviceResult:
+    """Result block resident in HBM (torch tensors are only the allocator; the engine writes through raw
+    pointers and the library's communicator -- `comm`, a Comm -- reduces them).  Without a communicator
+    the block is summed by torch.distributed (host tensors in the gloo tests)."""
+
+    def __init__(self, model, device, comm=None):
         from . import _ffi
         n = model.n_seismometers * model.n_bins
         self.model = model
+        self.comm = comm
         self.energy = torch.zeros(max(1, n) * _ffi.R3D_N_ENERGY, dtype=torch.float64, device=device)
         # the integer outputs share one buffer, so the reduction is two collectives, not three
         n_counts = max(1, n) * _ffi.R3D_N_COUNT
@@ -58,7 +125,9 @@ class DeviceResult:
         return self.energy.data_ptr(), self.counts.data_ptr(), self.scalars.data_ptr()
 
     def allreduce_(self):
-        if dist.is_available() and dist.is_initialized():
+        if self.comm is not None:     # the product's reduce (r3d_comm_reduce): one grouped all-reduce of the three buffers
+            self.comm.reduce_(self.energy, self.counts, self.scalars)
+        elif dist.is_available() and dist.is_initialized():
             dist.all_reduce(self.energy, op=dist.ReduceOp.SUM)
             dist.all_reduce(self._ints, op=dist.ReduceOp.SUM)
         return self

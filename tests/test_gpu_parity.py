@@ -623,24 +623,51 @@ def test_run_model_on_three_engines_on_one_device(engines):
         run_model(e.model, 100, devices=[])
 
 
-def test_node_sums_the_shards_on_the_device_through_rccl(engines):
-    """r3d_node_*: the product's own RCCL reduce (north_star: "an RCCL reduce over xGMI of the per-receiver
-    energy-envelope histograms at the end"; semantics combine.m:26-33).  A node on the box's one GPU goes
-    through ncclCommInitAll / ncclReduce (a one-rank communicator) and equals Engine.run and the oracle; a
-    node whose shards share the device takes the host sum; both equal each other (counts exactly, energies
-    to summation order); a node is reusable -- a second run adds into the caller's block without rebuilding
-    tables; a failing run leaves *out untouched."""
-    from radiative3d_amd import Node
+def test_node_sums_the_shards_and_the_library_communicator_reduces_a_block(engines):
+    """r3d_node_* and r3d_comm_*: the product's own reduction (north_star: "an RCCL reduce over xGMI of the per-receiver
+    energy-envelope histograms at the end"; semantics combine.m:26-33).  Both go through ONE function
+    (csrc/r3d_rccl.h reduce_block).  On the box's one GPU: a node of one shard has nothing to reduce (its block is the
+    job's: "host", with the reason), a node whose shards share the device takes the host sum, both equal Engine.run
+    and the oracle (counts exactly, energies to summation order); the library's communicator is formed at one rank
+    (ncclGetUniqueId / ncclCommInitRank through the lazily bound librccl), reports its size from ncclCommCount and the
+    device's UUID, and its reduce -- all-reduce and reduce to a root -- leaves a one-rank block as it was; a node is
+    reusable -- a second run adds into the caller's block without rebuilding tables; a failing run leaves *out untouched."""
+    import ctypes as C
+    import torch
+    from radiative3d_amd import Node, _ffi
+    from radiative3d_amd.parallel import Comm, DeviceResult
     e = engines("crustpinch")
     n = 6001
     want = e.run(n, first_id=5, seed=77)
     one = Node(e.model, [0])
-    assert one.reduction == "rccl" and len(one) == 1
+    assert one.reduction == "host" and "one shard" in one.reduction_note and len(one) == 1
     got = one.run(n, first_id=5, seed=77)
     assert (got.counts == want.counts).all() and got.events == want.events
     assert (got.n_lost, got.n_timeout, got.n_invalid) == (want.n_lost, want.n_timeout, want.n_invalid)
     assert np.allclose(got.energy, want.energy, rtol=1e-12, atol=1e-300)
-    assert_result_equals_oracle(got, O.run(e.model, n, 5, 77), "r3d_node_run over RCCL")
+    assert_result_equals_oracle(got, O.run(e.model, n, 5, 77), "r3d_node_run")
+    # the communicator of a one-rank job, without any process group around it
+    L = _ffi.hip_lib()
+    ident = C.create_string_buffer(_ffi.R3D_COMM_ID_BYTES)
+    assert L.r3d_comm_unique_id(ident) == 0, L.r3d_last_error()
+    handle = L.r3d_comm_create(ident, 0, 1, 0)
+    assert handle, L.r3d_last_error()
+    comm = Comm(handle, L)
+    info = comm.describe()
+    assert info["n_ranks"] == 1 and info["rank"] == 0 and info["device"] == 0 and info["rccl_version"] > 20000
+    assert len(info["device_uuid"]) == 32 and "librccl" in info["library"]
+    block = DeviceResult(e.model, "cuda:0", comm)
+    e.run_device(n, 5, 77, *block.pointers())
+    torch.cuda.synchronize()
+    before = block.to_result()
+    block.allreduce_()                                                     # ncclAllReduce x 3, grouped
+    comm.reduce_(block.energy, block.counts, block.scalars, root=0)        # ncclReduce x 3, grouped
+    torch.cuda.synchronize()
+    after = block.to_result()
+    assert (after.counts == before.counts).all() and after.events == before.events and (after.energy == before.energy).all()
+    assert (after.counts == want.counts).all() and after.events == want.events
+    assert L.r3d_comm_reduce(handle, None, 0, None, 0, None, 0, 5, None) != 0 and b"no such root" in L.r3d_last_error()
+    comm.close()
     three = Node(e.model, [0, 0, 0])
     assert three.reduction == "host" and len(three) == 3
     host = three.run(n, first_id=5, seed=77)
@@ -832,8 +859,13 @@ def test_bench_under_a_launcher_runs_rccl_and_equals_the_direct_run(config, volu
     direct = _bench_child(args, launched=False)
     rccl = _bench_child(args, launched=True, port=free_port())
     assert direct["n_gpus"] == rccl["n_gpus"] == 1
-    assert rccl["collective"]["backend"] == "nccl" and rccl["collective"]["process_group"]
-    assert direct["collective"]["backend"] is None
+    # the bins went through the library's own communicator (the code `./main --devices` reduces with), which says what
+    # RCCL itself reports about the job
+    c = rccl["collective"]
+    assert c["control_plane"] == "nccl" and c["process_group"] and c["r3d_comm_error"] is None
+    assert c["bins"].startswith("r3d_comm_reduce") and c["rccl_ranks"] == 1 and c["rccl_version"] > 20000
+    assert [r["rank"] for r in c["ranks"]] == [0] and len(c["ranks"][0]["device_uuid"]) == 32
+    assert direct["collective"]["bins"] is None and direct["collective"]["control_plane"] is None
     assert rccl["roofline"]["events_per_history"] == direct["roofline"]["events_per_history"]
     assert rccl["value"] > 0 and len(rccl["collective"]["per_rank_kernel_ms"]) == 1
     if config == "crustpinch_volume":

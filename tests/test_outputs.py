@@ -117,7 +117,8 @@ def test_main_cli_end_to_end_on_gpu(tmp_path):
     lost = int(re.search(r"Loss surfaces:\s+(\d+)", run.stdout).group(1))
     tmo = int(re.search(r"Timeout:\s+(\d+)", run.stdout).group(1))
     assert lost + tmo == 200000
-    assert "|  Shards: 1 (summed by rccl)" in run.stdout     # the product's own reduce: r3d_node_run, ncclReduce
+    assert "|  Shards: 1 (summed by host: one shard" in run.stdout     # (a node of one shard has nothing to reduce)
+    assert "RCCL version" not in run.stdout                   # libraries' banners do not land in the reference's format
     m = Model(halfspace(4))
     want = O.run(m, 200000, seed=7)
     assert (lost, tmo) == (want.n_lost, want.n_timeout)
