@@ -392,10 +392,16 @@ R3D_HD V3 through_angles(V3 v) {
 // theta^ and phi^ at unit direction d (reference OrthoAxes E1, E2,
 // geom_r3.cpp:222-224).
 R3D_HD void sph_basis(V3 d, V3& th_hat, V3& ph_hat) {
-  double h2 = d.x * d.x + d.y * d.y;
-  double ih = (h2 != 0) ? frsqrt(h2) : 0.0;
-  double st = h2 * ih;     // sqrt(h2)
-  double cp = (h2 != 0) ? d.x * ih : 1.0, sp = d.y * ih;
+  const double h2 = d.x * d.x + d.y * d.y;
+  double ih = frsqrt(h2);
+  double cp = d.x * ih;
+  // (a ray along the pole: phi = atan2(0, 0) = 0.  Rare -- served under a vote of the wave, so that the lanes of every
+  //  other batch do not pay the selects; the values of the other lanes are the same either way)
+  if (any_lanes(h2 == 0)) {
+    if (h2 == 0) ih = 0.0, cp = 1.0;
+  }
+  const double st = h2 * ih;     // sqrt(h2)
+  const double sp = d.y * ih;
   th_hat = v3(d.z * cp, d.z * sp, -st);
   ph_hat = v3(-sp, cp, 0.0);
 }

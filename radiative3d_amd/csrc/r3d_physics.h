@@ -68,8 +68,10 @@ R3D_HD void set_pol(Phonon& p, V3 pdom, V3 d) {
   const double x = dot(pdom, th), y = dot(pdom, ph);
   const double h2 = x * x + y * y;
   const double ih = frsqrt(h2);
-  p.pc = (h2 == 0) ? 1.0 : x * ih;   // atan2(0, 0) = 0
-  p.ps = (h2 == 0) ? 0.0 : y * ih;
+  p.pc = x * ih, p.ps = y * ih;
+  if (any_lanes(h2 == 0)) {   // atan2(0, 0) = 0 (rare: under a vote of the wave, as in sph_basis)
+    if (h2 == 0) p.pc = 1.0, p.ps = 0.0;
+  }
 }
 
 // ===================================================================== CYL ==
@@ -917,7 +919,12 @@ R3D_HD RtWeights rt_weights_slowness(const Iface& f, double m2, double acn, int 
   const double psq = m2 * (iv * iv);        // horizontal slowness squared
   const double x1 = acn * iv;               // the incident ray's own vertical slowness (real)
   const double io1 = frcp(oth1), ix2 = frcp(own2), io2 = frcp(oth2);
-  const Cx y1 = sqrt_real(io1 * io1 - psq), x2 = sqrt_real(ix2 * ix2 - psq), y2 = sqrt_real(io2 * io2 - psq);
+  // (sqrt_real, placed with one select: the other component is what is left)
+  auto slowness = [&](double iv_k) {
+    const double q = iv_k * iv_k - psq, r = fsqrt(fabs(q)), re = q >= 0 ? r : 0.0;
+    return cx(re, r - re);
+  };
+  const Cx y1 = slowness(io1), x2 = slowness(ix2), y2 = slowness(io2);
   R3D_SCHED_FENCE();
   const double mu1 = rho1 * (b1 * b1), mu2 = rho2 * (b2 * b2);
   const double d = 2.0 * (mu2 - mu1), dp = d * psq;
@@ -937,9 +944,11 @@ R3D_HD RtWeights rt_weights_slowness(const Iface& f, double m2, double acn, int 
   const double k_rs = (rho1 * own1) * acn;            // rho v Re(cos) of the incident ray's own type
   const double k_t = ((rho1 * rho1) * rho2) * four_cn2;
   const double w_rs = k_rs * norm(same);
-  const double w_rc = ((rho1 * y1.re) * (four_cn2 * psq)) * norm(conv);
+  // (an SH ray couples to neither converted ray: their weights through a zero factor)
+  const double psq_c = sh ? 0.0 : psq;
+  const double w_rc = ((rho1 * y1.re) * (four_cn2 * psq_c)) * norm(conv);
   const double w_ts = (k_t * x2.re) * norm(F);
-  const double w_tc = ((k_t * y2.re) * psq) * norm(H);
+  const double w_tc = ((k_t * y2.re) * psq_c) * norm(H);
   // SH: a = mu1 x1, b = mu2 x2; R = (a - b) / (a + b), T = 2 a / (a + b)
   const double ash = mu1 * x1;
   const Cx bsh = mu2 * x2;
@@ -948,8 +957,8 @@ R3D_HD RtWeights rt_weights_slowness(const Iface& f, double m2, double acn, int 
   RtWeights o;
   o.det2 = sh ? norm(cx(ash + bsh.re, bsh.im)) : norm(D);
   // (SH lanes: the P-SV block's numbers are finite -- the "other" velocities of an S ray are P velocities -- and left out)
-  const double s_rs = sh ? w_rsh : w_rs, s_ts = sh ? w_tsh : w_ts, s_rc = sh ? 0.0 : w_rc, s_tc = sh ? 0.0 : w_tc;
-  o.w[0] = sv ? s_rc : s_rs, o.w[1] = sv ? s_rs : s_rc, o.w[2] = sv ? s_tc : s_ts, o.w[3] = sv ? s_ts : s_tc;
+  const double s_rs = sh ? w_rsh : w_rs, s_ts = sh ? w_tsh : w_ts;
+  o.w[0] = sv ? w_rc : s_rs, o.w[1] = sv ? s_rs : w_rc, o.w[2] = sv ? w_tc : s_ts, o.w[3] = sv ? s_ts : w_tc;
   o.zr_own[0] = x1, o.zr_own[1] = x2.re, o.zr_oth[0] = y1.re, o.zr_oth[1] = y2.re;
   o.v_own[0] = own1, o.v_own[1] = own2, o.v_oth[0] = oth1, o.v_oth[1] = oth2;
   o.iv_in = iv;
@@ -1029,7 +1038,7 @@ R3D_HD RtChoice rt_choose(const Phonon& p, Iface f, double u_pol, double u_out) 
   const RtWeights o = rt_weights_slowness(f, m2, fabs(cn), intype);
   R3D_SCHED_FENCE();
   // Choose, rtcoef.cpp:436-475 (the partial sums of the six-entry table with its zero entries left out: the same values)
-  const double c0 = o.w[0], c1 = c0 + o.w[1], c2 = c1 + o.w[2], total = c2 + o.w[3];
+  const double c0 = o.w[0], c1 = c0 + o.w[1], c2 = c1 + o.w[2], total = c2 + o.w[3];   // (c1 either way round: the same bits)
   const double ran = u_out * total;
   int idx = 3;
   if (ran <= c2) idx = 2;
@@ -1066,10 +1075,10 @@ R3D_HD bool rt_apply(Phonon& p, V3 n, RtChoice ch) {
   if (out_s) {
     double w2;
     const V3 w = rt_plane_normal(n, p.dir, 0.0, w2);
-    V3 dopm;
-    if (sh) dopm = w;                              // SH stays SH
-    else if (reflected) dopm = cross(out, w);      // R_SV
-    else dopm = cross(w, out);                     // T_SV
+    // SH stays SH: w; R_SV: out x w; T_SV: w x out = -(out x w)
+    const V3 c = cross(out, w);
+    const double sg = reflected ? 1.0 : -1.0;
+    const V3 dopm = sh ? w : v3(sg * c.x, sg * c.y, sg * c.z);
     set_pol(p, dopm, out);
   }
   p.dir = out;

@@ -364,6 +364,21 @@ constexpr int kKeepersWord = 7;   // PoolCtl::word[kKeepersWord]: waves that kee
 #ifndef R3D_POOL_CHAIN_COLLECT
 #define R3D_POOL_CHAIN_COLLECT 1
 #endif
+// Layered models: a MOVE batch of which at least this many lanes end on an interface that wants the reflection /
+// transmission solve serves it itself (0: never; see the MOVE phase).
+#ifndef R3D_CYL_INLINE_RT
+#define R3D_CYL_INLINE_RT 40
+#endif
+// ... and the thin batches of a tetra model's drain (kernels with a tail; a lone NSCP history 2.91 -> 2.72 us per move, flush
+// -4 %.  Not the shell kernel: a spherical model's flush is a twentieth of its step and gains nothing, and the solve's
+// registers beside the move's cost its self-contained launch 3 % -- profiles/r06/inline_rt_ab.log).
+#ifndef R3D_TAIL_INLINE_RT
+#define R3D_TAIL_INLINE_RT 1
+#endif
+#ifndef R3D_INLINE_RT_THIN_NUM
+#define R3D_INLINE_RT_THIN_NUM 1u
+#define R3D_INLINE_RT_THIN_DEN 2u
+#endif
 #ifndef R3D_POOL_CHAIN_REFILL
 #define R3D_POOL_CHAIN_REFILL 0
 #endif
@@ -642,6 +657,9 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   // the drain's kept lanes four to a history (tetra cells; not in the diagnostic kernel, whose report stream is per lane)
   constexpr bool kQuad = TAIL && !TRACE && KIND == CELL_TET && R3D_POOL_QUAD_DRAIN != 0;
   constexpr bool kChainCollect = kChainMove && R3D_POOL_CHAIN_COLLECT != 0;
+  // the interface solve inside the MOVE phase (layered models: the MOVE phase below)
+  constexpr bool kInlineRt = (KIND == CELL_CYL && R3D_CYL_INLINE_RT != 0) || (TAIL && !TRACE && KIND == CELL_TET && R3D_TAIL_INLINE_RT != 0);
+  constexpr unsigned kInlineRtLanes = (KIND == CELL_CYL && R3D_CYL_INLINE_RT != 0) ? R3D_CYL_INLINE_RT : 65u;   // (65: thin batches only)
   constexpr bool kChainRefill = kChainMove && R3D_POOL_CHAIN_REFILL != 0 && KIND == CELL_CYL;
   bool held = false;
   unsigned k_chain = 0;   // (wave-uniform) slots of the batch just served that all want MOVE next and stay with this wave
@@ -728,7 +746,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
     if constexpr (TAIL) dest = act ? Q_FREE : dest;
     else dest = Q_FREE;
     // the batch's event counts (wave-uniform; scalar registers), added to the block's tallies together below
-    uint32_t n_iter = 0, n_transfer = 0, n_reflect = 0, n_generated = 0, n_collect = 0, n_catch = 0;
+    uint32_t n_iter = 0, n_transfer = 0, n_reflect = 0, n_generated = 0, n_collect = 0, n_catch = 0, n_rtsolve = 0;
     uint32_t n_volout = 0;   // (video runs: events outside the attached grid)
     n_lost = 0, n_timeout = 0;
 
@@ -874,8 +892,24 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
             leaving = false;   // hand-over or bend: served right here, and on to the next move
           }
         }
-        const bool light = live && !leaving;
+        bool light = live && !leaving;
         if (light) step_event<KIND, EV_BEND>(a, T, p, rng, st, ev, ev.nbr);
+        if constexpr (kInlineRt) {
+          // Layered models: nearly every move ends on an interface that wants the solve, so when most of the batch
+          // does, the wave serves it here, on the state it holds -- no hand-off, no take, no store and reload of the
+          // slots -- and those lanes go on to their next move with the others (a thin batch: whenever any does).
+          const bool wants = live && leaving && dest == Q_RT;
+          const unsigned n_wants = count(wants && lead);
+          // (a thin batch: when at least half of its histories want it -- the solve for a few lanes of many keeps the
+          //  others from their next move for two thousand cycles, and the queue would batch those few with others')
+          if (n_wants != 0u && n_wants >= (thin ? (quad ? 1u : (k * R3D_INLINE_RT_THIN_NUM + R3D_INLINE_RT_THIN_DEN - 1u) / R3D_INLINE_RT_THIN_DEN) : kInlineRtLanes)) {
+            if (wants) {
+              step_event<KIND, EV_RT>(a, T, p, rng, st, ev, ev.nbr);
+              leaving = false, light = true, dest = Q_MOVE;
+            }
+            n_rtsolve += n_wants;
+          }
+        }
         if (TRACE) {
           report(st.reflect != 0u, 2, p, hid);    // REF
           report(st.transfer != 0u, 4, p, hid);   // CEL
@@ -1027,7 +1061,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       tally_n(kEv + R3D_EV_ITERATIONS, n_iter), tally_n(kEv + R3D_EV_TRANSFER, n_transfer);
       tally_n(kEv + R3D_EV_REFLECT, n_reflect);
       tally_n(kEv + R3D_EV_VOLUME_OUT, n_volout);
-      if (q == Q_RT) tally_n(kEv + R3D_EV_RTSOLVE, k);
+      tally_n(kEv + R3D_EV_RTSOLVE, q == Q_RT ? k : n_rtsolve);
     } else {
       // lane j holds what the batch adds to tally j (include/r3d.h: lost, timeout, invalid + reasons, the
       // eight event counters): one LDS add for all of them
@@ -1049,7 +1083,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       R3D_PUT(kEv + R3D_EV_REFLECT, n_reflect);
       R3D_PUT(kEv + R3D_EV_VOLUME_OUT, n_volout);
       R3D_PUT(kEv + R3D_EV_TRANSFER, n_transfer);
-      R3D_PUT(kEv + R3D_EV_RTSOLVE, q == Q_RT ? k : 0u);
+      R3D_PUT(kEv + R3D_EV_RTSOLVE, q == Q_RT ? k : n_rtsolve);
 #undef R3D_PUT
       if (lane < (unsigned)R3D_N_SCALARS && tv) atomicAdd(&s_tally[lane], (unsigned long long)tv);
     }

@@ -224,7 +224,7 @@ def test_main_cli_writes_the_scatter_grid_of_a_video_run_on_gpu(tmp_path):
     assert (got == want).all() and int(hdr["GridEventsBinned"]) == int(want.sum()) > 100000
     assert int(hdr["GridSaturatedCells"]) == 0
     assert f"{int(want.sum())} events binned" in run.stdout
-    assert "|  Shards: 3 (summed by host)" in run.stdout     # (three shards on ONE device: RCCL refuses that communicator)
+    assert "|  Shards: 3 (summed by host: shards share a device)" in run.stdout     # (three shards on ONE device: RCCL refuses that communicator)
     lost = int(re.search(r"Loss surfaces:\s+(\d+)", run.stdout).group(1))
     assert lost == res.n_lost
     assert not os.path.exists(tmp_path / "grid.u32.part")
