@@ -377,16 +377,22 @@ int r3d_run_device_carry(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t 
 int r3d_run_traced(r3d_engine* e, uint64_t n, uint64_t first_id, uint64_t seed,
                    r3d_result* out, r3d_final* finals);
 
-/* The same records out of the PRODUCTION kernels -- the code objects r3d_run, r3d_run_device,
- * r3d_run_device_carry and a chain's flush launch, i.e. the ones that are timed (r3d_run_traced runs the
- * diagnostic kernel, another compilation).  r3d_engine_set_production_finals attaches an engine-owned buffer of
- * `capacity` records: from then on a history with base_id <= id < base_id + capacity leaves its final record
- * where it ends, in whichever launch of a chain that is (capacity 0 detaches); while a buffer is attached a
- * launch whose ids it does not cover is refused, and a buffer cannot be attached or detached while histories
- * are carried over.  r3d_production_finals_read
- * copies records [first, first + count) to the host (waits for the engine's launches).  A record never
- * written has fate 255; n_catch is 0xFFFF in all of them (only the diagnostic kernel counts catches per
- * history).  Costs a run without a buffer one scalar test per batch in which a history ends.           */
+/* The same records out of the PRODUCTION kernels that end histories for good (r3d_run_traced runs the diagnostic
+ * kernel, another compilation).  r3d_engine_set_production_finals attaches an engine-owned buffer of `capacity`
+ * records; from then on a history with base_id <= id < base_id + capacity leaves its final record when it ends in
+ *   - a SELF-CONTAINED launch (r3d_run, r3d_run_device, r3d_node_run, r3d_run_device_carry with final != 0 and
+ *     ids of its own): every history of the launch, or
+ *   - a chain's FLUSH (r3d_run_device_carry with final != 0): the histories carried into it.
+ * A chain's STEP launches (r3d_run_device_carry with final == 0) write NO record: their kernel is compiled without
+ * that code (it cost the launch 3.5 %), so a history that ends inside a step launch keeps fate 255 -- "never written"
+ * -- and is accounted for through the bins and counters it leaves; launches that run the diagnostic kernel (an event
+ * log or r3d_run_traced's records attached) do not write these records either.  (A test-only compilation with the
+ * step kernel's stores in, `make variant DEFS=-DR3D_STEP_FINALS=1`, is held against the oracle per history.)
+ * Capacity 0 detaches; while a buffer is attached a launch whose ids it does not cover is refused, and a buffer
+ * cannot be attached or detached while histories are carried over.  r3d_production_finals_read copies records
+ * [first, first + count) to the host (waits for the engine's launches).  n_catch is 0xFFFF in all of them (only
+ * the diagnostic kernel counts catches per history); `amp` is exponentiated on the host by the read.  Costs a run
+ * without a buffer one scalar test per batch in which a history ends.                                        */
 int r3d_engine_set_production_finals(r3d_engine* e, uint64_t base_id, uint64_t capacity);
 int r3d_production_finals_read(r3d_engine* e, r3d_final* out, uint64_t first, uint64_t count);
 

@@ -112,10 +112,32 @@ def upthrust(deg=4):
             "--seis-p2p=0,112.5,0,950,112.5,0,1.0,2.0,40.0,40").split()
 
 
+def lopnor_moho(deg=4, selector=1):
+    """The Lop Nor model with its Moho transition layers: selectors 1-4 of the reference's dispatcher given 20 or more
+    model arguments (user.cpp:69-80 -> LopNorCylinderMoho, user_LopNorCylMoho_inc.cpp; four scattering regions of five
+    numbers each), run as do-lopnor.sh runs the baseline model (earthquake source, the script's two arrays)."""
+    return (f"--grid-compiled={selector} --flatten --range=1200 "
+            "--model-args=0.8,0.06,0.25,0.5,250,0.8,0.05,0.5,0.5,1000,0.8,0.04,1.0,0.5,2000,0.7,0.03,0.4,0.3,1500 "
+            "--source=SDR,125,40,90,0.0 --source-loc=425.54,-169.53,-31.02 --frequency=2.0 --timetolive=600 "
+            f"--binsize=2.00 --toa-degree={deg} "
+            "--seis-p2p=425.54,-169.53,0.98,-390.04,-167.18,1.457,1.0,2.0,40.0,40 "
+            "--seis-p2p=425.54,-169.53,0.98,-102.27,430.84,0.60,1.0,2.0,40.0,40").split()
+
+
+def scat_params_study(deg=4):
+    """Selector 128 (user.cpp:115-118 -> ScatParamsStudy, user.cpp:200-310: a stack of layers that differ in one
+    scattering parameter at a time), with the half-space run's source and arrays (no reference run script uses it)."""
+    return ("--grid-compiled=128 --range=300 --source=SDR,0,90,0,0.0 --source-loc=0,0,-5 --frequency=2.0 "
+            f"--timetolive=200 --binsize=0.50 --toa-degree={deg} "
+            "--seis-p2p=0,0,0,100,100,0,2.737,0.105,10.0,24 --seis-p2p=0,0,0,140,0,0,2.737,0.105,10.0,24").split()
+
+
 def halfspace_one(deg=9):
     """BASELINE config 1 as it names it: the half-space run with one receiver."""
     return halfspace(deg, one_receiver=True)
 
 
 CONFIGS = {"halfspace": halfspace, "halfspace_one": halfspace_one, "crustpinch": crustpinch, "crustpinch_vids": crustpinch_vids, "lopnor": lopnor, "sphere": sphere, "sphere_deep": sphere_deep,
-           "toysphere_vids": toysphere_vids, "lopnor_vids": lopnor_vids, "upthrust": upthrust}
+           "toysphere_vids": toysphere_vids, "lopnor_vids": lopnor_vids, "upthrust": upthrust,
+           "lopnor_moho": lopnor_moho, "lopnor_moho_sel3": lambda deg=4: lopnor_moho(deg, selector=3),
+           "scat_params_study": scat_params_study}

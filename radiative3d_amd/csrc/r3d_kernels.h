@@ -12,16 +12,13 @@
 
 namespace r3d {
 
-#ifndef R3D_POOL_BLOCK
-#define R3D_POOL_BLOCK 768
-#endif
 // 12 waves = 3 per SIMD, i.e. a budget of 168 registers per lane.  At two waves per SIMD a wave that
 // waits (memory round trips, dependent fp64 chains) is covered by one other only, so a third is
 // worth 15-25 % -- once every phase fits the budget: the R/T solve in two halves with nothing but
 // the choice carried across, event counters that live for one batch, the launch arguments fetched
 // per batch (0-4 vector registers spilled).  Measured at 512 / 768 threads, same code otherwise:
 // NSCP 15.8 / 12.8 ms, LopNor 13.9 / 11.0, SphereEarth 40.8 / 33.0 per 3e6 histories.
-constexpr int kPoolBlock = R3D_POOL_BLOCK;
+constexpr int kPoolBlock = 768;
 
 enum { Q_MOVE = 0, Q_COLLECT = 1, Q_RT = 2, Q_SCATTER = 3, Q_FREE = 4, Q_NUM = 5 };
 

@@ -14,12 +14,8 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define R3D_HD __host__ __device__ __forceinline__
-// A function that is CALLED, not inlined: its registers are allocated on their own, and what the caller
-// holds across the call is saved around it -- for code that one move in ten thousand runs.
-#define R3D_HD_COLD inline __host__ __device__ __attribute__((noinline))
 #else
 #define R3D_HD inline
-#define R3D_HD_COLD inline
 #endif
 
 // A point the instruction scheduler may not move code across (device builds).  The long

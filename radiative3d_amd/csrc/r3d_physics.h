@@ -551,10 +551,6 @@ R3D_HD TetSlowOut tet_move_reference_inline(const CellTet* cp, Phonon p, double 
   return o;
 }
 
-R3D_HD_COLD TetSlowOut tet_move_reference(const CellTet* cp, Phonon p, double u_free, double mfp) {
-  return tet_move_reference_inline(cp, p, u_free, mfp);
-}
-
 // ===================================================================== SPH ==
 R3D_HD double sph_linear_exit(double radius, V3 loc, V3 dir) {
   // reference SphereFace::LinearRayDistToExit, media_cellface.cpp:664-684

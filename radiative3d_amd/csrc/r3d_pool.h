@@ -49,12 +49,8 @@ namespace r3d {
 
 // Wave priority: raised while a wave is between batches (hand-off, scheduling, take) -- serial LDS
 // round trips during which it holds slots other waves may be polling for -- and lowered for the
-// phase's arithmetic: from the hand-off until the next batch's state is in registers
-// (R3D_PRIO_NARROW: around the hand-off and the take only).
-#ifndef R3D_POOL_PRIO
-#define R3D_POOL_PRIO 2
-#endif
-#define R3D_PRIO_HIGH() __builtin_amdgcn_s_setprio(R3D_POOL_PRIO)
+// phase's arithmetic: from the hand-off until the next batch's state is in registers.
+#define R3D_PRIO_HIGH() __builtin_amdgcn_s_setprio(2)
 #define R3D_PRIO_LOW() __builtin_amdgcn_s_setprio(0)
 #define R3D_PRIO_MOVE() __builtin_amdgcn_s_setprio(1)
 constexpr int kPoolWaves = kPoolBlock / 64;
@@ -171,25 +167,6 @@ __device__ __forceinline__ void q_push_all(PoolCtl& ctl, lds_u16* rings, uint32_
   if (lane < Q_NUM && kq) atomicAdd(&ctl.word[lane], kq);
 }
 
-// The same for a batch whose first k lanes ALL go to queue q (what a reflection / transmission or a
-// scattering batch does: on to MOVE): no lane masks, no ranks -- lane l takes ticket l of the k.
-__device__ __forceinline__ void q_push_one(PoolCtl& ctl, lds_u16* rings, uint32_t rcap, uint32_t log2cap, int q,
-                                           unsigned lane, unsigned k, unsigned id) {
-  uint32_t pos = 0;
-  if (lane == 0) pos = atomicAdd(&ctl.tail[q], k);
-  R3D_LDS_RELEASE();   // (the slots' state before their numbers)
-  pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
-  if (lane < k) {
-    const uint32_t t = pos + lane;
-    volatile lds_u16* e = rings + (((uint32_t)q << log2cap) | (t & (rcap - 1u)));
-    while (*e != kRingEmpty) {
-    }
-    *e = (uint16_t)((lap_of(t, log2cap) << kSlotBits) | id);
-  }
-  R3D_LDS_RELEASE();
-  if (lane == 0) atomicAdd(&ctl.word[q], k);
-}
-
 // Seismometer collection for a batch of arrivals (one per lane with k1 > k0): the same tests and
 // bin updates as collect() in r3d_step.h (reference dataout.cpp:103-216, :545-568).  The
 // (arrival, candidate receiver) pairs of the whole batch are numbered through a prefix sum of
@@ -204,16 +181,7 @@ __device__ __forceinline__ uint32_t pool_collect_pairs(const KArgs& a, const Tab
                                                        const uint16_t* lds_items /* or null: a.grid.items */,
                                                        unsigned lane, uint32_t& lane_catches, const BinCache& bc) {
   const uint32_t cnt = k1 - k0;
-#if R3D_COLLECT_DPP
   const uint32_t incl = wave_scan_add(cnt);   // inclusive prefix sum over the wave (r3d_wave.h: no LDS round trips)
-#else
-  uint32_t incl = cnt;   // inclusive prefix sum over the wave
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t y = __shfl_up(incl, off);
-    if (lane >= (unsigned)off) incl += y;
-  }
-#endif
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   const uint32_t excl = incl - cnt;
   V3 dopm = p.dir;
@@ -228,7 +196,6 @@ __device__ __forceinline__ uint32_t pool_collect_pairs(const KArgs& a, const Tab
   for (uint32_t base = 0; base < total; base += 64u) {
     const uint32_t j = base + lane;
     uint32_t src = 0;   // smallest lane whose inclusive sum exceeds j
-#if R3D_COLLECT_DPP
     {
       // Who owns pair j?  Every arrival whose range STARTS inside this pass's window of 64 pairs sends its lane number
       // to the lane of the pair it starts at (one forward permute; every such lane has its own target: arrivals without
@@ -242,13 +209,6 @@ __device__ __forceinline__ uint32_t pool_collect_pairs(const KArgs& a, const Tab
       const uint32_t mark = (uint32_t)__builtin_amdgcn_ds_permute((starts ? pos : 0) << 2, (int)((starts ? lane : src0) + 1u));
       src = wave_scan_max(mark) - 1u;
     }
-#else
-#pragma unroll
-    for (uint32_t step = 32u; step; step >>= 1) {
-      const uint32_t v = (uint32_t)__shfl((int)incl, (int)(src + step - 1u));
-      if (v <= j) src += step;
-    }
-#endif
     const bool valid = j < total;
     src = valid ? src : lane;
     const uint32_t k = (uint32_t)__shfl((int)k0, (int)src) + (j - (uint32_t)__shfl((int)excl, (int)src));
@@ -312,15 +272,9 @@ static __device__ unsigned long long g_pool_stats[5][8];   // rows 3 / 4: cycles
 // Moves a batch may make before its slots go back to the queues: lanes whose move ends with nothing
 // to do but change cells (or bend) stay in registers and move again while at least kMoveAgainLanes
 // of them do, so the pool round trip is paid once per several moves.
-#ifndef R3D_POOL_MOVES
-#define R3D_POOL_MOVES 4
-#endif
-#ifndef R3D_POOL_MOVE_AGAIN
-#define R3D_POOL_MOVE_AGAIN 44
-#endif
-constexpr int kPoolMoves = R3D_POOL_MOVES;
+constexpr int kPoolMoves = 4;
 constexpr int kPoolMovesThin = 32;   // (bounded, so that a drained launch with carry-over still parks promptly)
-constexpr unsigned kMoveAgainLanes = R3D_POOL_MOVE_AGAIN;
+constexpr unsigned kMoveAgainLanes = 44;
 // The drain of a launch that finishes its own stragglers (the ids are out, ever fewer histories are
 // alive): a wave that has served a THIN batch -- no more than kTailBatch slots -- KEEPS those slots
 // for as long as they all want the same next phase, and serves that phase itself: no hand-off, no
@@ -331,80 +285,27 @@ constexpr unsigned kMoveAgainLanes = R3D_POOL_MOVE_AGAIN;
 // different waves at once (whole batches kept whatever they want: LopNor's flush 11.1 -> 14.1 ms): a
 // batch that disagrees goes back to the queues, which also regroup the stragglers.  No more than
 // kPoolWaves - kTailServers waves keep lanes at a time, so that what waits in a queue is always served.
-#ifndef R3D_POOL_TAIL_BATCH
-#define R3D_POOL_TAIL_BATCH 16
-#endif
-constexpr uint32_t kTailBatch = R3D_POOL_TAIL_BATCH, kTailServers = 2;
+constexpr uint32_t kTailBatch = 16, kTailServers = 2;
 constexpr int kKeepersWord = 7;   // PoolCtl::word[kKeepersWord]: waves that keep lanes at the moment
+// Developer builds (make variant DEFS=-DR3D_STEP_FINALS=1): the final record's code in the chain-step kernel too, which
+// the shipped kernel is compiled without (3.5 % of its launch).  tests/test_gpu_parity.py holds that sibling compilation
+// per history against the oracle.
+#ifndef R3D_STEP_FINALS
+#define R3D_STEP_FINALS 0
+#endif
+// Layered models: a full MOVE batch of which at least this many lanes end on an interface that wants the reflection /
+// transmission solve serves it itself, on the state it holds (the MOVE phase below); a thin batch: when at least half
+// of its histories do.  A lone LopNor history 4.27 -> 3.57 us per move, flush 9.3 -> 8.0 ms, step launch 6.60 -> 6.38.
+// The same for the thin batches of a tetra model's drain (kernels with a tail: a lone NSCP history 2.91 -> 2.72 us per
+// move, flush -4 %); not the shell kernel (a spherical model's flush is a twentieth of its step and gains nothing, and
+// the solve's registers beside the move's cost its self-contained launch 3 %).  profiles/r06/inline_rt_ab.log.
+constexpr unsigned kInlineRtFullBatch = 40;
 // A refill starts kRefillBatches batches of histories at a time, their table fetches set going together (the
 // FREE phase below); the FREE queue counts as full for the scheduler at kRefillFull entries.
-// Final records out of the production kernels when a buffer is attached (include/r3d.h
-// r3d_engine_set_production_finals); 0 compiles the code out (developer builds: what it costs).
-#ifndef R3D_PRODUCTION_FINALS
-#define R3D_PRODUCTION_FINALS 1
-#endif
-// A reflection / transmission or scattering batch hands ALL its slots to MOVE: with R3D_POOL_CHAIN_MOVE the wave that
-// served it serves that move itself, next -- no hand-off, no scheduling, no take (the slots' state is in LDS as for a
-// hand-off and the move reads it back).
-#ifndef R3D_POOL_CHAIN_MOVE
-#define R3D_POOL_CHAIN_MOVE 2
-#endif
-// The collection phase's prefix sum and pair-to-arrival map on data-parallel primitives (r3d_wave.h wave_scan_*) instead
-// of cross-lane fetches through the LDS crossbar.
-#ifndef R3D_COLLECT_DPP
-#define R3D_COLLECT_DPP 1
-#endif
-// The drain's kept histories four lanes each in the tetra move (the MOVE phase below, kQuad; r3d_physics.h
-// tet_fast_exit_quad): a drain is its longest history's instruction chain at ONE wave's issue rate, with 3-4 of the wave's
-// 64 lanes alive, so the idle lanes take a face of the boundary search each.  A lone NSCP history 3.06 -> 2.95 us per
-// move, flush 4.2 -> 3.8 ms, the literal 1e7 job 12.0 -> 11.9 ms (same-call A/B); results equal, face for face.
-#ifndef R3D_POOL_QUAD_DRAIN
-#define R3D_POOL_QUAD_DRAIN 1
-#endif
-#ifndef R3D_POOL_CHAIN_COLLECT
-#define R3D_POOL_CHAIN_COLLECT 1
-#endif
-// Layered models: a MOVE batch of which at least this many lanes end on an interface that wants the reflection /
-// transmission solve serves it itself (0: never; see the MOVE phase).
-#ifndef R3D_CYL_INLINE_RT
-#define R3D_CYL_INLINE_RT 40
-#endif
-// ... and the thin batches of a tetra model's drain (kernels with a tail; a lone NSCP history 2.91 -> 2.72 us per move, flush
-// -4 %.  Not the shell kernel: a spherical model's flush is a twentieth of its step and gains nothing, and the solve's
-// registers beside the move's cost its self-contained launch 3 % -- profiles/r06/inline_rt_ab.log).
-#ifndef R3D_TAIL_INLINE_RT
-#define R3D_TAIL_INLINE_RT 1
-#endif
-#ifndef R3D_INLINE_RT_THIN_NUM
-#define R3D_INLINE_RT_THIN_NUM 1u
-#define R3D_INLINE_RT_THIN_DEN 2u
-#endif
-#ifndef R3D_POOL_CHAIN_REFILL
-#define R3D_POOL_CHAIN_REFILL 0
-#endif
-#ifndef R3D_TET_REFILL_PAIRS
-#define R3D_TET_REFILL_PAIRS 0
-#endif
-#ifndef R3D_TET_VECTOR_TALLY
-#define R3D_TET_VECTOR_TALLY 0
-#endif
-#ifndef R3D_POOL_REFILL_PAIRS
-#define R3D_POOL_REFILL_PAIRS 1
-#endif
-constexpr bool kRefillPairs = R3D_POOL_REFILL_PAIRS != 0;
-#ifndef R3D_POOL_REFILL_BATCHES
-#define R3D_POOL_REFILL_BATCHES 2
-#endif
-constexpr int kRefillBatches = R3D_POOL_REFILL_BATCHES;
-#ifndef R3D_POOL_REFILL_FULL
-#define R3D_POOL_REFILL_FULL (R3D_POOL_REFILL_PAIRS ? 64 * R3D_POOL_REFILL_BATCHES : 64)
-#endif
-constexpr uint32_t kRefillFull = R3D_POOL_REFILL_FULL;
+constexpr int kRefillBatches = 2;
+constexpr uint32_t kRefillFull = 64 * kRefillBatches;
 // Entries a minor phase's queue must hold before a wave goes for it.
-#ifndef R3D_POOL_MINOR_FULL
-#define R3D_POOL_MINOR_FULL 64
-#endif
-constexpr uint32_t kMinorFull = R3D_POOL_MINOR_FULL;
+constexpr uint32_t kMinorFull = 64;
 
 // LDS_CELLS / LDS_SCAT: the cell records / the scatterer heads are staged in LDS (models with a few
 // dozen cells; all but models with thousands of scatterers).  The receiver tables are read through
@@ -418,7 +319,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   // refills in pairs of batches (the FREE phase): not in the tetra kernel, whose boundary search leaves the
   // register allocator no slack at all -- the pair's second queue take alone had it spill two registers in the
   // move, and 64 slots waiting for their partners are a smaller pool (NSCP +3 % with it, half-space -10 %)
-  constexpr bool kPairs = kRefillPairs && (KIND != CELL_TET || R3D_TET_REFILL_PAIRS);
+  constexpr bool kPairs = KIND != CELL_TET;
   extern __shared__ __align__(16) unsigned char smem[];
   const unsigned tid = threadIdx.x, lane = tid & 63u;
 
@@ -552,7 +453,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   // A batch's counts go to the block's tallies as ONE LDS instruction where the batch ends (lane j adds
   // to tally j), in the layered and the spherical kernel; the tetra kernel, with no vector register to
   // spare for that, adds them one by one where they arise (the vector form there: +0.8 %).
-  constexpr bool kVectorTally = KIND != CELL_TET || R3D_TET_VECTOR_TALLY;
+  constexpr bool kVectorTally = KIND != CELL_TET;
   uint32_t n_lost = 0, n_timeout = 0;   // (per batch, like the event counts: reset where a batch starts)
   auto finish = [&](bool died, int fate, int reason, const Phonon& p, uint64_t hid, uint32_t catches, unsigned slot) {
     if (!any_lane(died)) return;
@@ -567,7 +468,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
 #pragma unroll
       for (int r = 0; r < R3D_INV_NUM; r++) tally(died && fate == FATE_INVALID && reason == r, 3 + r);
     }
-    if (!TRACE && TAIL && R3D_PRODUCTION_FINALS) {
+    if (!TRACE && (TAIL || R3D_STEP_FINALS)) {
       // (the production kernels' own witness, when a buffer is attached: everything but the catch count, which
       //  only the diagnostic kernel keeps per history.  In the self-contained and the drain kernel; compiled into
       //  the chain-step kernel too it cost the NSCP launch 3.5 % -- four to six registers spilled -- with no
@@ -650,17 +551,14 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
   typedef const __attribute__((address_space(4))) KArgs* KernArgs;
   KernArgs args = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();   // (KArgs is the kernels' only parameter)
   // the drain (kTailBatch above): the lanes that keep their slot, and the phase they all want next
-  constexpr bool kChainMove = R3D_POOL_CHAIN_MOVE != 0 && (!TAIL || R3D_POOL_CHAIN_MOVE > 1);
+  constexpr bool kChainMove = true;   // a batch that goes on to its move as a whole is served by the wave that has it
   constexpr int kChainFlag = 8;   // (above the queue numbers 0 .. Q_NUM - 1)
-  // ... and a refill whose slots all got a history: in the layered kernel only (the tetra and the shell kernel spill
-  // 13-40 registers under it: their moves leave no room for the spray's values beside them)
   // the drain's kept lanes four to a history (tetra cells; not in the diagnostic kernel, whose report stream is per lane)
-  constexpr bool kQuad = TAIL && !TRACE && KIND == CELL_TET && R3D_POOL_QUAD_DRAIN != 0;
-  constexpr bool kChainCollect = kChainMove && R3D_POOL_CHAIN_COLLECT != 0;
+  constexpr bool kQuad = TAIL && !TRACE && KIND == CELL_TET;
+  constexpr bool kChainCollect = kChainMove;
   // the interface solve inside the MOVE phase (layered models: the MOVE phase below)
-  constexpr bool kInlineRt = (KIND == CELL_CYL && R3D_CYL_INLINE_RT != 0) || (TAIL && !TRACE && KIND == CELL_TET && R3D_TAIL_INLINE_RT != 0);
-  constexpr unsigned kInlineRtLanes = (KIND == CELL_CYL && R3D_CYL_INLINE_RT != 0) ? R3D_CYL_INLINE_RT : 65u;   // (65: thin batches only)
-  constexpr bool kChainRefill = kChainMove && R3D_POOL_CHAIN_REFILL != 0 && KIND == CELL_CYL;
+  constexpr bool kInlineRt = KIND == CELL_CYL || (TAIL && !TRACE && KIND == CELL_TET);
+  constexpr unsigned kInlineRtLanes = KIND == CELL_CYL ? kInlineRtFullBatch : 65u;   // (65: thin batches only)
   bool held = false;
   unsigned k_chain = 0;   // (wave-uniform) slots of the batch just served that all want MOVE next and stay with this wave
   bool ids_out = false;   // (wave-uniform) the id counter was seen exhausted
@@ -729,9 +627,6 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       ids_out = drained != 0u;
       R3D_PRIO_HIGH();
       k = q_pop(ctl, ring(q), rmask, rlog, q, lane, wq, id);
-#ifdef R3D_PRIO_NARROW
-      R3D_PRIO_LOW();
-#endif
       if (k == 0) {   // another wave was quicker
         R3D_PRIO_LOW();
         continue;
@@ -750,9 +645,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
     uint32_t n_volout = 0;   // (video runs: events outside the attached grid)
     n_lost = 0, n_timeout = 0;
 
-#ifndef R3D_PRIO_NARROW
     if (q == Q_FREE) R3D_PRIO_LOW();
-#endif
     if (q == Q_FREE) {
       // ---- fresh histories: ids from the global counter, source spray (events.cpp:111-124) ----
       // A refill starts TWO batches of histories at a time (kRefillBatches; the scheduler lets the FREE queue
@@ -863,9 +756,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       bool live = act;   // still moving in registers
       if (act) {
         load_state(id, p, rng, meta, nbr0);
-#ifndef R3D_PRIO_NARROW
         R3D_PRIO_MOVE();   // (the phase every other one waits for: above them, below a wave between batches)
-#endif
         hid = ((uint64_t)rng.id_hi << 32) | rng.id_lo;
       }
 #pragma nounroll
@@ -902,7 +793,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
           const unsigned n_wants = count(wants && lead);
           // (a thin batch: when at least half of its histories want it -- the solve for a few lanes of many keeps the
           //  others from their next move for two thousand cycles, and the queue would batch those few with others')
-          if (n_wants != 0u && n_wants >= (thin ? (quad ? 1u : (k * R3D_INLINE_RT_THIN_NUM + R3D_INLINE_RT_THIN_DEN - 1u) / R3D_INLINE_RT_THIN_DEN) : kInlineRtLanes)) {
+          if (n_wants != 0u && n_wants >= (thin ? (quad ? 1u : (k + 1u) / 2u) : kInlineRtLanes)) {
             if (wants) {
               step_event<KIND, EV_RT>(a, T, p, rng, st, ev, ev.nbr);
               leaving = false, light = true, dest = Q_MOVE;
@@ -955,9 +846,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       ev.vel = 0.0, ev.face = 0, ev.flags = 0u, ev.nbr = -1;
       if (act) {
         load_state(id, p, rng, meta, nbr);
-#ifndef R3D_PRIO_NARROW
         R3D_PRIO_LOW();
-#endif
         hid = ((uint64_t)rng.id_hi << 32) | rng.id_lo;
         ev.face = (int)((meta >> 1) & 7u) - 1, ev.flags = (meta >> 8) & 0xFFu;
         vel = velocity_in<KIND>(T, p.cell, p.loc, p.type);
@@ -1020,9 +909,7 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       LaneStats st = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       if (act) {
         load_state(id, p, rng, meta, nbr);
-#ifndef R3D_PRIO_NARROW
         R3D_PRIO_LOW();
-#endif
         hid = ((uint64_t)rng.id_hi << 32) | rng.id_lo;
         Pending ev;
         ev.vel = 0.0, ev.face = (int)((meta >> 1) & 7u) - 1, ev.flags = (meta >> 8) & 0xFFu, ev.nbr = -1;
@@ -1123,20 +1010,15 @@ __device__ __forceinline__ void pool_body(const KArgs& a) {
       // (a full collection batch whose arrivals are all reflected -- a free surface: every one of them --: its solve next)
       if (!TAIL) k_chain = (unsigned)__builtin_amdgcn_readfirstlane((int)(k | ((unsigned)Q_RT << 8)));
       else held = act, dest = act ? (Q_RT | kChainFlag) : dest, chain_set = true;
-    } else if (!was_kept && (q == Q_RT || q == Q_SCATTER || (kChainRefill && q == Q_FREE && !any_lane(act && dest != Q_MOVE)))) {
-      // (all on to MOVE -- every R/T and scattering batch, and a refill whose slots all got a history; a batch fresh
-      //  from a queue, or chained, sits in lanes 0 .. k-1)
-      if (kChainMove && !TAIL) k_chain = (unsigned)__builtin_amdgcn_readfirstlane((int)(k | ((unsigned)Q_MOVE << 8)));   // served by this wave next: see the top of the loop
-      else if (kChainMove) held = act, dest = act ? (Q_MOVE | kChainFlag) : dest, chain_set = true;   // ... as held lanes, in the kernels with a tail
-      else q_push_one(ctl, rings, rcap, rlog, Q_MOVE, lane, k, id);
+    } else if (!was_kept && (q == Q_RT || q == Q_SCATTER)) {
+      // (all on to MOVE -- every R/T and scattering batch; a batch fresh from a queue, or chained, sits in lanes 0 .. k-1)
+      if (!TAIL) k_chain = (unsigned)__builtin_amdgcn_readfirstlane((int)(k | ((unsigned)Q_MOVE << 8)));   // served by this wave next: see the top of the loop
+      else held = act, dest = act ? (Q_MOVE | kChainFlag) : dest, chain_set = true;   // ... as held lanes, in the kernels with a tail
     }
     else q_push_all(ctl, rings, rcap, rlog, lane, act, dest, id);
     if constexpr (TAIL) {
       if (!keep_lanes && !chain_set) held = false;
     }
-#ifdef R3D_PRIO_NARROW
-    R3D_PRIO_LOW();
-#endif
 #ifdef R3D_PHASE_TIMING
     if (lane == 0) {
       const unsigned long long t_end = __builtin_readcyclecounter();

@@ -28,21 +28,6 @@
 #define R3D_ADD_U32(ptr, val) (*(ptr) += (unsigned int)(val))
 #endif
 
-// The tetra move: 1 the local form, certified, with the reference's construction behind it; 0 (developer builds:
-// timing comparisons) the reference's construction for every lane.  R3D_TET_SLOW_CALL: that construction as a called
-// function (1) or inlined (0).
-#ifndef R3D_TET_LOCAL
-#define R3D_TET_LOCAL 1
-#endif
-#ifndef R3D_SPH_LOCAL
-#define R3D_SPH_LOCAL 1
-#endif
-#ifndef R3D_TET_EARLY_MFP
-#define R3D_TET_EARLY_MFP 0
-#endif
-#ifndef R3D_TET_SLOW_CALL
-#define R3D_TET_SLOW_CALL 0
-#endif
 // (tests/emul counts the moves that take the reference's construction; nothing in a device build)
 #ifndef R3D_COUNT_SLOW_MOVE
 #define R3D_COUNT_SLOW_MOVE() ((void)0)
@@ -306,7 +291,7 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
   //  soon as that is in, not where the free path is formed, a boundary search later; the tetra
   //  kernel has no register to spare for it across the search: +2 % with two spilled)
   double mfp = 0;
-  if constexpr (KIND != CELL_TET || R3D_TET_EARLY_MFP) {
+  if constexpr (KIND != CELL_TET) {
     mfp = T.scat_head[cell_scat(c)].mfp[p.type];
     R3D_SCHED_FENCE();
   }
@@ -320,7 +305,6 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
     // feet: one move in 1e4 in a tetrahedral grid -- takes the reference's own construction, as before.
     // (the certified lanes' whole move first, then the others': nothing of the local form is alive across the
     //  reference's construction, which needs every register the kernel has)
-#if R3D_TET_LOCAL
     bool slow;
     e.len = 0.0, scatters = false;
     {
@@ -336,7 +320,7 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
       if (!slow) {
         e.len = L.R * two_atan(F.t, F.sn, F.cs);
         // free path (scatterers.cpp:297-307, phonons.cpp:601), screened as below
-        if (!R3D_TET_EARLY_MFP) mfp = T.scat_head[cell_scat(c)].mfp[p.type];
+        mfp = T.scat_head[cell_scat(c)].mfp[p.type];
         double scatlen = pos_inf();
         if (!((1.0 - u_free) * mfp >= e.len)) scatlen = -log_lean(u_free) * mfp;
         scatters = scatlen < e.len;
@@ -354,25 +338,13 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
     if (any_lanes(slow)) {
       if (slow) {
         R3D_COUNT_SLOW_MOVE();
-#if R3D_TET_SLOW_CALL
-        const TetSlowOut o = tet_move_reference(&cell_rec<KIND>(T, p.cell, p.type), p, u_free,
-                                                T.scat_head[cell_scat(c)].mfp[p.type]);
-#else
         const TetSlowOut o = tet_move_reference_inline(&cell_rec<KIND>(T, p.cell, p.type), p, u_free,
                                                        T.scat_head[cell_scat(c)].mfp[p.type]);
-#endif
         if (o.fate != FATE_ALIVE) return o.fate;
         p = o.p, e.face = o.face, scatters = o.scatters != 0;
       }
     }
-#else   // (developer builds: the reference's construction for every lane, as until round 5)
-    {
-      const TetSlowOut o = tet_move_reference_inline(&c, p, u_free, T.scat_head[cell_scat(c)].mfp[p.type]);
-      if (o.fate != FATE_ALIVE) return o.fate;
-      p = o.p, e.face = o.face, scatters = o.scatters != 0;
-    }
-#endif
-  } else if constexpr (KIND == CELL_SPH && R3D_SPH_LOCAL != 0) {
+  } else if constexpr (KIND == CELL_SPH) {
     // The shell move in local form (r3d_physics.h sph_fast_exit), certified as the tetra's; the other lanes -- straight
     // and vertical rays, starts outside the shell, tangent arcs, exits at the phonon's feet -- take the reference's.
     bool slow;
@@ -411,39 +383,19 @@ R3D_HD int step_move(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng,
         p = o.p, e.face = o.face, scatters = o.scatters != 0;
       }
     }
-  } else {
-  SphArc sarc;
-  SphExit sexit;
-  if constexpr (KIND == CELL_CYL) {
+  } else {   // layered models: straight rays in a cylinder (media.cpp:236-330)
     e = cyl_exit(c, a.cyl_radius2, p);
-  } else {
-    sarc = sph_arc(c, v3(a.earth_center[0], a.earth_center[1], a.earth_center[2]), p);
-    sexit = sph_exit(c, sarc, p);
-    e.face = sexit.face, e.len = sexit.len;
-  }
-  if (e.len == pos_inf()) return FATE_TIMEOUT;  // phonons.cpp:595-598
+    if (e.len == pos_inf()) return FATE_TIMEOUT;  // phonons.cpp:595-598
 
-  // --- free path to the next scattering event, drawn afresh every iteration
-  //     (scatterers.cpp:297-307, phonons.cpp:601)
-  // scatlen = -ln(u) mfp.  Since -ln(u) >= 1 - u, (1-u) mfp >= len already rules a scatter
-  // out, and the logarithm is only taken for the lanes that pass this screen.
-  double scatlen = pos_inf();
-  if (!((1.0 - u_free) * mfp >= e.len)) scatlen = -log_lean(u_free) * mfp;
-  scatters = scatlen < e.len;
-  const double len = scatters ? scatlen : e.len;
-
-  // --- advance (both branches) and Move (phonons.cpp:608-609, :623)
-  if constexpr (KIND == CELL_CYL) {
-    cyl_advance(c, p, len);
-  } else {
-    double s1 = sexit.sx, c1 = sexit.cx;  // a boundary leg ends at the exit point itself
-    if (scatters || !sexit.on_arc) {
-      double sd, cd;                      // scatter leg (or a squashed one): rotate by len / R
-      rotation(len * frcp(sarc.radius), &sd, &cd);
-      s1 = sarc.s0 * cd + sarc.c0 * sd, c1 = sarc.c0 * cd - sarc.s0 * sd;
-    }
-    sph_advance(c, sarc, p, len, s1, c1);
-  }
+    // --- free path to the next scattering event, drawn afresh every iteration
+    //     (scatterers.cpp:297-307, phonons.cpp:601)
+    // scatlen = -ln(u) mfp.  Since -ln(u) >= 1 - u, (1-u) mfp >= len already rules a scatter
+    // out, and the logarithm is only taken for the lanes that pass this screen.
+    double scatlen = pos_inf();
+    if (!((1.0 - u_free) * mfp >= e.len)) scatlen = -log_lean(u_free) * mfp;
+    scatters = scatlen < e.len;
+    // --- advance (both branches) and Move (phonons.cpp:608-609, :623)
+    cyl_advance(c, p, scatters ? scatlen : e.len);
   }
 
   ev.face = scatters ? -1 : e.face;

@@ -23,8 +23,9 @@
 // it, and with this guard no build without it can contain any of them (tests/test_abi.py holds the
 // Makefile and this list against the sources).
 #if !defined(R3D_DEV_BUILD) && (defined(R3D_ABLATE_CATCH) || defined(R3D_ABLATE_COLLECT) || defined(R3D_ABLATE_RT) || \
-                                defined(R3D_ABLATE_SPRAY_SEARCH) || defined(R3D_ABLATE_SCATTER) || defined(R3D_PHASE_TIMING))
-#error "R3D_ABLATE_* / R3D_PHASE_TIMING are developer-build switches: build with -DR3D_DEV_BUILD (make variant)"
+                                defined(R3D_ABLATE_SPRAY_SEARCH) || defined(R3D_ABLATE_SCATTER) || defined(R3D_PHASE_TIMING) || \
+                                defined(R3D_STEP_FINALS))
+#error "R3D_ABLATE_* / R3D_PHASE_TIMING / R3D_STEP_FINALS are developer-build switches: build with -DR3D_DEV_BUILD (make variant)"
 #endif
 
 namespace r3d {

@@ -26,10 +26,7 @@ extern thread_local std::string g_error;
 namespace {
 
 constexpr int kCompactBlock = 256;
-#ifndef R3D_COMPACT_QUADS
-#define R3D_COMPACT_QUADS 8
-#endif
-constexpr int kQuadsPerThread = R3D_COMPACT_QUADS;                       // 8 x 16 B per thread in flight
+constexpr int kQuadsPerThread = 8;                       // 8 x 16 B per thread in flight
 constexpr uint64_t kTileCounters = (uint64_t)kCompactBlock * kQuadsPerThread * 4;   // 8192 counters = 32 KB per tile
 
 // Non-zero counters of [begin, end) as (global index, count) pairs, in no particular order.

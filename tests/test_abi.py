@@ -111,7 +111,7 @@ def test_the_shipped_engine_reads_no_environment_and_holds_no_developer_switch()
         text = open(os.path.join(csrc, f)).read()
         code = re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", text, flags=re.S))
         assert "getenv" not in code, f
-        switches |= set(re.findall(r"#\s*if\w*\s+!?(?:defined\()?(R3D_ABLATE_\w+|R3D_PHASE_TIMING)", code))
+        switches |= set(re.findall(r"#\s*if\w*\s+!?(?:defined\()?(R3D_ABLATE_\w+|R3D_PHASE_TIMING|R3D_STEP_FINALS)", code))
     # every switch used anywhere is named in the one guard of r3d_tables.h
     guard = re.search(r"#if !defined\(R3D_DEV_BUILD\) && \((.*?)\)\n#error", open(os.path.join(csrc, "r3d_tables.h")).read(), re.S)
     assert guard, "the R3D_DEV_BUILD guard is gone from r3d_tables.h"

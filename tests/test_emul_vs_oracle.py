@@ -52,7 +52,8 @@ def test_the_checker_still_compares_aggregates_when_a_history_forks(models):
 
 
 @pytest.mark.parametrize("name,n", [("halfspace", 20000), ("crustpinch", 4000), ("lopnor", 4000),
-                                    ("sphere", 400), ("toysphere_vids", 500), ("lopnor_vids", 300), ("upthrust", 4000)])
+                                    ("sphere", 400), ("toysphere_vids", 500), ("lopnor_vids", 300), ("upthrust", 4000),
+                                    ("lopnor_moho", 1500), ("scat_params_study", 4000)])
 def test_kernel_code_matches_oracle_history_by_history(models, name, n):
     compare(models(name), n)
 

@@ -2,6 +2,8 @@
 (libr3d_hip.so), against the oracle on the same seeded histories -- history by
 history at sizes the oracle finishes in seconds, and through size-independent
 properties at the full BASELINE size."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -134,8 +136,12 @@ def test_production_kernel_small_pool_and_many_receivers(models, monkeypatch):
 
 @pytest.mark.parametrize("name,n", [("halfspace", 50000), ("crustpinch", 20000), ("lopnor", 20000),
                                     ("sphere", 3000), ("sphere_deep", 3000), ("toysphere_vids", 2000),
-                                    ("lopnor_vids", 2000), ("upthrust", 20000), ("crustpinch_vids", 5000)])
+                                    ("lopnor_vids", 2000), ("upthrust", 20000), ("crustpinch_vids", 5000),
+                                    ("lopnor_moho", 10000), ("lopnor_moho_sel3", 3000), ("scat_params_study", 20000)])
 def test_engine_matches_oracle_history_by_history(engines, name, n):
+    """Every model of the reference's dispatcher (user.cpp:69-125) through the engine, history by history against the
+    oracle: the four benchmark models, the video runs, the upthrust grid, the Lop Nor model with its Moho layers
+    (selectors 1-4 given 20 arguments) and the scattering-parameter study (128)."""
     check_against_oracle(engines(name), n)
 
 
@@ -737,6 +743,70 @@ def test_histories_that_lived_in_the_chain_step_kernel_end_with_the_oracles_reco
     assert not differ, f"{name}: {len(differ)} of {checked} records of histories carried through step launches differ from the oracle: ids {differ[:20]}"
 
 
+def finals_bytes(f):
+    """A final record (or a few) as its bytes."""
+    import ctypes
+    if isinstance(f, (list, tuple)):
+        return b"".join(finals_bytes(x) for x in f)
+    return bytes(ctypes.string_at(ctypes.addressof(f), ctypes.sizeof(f)))
+
+
+STEP_FINALS_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "radiative3d_amd", "lib",
+                               "variant_STEPFINALS.so")
+
+
+@pytest.mark.parametrize("name,per_launch", [("crustpinch", 150_000), ("lopnor", 150_000), ("sphere_deep", 120_000)])
+def test_chain_step_kernel_with_its_records_compiled_in_matches_the_oracle_per_history(name, per_launch):
+    """A direct witness of the chain-step kernel's code, with a caveat.  The shipped step kernel
+    (pool_kernel<kind, ., ., false>, the code object the headline is timed on) is compiled WITHOUT the final-record
+    stores (3.5 % of its launch); `make variant NAME=STEPFINALS DEFS=-DR3D_STEP_FINALS=1` (built by
+    __graft_entry__.build()) compiles the SAME sources with the SAME flags and those stores in -- a sibling
+    compilation: same code, its own register allocation and schedule, not the shipped binary.  Its step launches write
+    a record for every history that ENDS in them; those records are read BEFORE the chain's flush (so the drain kernel
+    has written none of them) and held against the oracle history by history, for the three cell kinds.  The shipped
+    binary itself stays held through its bins, counters and the drain's records of the histories it hands on (the test
+    above).  Reference loop: phonons.cpp:540-682."""
+    from radiative3d_amd.configs import CONFIGS
+    assert os.path.exists(STEP_FINALS_LIB), "variant_STEPFINALS.so is not built (__graft_entry__.build() makes it)"
+    e = Engine(Model(CONFIGS[name](4)), lib=STEP_FINALS_LIB)
+    n = 4 * per_launch
+    first, seed = 70_000_000, 0xFEED
+    rtol = 1e-8 if name == "sphere_deep" else 1e-9      # (as in the test above)
+    e.set_production_finals(first, n)
+    total = DeviceResult(e.model, "cuda:0")
+    for k in range(4):
+        e.run_device(per_launch, first + k * per_launch, seed, *total.pointers(), carry="carry")
+    torch.cuda.synchronize()
+    assert e.carry_pending
+    step_written = e.production_finals(0, n)             # before the flush: only step launches have run
+    ended = [i for i in range(n) if step_written[i].fate != 255]
+    assert len(ended) > 100_000, len(ended)              # histories do end inside step kernels, and leave their record
+    e.run_device(0, 0, seed, *total.pointers(), carry="final")
+    torch.cuda.synchronize()
+    got = total.to_result()
+    assert got.events["generated"] == n and got.n_lost + got.n_timeout + got.n_invalid == n
+    after = e.production_finals(0, n)
+    e.set_production_finals(0, 0)
+    assert all(f.fate != 255 for f in after)             # the drain wrote the rest: every history left a record
+    assert all(finals_bytes([after[i]]) == finals_bytes([step_written[i]]) for i in ended[:5000])   # (written once)
+    # the oracle on a sample of the histories that ended in step kernels, in runs of consecutive ids
+    differ, checked, budget = [], 0, 30_000
+    lo = 0
+    while lo < len(ended) and budget > 0:
+        hi = lo
+        while hi + 1 < len(ended) and ended[hi + 1] == ended[hi] + 1 and hi - lo < 2000:
+            hi += 1
+        a, b = ended[lo], ended[hi] + 1
+        _, want = O.run(e.model, b - a, first + a, seed, trace=True)
+        differ += [first + a + j for j in range(b - a) if production_finals_differ(step_written[a + j], want[j], rtol)]
+        checked += b - a
+        budget -= b - a
+        lo = hi + 1
+    assert checked >= 10_000, checked
+    assert not differ, f"{name}: {len(differ)} of {checked} records written by step launches differ from the oracle: ids {differ[:20]}"
+    e.close()
+
+
 def test_production_finals_buffer_rules(engines):
     """r3d_engine_set_production_finals: while a buffer is attached a launch whose ids it does not cover is refused
     (the kernel indexes the buffer by the history id itself), it cannot be attached or detached while histories are
@@ -790,11 +860,6 @@ def test_reproducible_build_defines_every_history_to_the_bit(models, monkeypatch
     """libr3d_hip_repro.so (-DR3D_REPRODUCIBLE: no wave-voted series choice, csrc/r3d_math.h): a history's
     final record is bit-identical whatever shares its wave -- another pool size, a chain of launches
     against one launch -- on all three cell kinds; and it still matches the oracle."""
-    import ctypes
-
-    def finals_bytes(f):
-        return bytes(ctypes.string_at(ctypes.addressof(f), ctypes.sizeof(f)))
-
     for name, n in (("crustpinch", 30000), ("lopnor", 20000), ("sphere_deep", 3000)):
         m = models(name)
         big = Engine(m, reproducible=True)
