@@ -15,6 +15,19 @@ from radiative3d_amd import Engine, Model, _ffi
 from radiative3d_amd.parallel import DeviceResult, shard_range
 from tests.configs import crustpinch, halfspace, lopnor, sphere_deep
 
+
+def energies_agree(a, b, tol=1e-11):
+    """Two ENGINE runs of the same histories, batched differently (another partition, a chain, other streams, shards):
+    integer outputs are identical; a history's numbers are defined to rounding -- which wave serves it, and whether its
+    interface solve runs in the R/T phase or inside a thin batch's MOVE phase (two inlinings of the same code, fused
+    into multiply-adds differently), depends on the batching -- and a component that is tiny against its bin's energy
+    (particle motion all but normal to that axis) moves in its leading digits.  So: every component to `tol` of its
+    BIN's energy by type (observed: 6e-13, tools/partition_deviation.py; the reproducible build is bit-identical)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64).reshape(np.shape(a))
+    scale = a[..., 3:].sum(-1, keepdims=True)
+    return bool(np.all(np.abs(a - b) <= tol * scale + 1e-300))
+
+
 pytestmark = pytest.mark.gpu
 
 
@@ -189,7 +202,7 @@ def test_shards_add_up_exactly(engines):
     assert (whole.counts == parts.counts).all()
     assert whole.events == parts.events
     assert (whole.n_lost, whole.n_timeout) == (parts.n_lost, parts.n_timeout)
-    assert np.allclose(whole.energy, parts.energy, rtol=1e-12, atol=1e-300)
+    assert energies_agree(whole.energy, parts.energy)
 
 
 def test_device_resident_accumulation(engines):
@@ -203,7 +216,7 @@ def test_device_resident_accumulation(engines):
     assert e.last_kernel_ms() > 0
     got = dev.to_result()
     assert (got.counts == host.counts).all() and got.events == host.events
-    assert np.allclose(got.energy, host.energy, rtol=1e-12, atol=1e-300)
+    assert energies_agree(got.energy, host.energy)
 
 
 def test_full_size_crustpinch_properties():
@@ -430,7 +443,7 @@ def test_two_ranks_on_the_gpu_sum_to_one_engine_run(engines, tmp_path):
     got = np.load(out)
     want = engines("lopnor", 4, ("--device-tables",)).run(n)
     assert (got["counts"] == want.counts).all() and (got["scalars"] == want.scalars()).all()
-    assert np.allclose(got["energy"], want.energy, rtol=1e-11, atol=1e-300)
+    assert energies_agree(got["energy"], want.energy)
 
 
 def test_engine_leaves_the_callers_device_and_refuses_to_drop_carried_histories(engines):
@@ -464,7 +477,7 @@ def test_one_call_seam_equals_engine_run(engines):
     got = run_model(e.model, 7000, first_id=11, seed=99, n_gpus=1)
     assert (got.counts == want.counts).all() and got.events == want.events
     assert (got.n_lost, got.n_timeout, got.n_invalid) == (want.n_lost, want.n_timeout, want.n_invalid)
-    assert np.allclose(got.energy, want.energy, rtol=1e-12, atol=1e-300)
+    assert energies_agree(got.energy, want.energy)
     import torch
     with pytest.raises(RuntimeError, match="device index out of range"):
         run_model(e.model, 100, n_gpus=torch.cuda.device_count() + 1)
@@ -527,7 +540,7 @@ def test_carry_chain_equals_one_run(engines, name, n, parts):
     got = total.to_result()
     assert (got.counts == want.counts).all() and got.events == want.events
     assert (got.n_lost, got.n_timeout, got.n_invalid) == (want.n_lost, want.n_timeout, want.n_invalid)
-    assert np.allclose(got.energy, want.energy, rtol=1e-11, atol=1e-300)
+    assert energies_agree(got.energy, want.energy)
     # the first launch started `per` histories but left some unfinished for the second
     assert first_piece.events["generated"] == per
     assert first_piece.n_lost + first_piece.n_timeout + first_piece.n_invalid < per
@@ -554,7 +567,7 @@ def test_launches_in_flight_on_two_streams(engines):
     torch.cuda.synchronize()
     got = bufs[0].add_(bufs[1]).to_result()
     assert (got.counts == want.counts).all() and got.events == want.events
-    assert np.allclose(got.energy, want.energy, rtol=1e-11, atol=1e-300)
+    assert energies_agree(got.energy, want.energy)
 
 
 def test_report_stream_over_a_carry_chain(engines):
@@ -605,7 +618,7 @@ def test_small_pool_many_short_launches(models, monkeypatch):
         total.add_(step)
         got = total.to_result()
         assert (got.counts == want.counts).all() and got.events == want.events
-        assert np.allclose(got.energy, want.energy, rtol=1e-11, atol=1e-300)
+        assert energies_agree(got.energy, want.energy)
         e.close()
 
 
@@ -621,7 +634,7 @@ def test_run_model_on_three_engines_on_one_device(engines):
     got = run_model(e.model, n, first_id=11, seed=99, devices=[0, 0, 0])
     assert (got.counts == want.counts).all() and got.events == want.events
     assert (got.n_lost, got.n_timeout, got.n_invalid) == (want.n_lost, want.n_timeout, want.n_invalid)
-    assert np.allclose(got.energy, want.energy, rtol=1e-12, atol=1e-300)
+    assert energies_agree(got.energy, want.energy)
     assert_result_equals_oracle(got, O.run(e.model, n, 11, 99), "r3d_run_model_on")
     with pytest.raises(RuntimeError, match=r"shard 1 \(device 99\): device index out of range"):
         run_model(e.model, 100, devices=[0, 99, 0])
@@ -650,7 +663,7 @@ def test_node_sums_the_shards_and_the_library_communicator_reduces_a_block(engin
     got = one.run(n, first_id=5, seed=77)
     assert (got.counts == want.counts).all() and got.events == want.events
     assert (got.n_lost, got.n_timeout, got.n_invalid) == (want.n_lost, want.n_timeout, want.n_invalid)
-    assert np.allclose(got.energy, want.energy, rtol=1e-12, atol=1e-300)
+    assert energies_agree(got.energy, want.energy)
     assert_result_equals_oracle(got, O.run(e.model, n, 5, 77), "r3d_node_run")
     # the communicator of a one-rank job, without any process group around it
     L = _ffi.hip_lib()
@@ -678,11 +691,11 @@ def test_node_sums_the_shards_and_the_library_communicator_reduces_a_block(engin
     assert three.reduction == "host" and len(three) == 3
     host = three.run(n, first_id=5, seed=77)
     assert (host.counts == got.counts).all() and host.events == got.events
-    assert np.allclose(host.energy, got.energy, rtol=1e-12, atol=1e-300)
+    assert energies_agree(host.energy, got.energy)
     # the same node again: its result is ADDED to what the caller's block holds
     again = one.run(n, first_id=5, seed=77, result=got)
     assert again is got and (got.counts == 2 * want.counts).all() and got.events["generated"] == 2 * n
-    assert np.allclose(got.energy, 2 * want.energy, rtol=1e-12, atol=1e-300)
+    assert energies_agree(got.energy, 2 * want.energy)
     one.close(), three.close()
     with pytest.raises(RuntimeError, match=r"shard 1 \(device 99\): device index out of range"):
         Node(e.model, [0, 99])
