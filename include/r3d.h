@@ -459,10 +459,12 @@ int r3d_volume_scatter_add(int device, uint32_t* d_counters, uint64_t len, const
  * types (`frames`: n + 1 entries, may be NULL; the cut is contiguous and balanced), the rest of its grid
  * keeps that engine's own counts.  Pairs travel by hipMemcpyPeer.  *saturated (may be NULL) receives the
  * number of cells that reached 2^32 - 1.  Waits for every launch of the engines.  Returns 0 on success.
- * In two phases: first every engine compacts and COUNTS what it would send -- a grid too full for its pair
- * buffer (more than a sixteenth of its cells non-zero in the other owners' frames) fails the call here, with
- * every grid as it was --, only then do pairs travel and owners add.  After a failure in the second phase (a
- * failed HIP call) the grids are undefined.                                                            */
+ * In two phases: first every engine COUNTS what it would send (the compaction with no room to write) -- a grid
+ * with more than a sixteenth of its cells non-zero in the other owners' frames fails the call here, with every
+ * grid as it was --; only then, source by source, the pairs are written into a buffer of exactly their number,
+ * travel, are added by their owners, and the buffer is freed: one pair buffer is alive at a time, so shards
+ * that share a device need the room of one.  After a failure in the second phase (a failed HIP call) the grids
+ * are undefined.                                                                                         */
 int r3d_volume_reduce_by_frame(r3d_engine* const* engines, int n, uint32_t* frames, uint64_t* saturated);
 
 /* ---- optional per-event report stream --------------------------------------

@@ -1225,45 +1225,61 @@ int r3d_volume_reduce_by_frame(r3d_engine* const* engines, int n, uint32_t* fram
       R3D_HIP_OK(hipDeviceSynchronize());
     }
   }
-  // Phase 1, nothing modified yet: every source compacts the other owners' frame ranges of its grid into its own
-  // pair buffer (on its own device) and the counts are read.  A source whose pairs do not fit is found HERE, before
-  // any owner's grid has been added to: the call then fails with every grid as it was.
-  struct Source {
-    DevBuf pairs, count;
-    std::vector<uint64_t> ends;
-  };
-  std::vector<Source> sources(n > 1 ? n : 0);
-  for (int src = 0; src < n && n > 1; src++) {
+  // Phase 1, nothing modified: every source COUNTS the non-zero cells of the other owners' frame ranges of its grid (the
+  // compaction kernel with no room to write: it counts what it would have written).  A source whose pairs would not fit
+  // the limit is found HERE, before any owner's grid has been added to: the call then fails with every grid as it was.
+  auto compact_others = [&](int src, uint32_t* pairs, uint64_t room, uint64_t* d_count, std::vector<uint64_t>* ends) -> int {
     r3d_engine* S = engines[src];
-    Source& P = sources[src];
-    R3D_ON_DEVICE(S->device);
-    R3D_HIP_OK(P.pairs.alloc_zero(cap * 2 * sizeof(uint32_t)));
-    R3D_HIP_OK(P.count.alloc_zero(sizeof(uint64_t)));
     const uint32_t* grid = reinterpret_cast<const uint32_t*>(r3d_volume_device_ptr(S));
-    P.ends.assign(n, 0);
     for (int owner = 0; owner < n; owner++) {
       if (owner != src)
         for (uint64_t t = 0; t < 2; t++) {
           const uint64_t b = (t * n_frames + frame_lo(owner)) * frame_cells, e = (t * n_frames + frame_lo(owner + 1)) * frame_cells;
-          if (e > b && r3d_volume_compact(S->device, grid, b, e, reinterpret_cast<uint32_t*>(P.pairs.p), cap,
-                                          reinterpret_cast<uint64_t*>(P.count.p), S->stream))
-            return 1;
+          if (e > b && r3d_volume_compact(S->device, grid, b, e, pairs, room, d_count, S->stream)) return 1;
         }
-      R3D_HIP_OK(hipStreamSynchronize(S->stream));
-      R3D_HIP_OK(hipMemcpy(&P.ends[owner], P.count.p, sizeof(uint64_t), hipMemcpyDeviceToHost));
+      if (ends) {   // (pairs written -- or counted -- once this owner's frames are done)
+        R3D_HIP_OK(hipStreamSynchronize(S->stream));
+        R3D_HIP_OK(hipMemcpy(&(*ends)[owner], d_count, sizeof(uint64_t), hipMemcpyDeviceToHost));
+      }
     }
-    if (P.ends[n - 1] > cap)
-      return g_error = "r3d_volume_reduce_by_frame: the grid of engine " + std::to_string(src) + " is too full for the pair buffer (" +
-                       std::to_string(P.ends[n - 1]) + " non-zero cells in the other owners' frames, room for " + std::to_string(cap) +
-                       ": a sixteenth of the grid); no grid has been modified", 1;
-  }
-  // Phase 2: the pairs to their owners, added there.  (A failure from here on is a failed HIP call -- a lost device,
-  // no memory for the received pairs --, and leaves the owners' frames partly summed: the grids are then undefined.)
+    return 0;
+  };
+  std::vector<std::vector<uint64_t>> ends(n > 1 ? n : 0);
   for (int src = 0; src < n && n > 1; src++) {
     r3d_engine* S = engines[src];
-    const Source& P = sources[src];
+    R3D_ON_DEVICE(S->device);
+    DevBuf count, nowhere;
+    R3D_HIP_OK(count.alloc_zero(sizeof(uint64_t)));
+    R3D_HIP_OK(nowhere.alloc_zero(2 * sizeof(uint32_t)));
+    ends[src].assign(n, 0);
+    if (compact_others(src, reinterpret_cast<uint32_t*>(nowhere.p), 0, reinterpret_cast<uint64_t*>(count.p), &ends[src])) return 1;
+    if (ends[src][n - 1] > cap)
+      return g_error = "r3d_volume_reduce_by_frame: the grid of engine " + std::to_string(src) + " is too full for the pair buffer (" +
+                       std::to_string(ends[src][n - 1]) + " non-zero cells in the other owners' frames, room for " + std::to_string(cap) +
+                       ": a sixteenth of the grid); no grid has been modified", 1;
+  }
+  // Phase 2, source by source: its pairs written into a buffer of exactly their number (the other owners' frames of a
+  // source's grid are touched by nobody: the count of phase 1 stands), sent to their owners, added there, and the buffer
+  // freed before the next source's is made -- one pair buffer alive at a time, however many shards share a device.
+  // (A failure from here on is a failed HIP call -- a lost device, no memory for the pairs --, and leaves the owners'
+  // frames partly summed: the grids are then undefined.)
+  for (int src = 0; src < n && n > 1; src++) {
+    r3d_engine* S = engines[src];
+    const std::vector<uint64_t>& E = ends[src];
+    if (E[n - 1] == 0) continue;
+    DevBuf pairs, count;   // (on the source's device; freed where this iteration ends)
+    {
+      R3D_ON_DEVICE(S->device);
+      R3D_HIP_OK(pairs.alloc_zero(E[n - 1] * 2 * sizeof(uint32_t)));
+      R3D_HIP_OK(count.alloc_zero(sizeof(uint64_t)));
+      if (compact_others(src, reinterpret_cast<uint32_t*>(pairs.p), E[n - 1], reinterpret_cast<uint64_t*>(count.p), nullptr)) return 1;
+      R3D_HIP_OK(hipStreamSynchronize(S->stream));
+      uint64_t written = 0;
+      R3D_HIP_OK(hipMemcpy(&written, count.p, sizeof written, hipMemcpyDeviceToHost));
+      if (written != E[n - 1]) return g_error = "r3d_volume_reduce_by_frame: internal error: a grid changed between the count and the compaction", 1;
+    }
     for (int owner = 0; owner < n; owner++) {
-      const uint64_t lo = owner ? P.ends[owner - 1] : 0, cnt = P.ends[owner] - lo;
+      const uint64_t lo = owner ? E[owner - 1] : 0, cnt = E[owner] - lo;
       if (owner == src || cnt == 0) continue;
       r3d_engine* D = engines[owner];
       DeviceGuard on_dst(D->device);
@@ -1272,7 +1288,7 @@ int r3d_volume_reduce_by_frame(r3d_engine* const* engines, int n, uint32_t* fram
       R3D_HIP_OK(got.alloc_zero(cnt * 2 * sizeof(uint32_t)));
       R3D_HIP_OK(flags.alloc_zero(2 * sizeof(uint64_t)));
       // (the pairs to the owner's device: a copy between peers, or within the device when the engines share one)
-      R3D_HIP_OK(hipMemcpyPeer(got.p, D->device, reinterpret_cast<const uint32_t*>(P.pairs.p) + 2 * lo, S->device, cnt * 2 * sizeof(uint32_t)));
+      R3D_HIP_OK(hipMemcpyPeer(got.p, D->device, reinterpret_cast<const uint32_t*>(pairs.p) + 2 * lo, S->device, cnt * 2 * sizeof(uint32_t)));
       if (r3d_volume_scatter_add(D->device, reinterpret_cast<uint32_t*>(r3d_volume_device_ptr(D)), len,
                                  reinterpret_cast<const uint32_t*>(got.p), cnt, reinterpret_cast<uint64_t*>(flags.p), D->stream))
         return 1;
@@ -1282,6 +1298,7 @@ int r3d_volume_reduce_by_frame(r3d_engine* const* engines, int n, uint32_t* fram
       if (f[1]) return g_error = "r3d_volume_reduce_by_frame: internal error: pairs outside the grid", 1;
       if (saturated) *saturated += f[0];
     }
+    DeviceGuard on_src(S->device);   // (the pair buffer is freed on its device)
   }
   if (frames)
     for (int g = 0; g <= n; g++) frames[g] = (uint32_t)frame_lo(g);

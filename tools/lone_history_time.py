@@ -1,11 +1,14 @@
+"""One history alone on the chip, timed on several builds of the engine in one call:
+    python tools/lone_history_time.py lopnor 9 3142726 variant_X.so libr3d_hip.so"""
 import os, sys
-sys.path.insert(0, '/root/repo')
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
 from radiative3d_amd import Model, Engine
 from radiative3d_amd.configs import CONFIGS
 name, deg, hid = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 m = Model(CONFIGS[name](deg) + ["--device-tables"])
 for lib in sys.argv[4:]:
-    e = Engine(m, lib=os.path.join('/root/repo/radiative3d_amd/lib', lib))
+    e = Engine(m, lib=os.path.join(REPO, 'radiative3d_amd', 'lib', lib))
     e.run(1, first_id=hid)
     ts = []
     for _ in range(5):

@@ -1,5 +1,8 @@
-import sys, numpy as np
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+"""How far two runs of the same histories, batched differently, differ in the bins (GPU): one launch against six
+launches of a sixth each -- per element and per bin energy.  python tools/partition_deviation.py"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from radiative3d_amd import Model, Engine
 from radiative3d_amd.configs import CONFIGS
 from radiative3d_amd.parallel import shard_range
