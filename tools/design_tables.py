@@ -1,5 +1,5 @@
 """Rewrite the two measured tables of DESIGN.md (between their BEGIN / END markers) from profiles/<round>/:
-python tools/design_tables.py r03"""
+python tools/design_tables.py r06"""
 import json
 import os
 import re
@@ -11,40 +11,37 @@ prof = os.path.join(repo, "profiles", rnd)
 
 
 def line(name):
-    return json.loads(open(os.path.join(prof, f"bench_line_{name}.json")).read().strip().splitlines()[-1])
+    return json.load(open(os.path.join(prof, f"bench_line_{name}.json")))
 
 
-names = {"crustpinch": "crustpinch (NSCP)", "halfspace": "halfspace", "lopnor": "lopnor", "sphere": "sphere, 600 km source",
-         "crustpinch_volume": "crustpinch_volume (config 5)"}
-roof = ["| config | ms / launch | VALU instr / launch | `roofline.frac` (busy) | lanes active | wave-cycles waiting | SALU / VALU | HBM bytes / launch (% of 8 TB/s) |",
+def f(x, fmt):
+    return "-" if x is None else format(x, fmt)
+
+
+names = {"crustpinch": "NSCP (config 2)", "halfspace": "half-space, one receiver (1)", "lopnor": "LopNor, explosion (3)",
+         "sphere": "SphereEarth, 600 km source (4)", "crustpinch_volume": "NSCP video run + 10 GB grid (5)"}
+roof = ["| workload (BASELINE config) | step launch | useful frac | VALU busy | lanes active | waiting | TA busy | HBM per launch |",
         "|---|---:|---:|---:|---:|---:|---:|---:|"]
 for c in names:
     b, pm = line(c), json.load(open(os.path.join(prof, f"pmc_{c}.json")))
     r, hb, ms = b["roofline"], pm["hbm_traffic_bytes_per_launch"], b["roofline"]["kernel_ms_step_avg"]
-    roof.append(f"| {names[c]} | {ms:.2f} | {pm['SQ_INSTS_VALU']:.2e} | {r['frac']:.2f} | {pm['lane_activity']:.2f} | "
-                f"{pm['wave_cycles_waiting']:.2f} | {pm['SQ_INSTS_SALU'] / pm['SQ_INSTS_VALU']:.2f} | {hb / 1e9:.1f} GB ({100 * hb / (ms * 1e-3) / 8e12:.0f} %) |")
-
-labels = {"crustpinch": "crustpinch, 5 steps", "halfspace": "halfspace (one receiver)", "lopnor": "lopnor (explosion)",
-          "sphere": "sphere (600 km source)", "crustpinch_volume": "crustpinch_volume (config 5: video run + 10 GB grid)"}
+    roof.append(f"| {names[c]} | {ms:.2f} ms | {f(r.get('useful_frac'), '.3f')} | {f(r.get('valu_busy'), '.2f')} | {pm['lane_activity']:.2f} | "
+                f"{pm['wave_cycles_waiting']:.2f} | {f(r.get('ta_busy'), '.2f')} | {hb / 1e9:.1f} GB ({100 * hb / (ms * 1e-3) / 8e12:.0f} % of 8 TB/s) |")
 
 
-def row(b, label, bold=False):
+def row(b, label):
     r, sl, cpu, env = b["roofline"], b.get("single_launch") or {}, b.get("cpu_baseline") or {}, b.get("envelope") or {}
     job = b.get("job") or {}
-    v = f"{b['value']:.2e}"
-    v = f"**{v}**" if bold else v
-    e = (f"{env['rms_sigma']:.2f} / {env['rms_sigma_gpu_vs_gpu_same_batches']:.2f}, {env['bins']} bins"
-         if env.get("rms_sigma") else "-")
-    return (f"| {label} | {v} | {r['kernel_ms_step_avg']:.2f} ms | {sum(r['kernel_ms_flush']):.2f} ms | "
-            f"{sl.get('kernel_ms', 0):.1f} ms = {sl.get('value', 0):.2e}/s | {job.get('histories', 0):.0e} in {job.get('ms', 0):.1f} ms = {job.get('value', 0):.2e}/s | "
-            f"{cpu.get('value', 0):.2e}/s ({cpu.get('cores')} threads) | {e} |")
+    e = f"{env['rms_sigma']:.2f} / {env['rms_sigma_gpu_vs_gpu_same_batches']:.2f}" if env.get("rms_sigma") else "-"
+    return (f"| {label} | **{b['value']:.3e}** | {r['kernel_ms_step_avg']:.2f} | {sum(r['kernel_ms_flush']):.2f} | {sl.get('kernel_ms', 0):.1f} | "
+            f"{job.get('histories', 0):.0e}: {job.get('ms', 0):.1f} ms | {cpu.get('value', 0):.2e} | {e} |")
 
 
-meas = ["| config (`bench.py --config`) | histories/s | step launch | flush | one self-contained launch of 1e7 | the BASELINE job as stated (one GPU) | CPU port (1e7-history sample where it fits 25 s) | envelope RMS (GPU vs CPU / GPU vs GPU) |",
+meas = ["| workload | histories/s | step ms | flush ms | lone 1e7 launch ms | the job as stated, one GPU | CPU port, 16 threads | envelope RMS: GPU-CPU / GPU-GPU |",
         "|---|---:|---:|---:|---:|---:|---:|---:|",
-        row(line("crustpinch_steps20_warmup5"), "crustpinch (headline), 20 steps + 5 warm-up (the driver's command)", True)]
-for c in labels:
-    meas.append(row(line(c), labels[c], c == "sphere"))
+        row(line("crustpinch_steps20_warmup5"), "NSCP, the driver's flags (20 steps + 5)")]
+for c in names:
+    meas.append(row(line(c), names[c]))
 
 path = os.path.join(repo, "DESIGN.md")
 text = open(path).read()
