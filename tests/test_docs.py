@@ -26,7 +26,7 @@ def test_every_committed_bench_line_is_one_json_object():
     for f in files:
         line = json.load(open(f))          # (the whole file: no banner before the line, nothing after it)
         assert line["metric"] == "phonon-histories/sec" and line["unit"] == "histories/s" and line["value"] > 0, f
-        if "under_rocprofv3" in f:
+        if line.get("cpu_baseline") is None:      # (a --timed-only line of a profiling pass: the timed region and nothing else)
             continue
         r = line["roofline"]
         assert r["frac"] == r["useful_frac"] and 0.05 < r["frac"] < 1.0, (f, r["frac"])
