@@ -1015,6 +1015,12 @@ R3D_HD V3 rt_plane_normal(V3 n, V3 d, double m2, double& w2) {
   }
   return w;
 }
+// FLAT_FACES (layered models): where the face is horizontal -- its normal (0, 0, +-1) exactly -- the plane of incidence is
+// the vertical plane through the ray, so the axis normal to it IS phi^ and the SV axis IS theta^: the SH fraction of an S
+// ray's particle motion is sin^2 of its polarisation angle as it stands, and the outgoing polarisation is one of four
+// constants (rt_apply) -- no axis, no projection.  Lanes on other faces take the general form, under a vote of the wave.
+R3D_HD bool face_is_flat(V3 n) { return n.x == 0.0 && n.y == 0.0; }
+template <bool FLAT_FACES = false>
 R3D_HD RtChoice rt_choose(const Phonon& p, Iface f, double u_pol, double u_out) {
   const double cn = dot(f.normal, p.dir);
   const double m2 = mag2(p.dir - cn * f.normal);   // sin^2(i)
@@ -1024,11 +1030,17 @@ R3D_HD RtChoice rt_choose(const Phonon& p, Iface f, double u_pol, double u_out) 
     no_transmit = true;
   }
   int intype = 0;  // 0 P, 1 SH, 2 SV
+  const bool flat = FLAT_FACES && face_is_flat(f.normal);
   if (p.type == RAY_S) {
-    double w2;
-    const V3 w = rt_plane_normal(f.normal, p.dir, m2, w2);
-    const double sh = dot(direction_of_motion(p), w);
-    intype = (u_pol * w2 <= sh * sh) ? 1 : 2;
+    if (FLAT_FACES) intype = (u_pol <= p.ps * p.ps) ? 1 : 2;   // (pdom . phi^)^2
+    if (!FLAT_FACES || any_lanes(!flat)) {
+      if (!flat) {
+        double w2;
+        const V3 w = rt_plane_normal(f.normal, p.dir, m2, w2);
+        const double sh = dot(direction_of_motion(p), w);
+        intype = (u_pol * w2 <= sh * sh) ? 1 : 2;
+      }
+    }
   }
   R3D_SCHED_FENCE();
   const RtWeights o = rt_weights_slowness(f, m2, fabs(cn), intype);
@@ -1062,6 +1074,7 @@ R3D_HD RtChoice rt_choose(const Phonon& p, Iface f, double u_pol, double u_out) 
   return ch;
 }
 // Returns true if the phonon crossed into the neighbour.
+template <bool FLAT_FACES = false>
 R3D_HD bool rt_apply(Phonon& p, V3 n, RtChoice ch) {
   const bool out_s = (ch.code & 1) != 0, reflected = (ch.code & 2) != 0, sh = (ch.code & 4) != 0;
   const double cn = dot(n, p.dir);
@@ -1069,30 +1082,38 @@ R3D_HD bool rt_apply(Phonon& p, V3 n, RtChoice ch) {
   const V3 out = ch.kt * dt + (reflected ? -ch.cz : ch.cz) * n;
   p.type = out_s ? RAY_S : RAY_P;
   if (out_s) {
-    double w2;
-    const V3 w = rt_plane_normal(n, p.dir, 0.0, w2);
-    // SH stays SH: w; R_SV: out x w; T_SV: w x out = -(out x w)
-    const V3 c = cross(out, w);
-    const double sg = reflected ? 1.0 : -1.0;
-    const V3 dopm = sh ? w : v3(sg * c.x, sg * c.y, sg * c.z);
-    set_pol(p, dopm, out);
+    const bool flat = FLAT_FACES && face_is_flat(n);
+    if (FLAT_FACES) {
+      // a horizontal face, normal (0, 0, s): the particle motion of the outgoing S ray is s phi^ (SH), -s theta^ (SV
+      // reflected), s theta^ (SV transmitted) of the outgoing ray's own axes -- what the general form below comes to
+      p.pc = sh ? 0.0 : (reflected ? -n.z : n.z);
+      p.ps = sh ? n.z : 0.0;
+    }
+    if (!FLAT_FACES || any_lanes(!flat)) {
+      if (!flat) {
+        double w2;
+        const V3 w = rt_plane_normal(n, p.dir, 0.0, w2);
+        // SH stays SH: w; R_SV: out x w; T_SV: w x out = -(out x w)
+        const V3 c = cross(out, w);
+        const double sg = reflected ? 1.0 : -1.0;
+        const V3 dopm = sh ? w : v3(sg * c.x, sg * c.y, sg * c.z);
+        set_pol(p, dopm, out);
+      }
+    }
   }
   p.dir = out;
   return !reflected;
 }
+template <bool FLAT_FACES = false>
 R3D_HD bool rt_event(Phonon& p, const Iface& f, double u_pol, double u_out) {
-  const RtChoice ch = rt_choose(p, f, u_pol, u_out);
-  return rt_apply(p, f.normal, ch);
-}
-R3D_HD bool full_rt(Phonon& p, Iface f, Rng& rng, RngKey key) {
-  double u_pol, u_out;
-  rt_draws(p, rng, key, u_pol, u_out);
-  return rt_event(p, f, u_pol, u_out);
+  const RtChoice ch = rt_choose<FLAT_FACES>(p, f, u_pol, u_out);
+  return rt_apply<FLAT_FACES>(p, f.normal, ch);
 }
 
 // Snell bending without mode conversion across a weak velocity step
 // (reference Phonon::Refraction_Bend, phonons.cpp:311-405).  Returns true if
 // transmitted.
+template <bool FLAT_FACES = false>
 R3D_HD bool bend(Phonon& p, V3 fnorm, double veli, double velo) {
   // The reference builds unit axes fpara (in the plane of incidence, along the face), fparash (normal
   // to that plane) and the SV axes of the incoming and outgoing ray, and expresses the particle
@@ -1112,14 +1133,21 @@ R3D_HD bool bend(Phonon& p, V3 fnorm, double veli, double velo) {
   const double kn = transfer ? fsqrt(1.0 - so2) : -cn;
   const V3 out = kt * dt + kn * fnorm;
   if (p.type != RAY_P) {
-    V3 w = cross(fnorm, p.dir);
-    if (is_zero(w)) {
-      w = cross(fnorm, v3(1, 0, 0));
-      if (is_zero(w)) w = cross(fnorm, v3(0, 1, 0));
+    // FLAT_FACES, a horizontal face: the outgoing ray keeps the incoming ray's azimuth, SH is phi^ and SV theta^ on both
+    // sides of the bend, so the polarisation ANGLE is what it was -- the general form below comes to exactly that.
+    const bool flat = FLAT_FACES && face_is_flat(fnorm);
+    if (!FLAT_FACES || any_lanes(!flat)) {
+      if (!flat) {
+        V3 w = cross(fnorm, p.dir);
+        if (is_zero(w)) {
+          w = cross(fnorm, v3(1, 0, 0));
+          if (is_zero(w)) w = cross(fnorm, v3(0, 1, 0));
+        }
+        const V3 pdomi = direction_of_motion(p);
+        const V3 pdomo = dot(pdomi, w) * w + dot(pdomi, cross(w, p.dir)) * cross(w, out);
+        set_pol(p, pdomo, out);
+      }
     }
-    const V3 pdomi = direction_of_motion(p);
-    const V3 pdomo = dot(pdomi, w) * w + dot(pdomi, cross(w, p.dir)) * cross(w, out);
-    set_pol(p, pdomo, out);
   } else {
     p.pc = 1.0, p.ps = 0.0;                  // polout = 0
   }

@@ -501,7 +501,7 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
     // (the event's uniforms first: they wait for nothing, the interface's records have to be fetched)
     double u_pol, u_out;
     rt_draws(p, rng, rng_key(a.seed), u_pol, u_out);
-    crossed = rt_event(p, rt_interface<KIND>(a, T, p, ev, nbr), u_pol, u_out);
+    crossed = rt_event<KIND == CELL_CYL>(p, rt_interface<KIND>(a, T, p, ev, nbr), u_pol, u_out);
 #endif
   } else if (PART == EV_RT) {
     crossed = true;   // (not reached)
@@ -523,7 +523,7 @@ R3D_HD int step_event(const KArgs& a, const Tables<KIND>& T, Phonon& p, Rng& rng
       step = (dvp > dvs ? dvp : dvs) > 0.00001;
     }
     if (step) {
-      crossed = bend(p, cell_face_normal(c, ev.face, p.loc), vi, vo);
+      crossed = bend<KIND == CELL_CYL>(p, cell_face_normal(c, ev.face, p.loc), vi, vo);
     } else {
       crossed = true;
     }
@@ -548,13 +548,13 @@ R3D_HD RtChoice rt_event_choose(const KArgs& a, const Tables<KIND>& T, const Pho
   // (the event's uniforms first: they wait for nothing, the interface's records have to be fetched)
   double u_pol, u_out;
   rt_draws(p, rng, rng_key(a.seed), u_pol, u_out);
-  return rt_choose(p, rt_interface<KIND>(a, T, p, ev, nbr), u_pol, u_out);
+  return rt_choose<KIND == CELL_CYL>(p, rt_interface<KIND>(a, T, p, ev, nbr), u_pol, u_out);
 }
 template <int KIND>
 R3D_HD void rt_event_apply(const KArgs& a, const Tables<KIND>& T, Phonon& p, LaneStats& st, const Pending& ev,
                            int nbr, RtChoice ch) {
   // what is read again of the tables: the face normal
-  const bool crossed = rt_apply(p, cell_face_normal(cell_rec<KIND>(T, p.cell, p.type), ev.face, p.loc), ch);
+  const bool crossed = rt_apply<KIND == CELL_CYL>(p, cell_face_normal(cell_rec<KIND>(T, p.cell, p.type), ev.face, p.loc), ch);
   if (crossed) {
     p.cell = nbr, st.transfer++;
   } else {

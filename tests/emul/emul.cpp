@@ -410,7 +410,8 @@ extern "C" void r3d_emul_shell_filter(int mode, uint64_t n, uint64_t seed, doubl
 // mode: 0 solid on solid, moderate contrasts; 1 free surface; 2 incidence within 1e-12 .. 1e-2 of a critical angle of one
 //       of the outgoing rays; 3 grazing incidence, cos(i) = 1e-6 .. 1e-2; 4 nearly identical media; 5 a fluid (beta = 0)
 //       on either side: the reference's default outcome; 6 contrasts up to 1e3; 7 near-normal incidence, sin(i) = 1e-9 ..
-//       1e-3; 8 along the normal exactly (the reference's substitute axis, geom_r3.cpp:146-171)
+//       1e-3; 8 along the normal exactly (the reference's substitute axis, geom_r3.cpp:146-171); 9 HORIZONTAL faces, normal
+//       (0, 0, +-1), through the layered models' flat-face form (rt_choose<true> / rt_apply<true>), vertical rays included
 // Two places where the REFERENCE's formulation is the ill-conditioned side, and the comparison allows what it loses:
 //   * it takes cos(i) as sqrt(1 - sin(i)^2), good to 1.1e-16 / cos(i) (absolutely), where the engine has n.d itself: the
 //     weights (which carry cos(i)) then differ by 1e-16 / cos(i)^2 of themselves, the reflected direction by 1e-16 / cos(i);
@@ -454,7 +455,7 @@ extern "C" void r3d_emul_rt_events(int mode, uint64_t n, uint64_t seed, double t
     int type = g.u() < 0.5 ? RAY_P : RAY_S;
     if (mode == 5 && media[2] == 0.0) type = RAY_P;   // (no S ray travels in a fluid)
     // (mode 8: +z is the one normal whose (theta, phi) give the unit vector back exactly)
-    const V3 nrm = mode == 8 ? v3(0, 0, 1) : rnd_unit(g);
+    const V3 nrm = mode == 8 ? v3(0, 0, 1) : mode == 9 ? v3(0, 0, g.u() < 0.5 ? 1.0 : -1.0) : rnd_unit(g);
     // incidence: the sine of the angle to the normal
     double sini = std::sqrt(g.u());
     if (mode == 2) {
@@ -469,12 +470,13 @@ extern "C" void r3d_emul_rt_events(int mode, uint64_t n, uint64_t seed, double t
     if (mode == 3) sini = std::sqrt(1.0 - std::pow(g.logu(1e-6, 1e-2), 2));   // grazing
     if (mode == 7) sini = g.logu(1e-9, 1e-3);                                  // near normal
     if (mode == 8) sini = 0.0;                                                 // along the normal exactly
+    if (mode == 9 && g.u() < 0.05) sini = 0.0;
     // a direction with that incidence: normal cos(i) + tangent sin(i)
     V3 tng = cross(nrm, rnd_unit(g));
     while (mag2(tng) < 1e-6) tng = cross(nrm, rnd_unit(g));
     tng = (1.0 / std::sqrt(mag2(tng))) * tng;
     V3 dir = std::sqrt(std::fmax(0.0, 1.0 - sini * sini)) * nrm + sini * tng;
-    if (mode == 8) dir = nrm;
+    if (mode == 8 || (mode == 9 && sini == 0.0)) dir = nrm;
     // the reference's phonon carries (theta, phi): both sides start from the direction those angles give
     const double theta = std::acos(std::fmax(-1.0, std::fmin(1.0, dir.z))), phi = std::atan2(dir.y, dir.x);
     dir = v3(std::sin(theta) * std::cos(phi), std::sin(theta) * std::sin(phi), std::cos(theta));
@@ -491,8 +493,8 @@ extern "C" void r3d_emul_rt_events(int mode, uint64_t n, uint64_t seed, double t
     f.normal = nrm, f.has_neighbor = has_nbr != 0;
     f.rhoR = media[0], f.vR[0] = media[1], f.vR[1] = media[2];
     f.rhoT = media[3], f.vT[0] = media[4], f.vT[1] = media[5];
-    const RtChoice ch = rt_choose(p, f, u_pol, u_out);
-    const bool crossed = rt_apply(p, f.normal, ch);
+    const RtChoice ch = mode == 9 ? rt_choose<true>(p, f, u_pol, u_out) : rt_choose<false>(p, f, u_pol, u_out);
+    const bool crossed = mode == 9 ? rt_apply<true>(p, f.normal, ch) : rt_apply<false>(p, f.normal, ch);
     double o[8];
     const double nn[3] = {nrm.x, nrm.y, nrm.z};
     oracle(media, has_nbr, nn, theta, phi, pol, type, u_pol, u_out, o);

@@ -24,7 +24,8 @@ from oracle import oracle_ffi as O
 MODES = {0: "solid on solid", 1: "free surface", 2: "within 1e-12 .. 1e-2 of a critical angle",
          3: "grazing incidence", 4: "nearly identical media",
          5: "a fluid on one side (the reference's default outcome)", 6: "contrasts up to 1e3",
-         7: "near-normal incidence", 8: "along the normal exactly (the substitute axis)"}
+         7: "near-normal incidence", 8: "along the normal exactly (the substitute axis)",
+         9: "horizontal faces through the layered models' flat-face form"}
 TOL, MARGIN = 1e-9, 1e-9
 
 
@@ -42,7 +43,7 @@ def run(mode, n, seed):
 
 
 @pytest.mark.parametrize("mode,n", [(0, 6_000_000), (1, 3_000_000), (2, 3_000_000), (3, 2_000_000), (4, 2_000_000),
-                                    (5, 1_000_000), (6, 3_000_000), (7, 2_000_000), (8, 500_000)])
+                                    (5, 1_000_000), (6, 3_000_000), (7, 2_000_000), (8, 500_000), (9, 4_000_000)])
 def test_event_is_the_oracles_event(mode, n):
     r = run(mode, n, seed=20261005 + mode)
     assert r["cases"] == n
