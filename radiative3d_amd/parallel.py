@@ -54,11 +54,19 @@ class Comm:
         L = _ffi.hip_lib(path=lib)
         rank, world = dist.get_rank(), dist.get_world_size()
         ident = C.create_string_buffer(_ffi.R3D_COMM_ID_BYTES)
+        on = torch.device(device) if dist.get_backend() == "nccl" else torch.device("cpu")
+        # Forming the communicator is a collective INSIDE the library: a rank that cannot take part (no librccl to bind)
+        # must say so BEFORE the others enter it and wait for it for ever -- every rank probes the library first (an id
+        # of its own, thrown away) and the ranks agree on the outcome.
+        probe = C.create_string_buffer(_ffi.R3D_COMM_ID_BYTES)
+        can = torch.tensor([0 if L.r3d_comm_unique_id(probe) else 1], dtype=torch.int32, device=on)
+        dist.all_reduce(can, op=dist.ReduceOp.MIN)
+        if not int(can.item()):
+            raise RuntimeError("librccl cannot be bound on some rank: " + L.r3d_last_error().decode())
         status = 0
         if rank == 0 and L.r3d_comm_unique_id(ident):
             status = 1
         # (the id and rank 0's status travel together, so that every rank gives up when rank 0 could not make one)
-        on = torch.device(device) if dist.get_backend() == "nccl" else torch.device("cpu")
         box = torch.tensor(list(ident.raw) + [status], dtype=torch.uint8, device=on)
         dist.broadcast(box, src=0)
         box = box.cpu()

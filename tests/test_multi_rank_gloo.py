@@ -256,3 +256,32 @@ def test_grid_reduced_by_frame_equals_the_all_reduced_grid(tmp_path, world):
     got = np.load(str(tmp_path / f"frames_{world}.npy"))
     _, want = E.run_with_volume(Model(crustpinch(3) + VIDEO), n, volume_desc(**GRID))
     assert int(want.sum()) > 5000 and (got == want).all()
+
+
+def _comm_form_worker(rank, world, port, out_path):
+    """Comm.form without a GPU: the library's collective communicator cannot be formed here, and what matters is HOW
+    that goes -- every rank gets the same RuntimeError (nobody is left waiting inside ncclCommInitRank for a rank that
+    gave up), and the process group is usable afterwards (bench.py then reduces the bins through torch.distributed)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from radiative3d_amd.parallel import Comm
+    said = ""
+    try:
+        Comm.form("cuda:%d" % rank)
+    except RuntimeError as exc:
+        said = str(exc)
+    t = torch.tensor([1 if said else 0], dtype=torch.int64)
+    dist.all_reduce(t)                     # (still in step with each other)
+    if rank == 0:
+        with open(out_path, "w") as f:
+            f.write("%d\n%s\n" % (int(t.item()), said))
+    dist.destroy_process_group()
+
+
+def test_a_communicator_that_cannot_form_fails_on_every_rank_alike(tmp_path):
+    world = 2
+    out = tmp_path / "said.txt"
+    mp.spawn(_comm_form_worker, args=(world, _free_port(), str(out)), nprocs=world, join=True)
+    lines = out.read_text().splitlines()
+    assert int(lines[0]) == world, lines            # every rank raised
+    assert "librccl" in lines[1] or "r3d_comm" in lines[1], lines
