@@ -780,6 +780,10 @@ def test_chain_step_kernel_with_its_records_compiled_in_matches_the_oracle_per_h
     binary itself stays held through its bins, counters and the drain's records of the histories it hands on (the test
     above).  Reference loop: phonons.cpp:540-682."""
     from radiative3d_amd.configs import CONFIGS
+    if not os.path.exists(STEP_FINALS_LIB):   # (__graft_entry__.build() makes it; a tree that was built by `make` alone: here)
+        import subprocess
+        repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        subprocess.run(["make", "-C", repo, "variant", "NAME=STEPFINALS", "DEFS=-DR3D_STEP_FINALS=1"], capture_output=True, timeout=900)
     assert os.path.exists(STEP_FINALS_LIB), "variant_STEPFINALS.so is not built (__graft_entry__.build() makes it)"
     e = Engine(Model(CONFIGS[name](4)), lib=STEP_FINALS_LIB)
     n = 4 * per_launch
