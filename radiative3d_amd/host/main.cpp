@@ -5,10 +5,10 @@
 // files.  The N-phonon loop itself (Model::RunSimulation, model.cpp:602-633)
 // is one call into the engine's C-ABI.
 //
-// Differences a user can see: `--seed=S` and `--gpus=N` are accepted (the
-// reference seeds from the clock and is single-process); `--reports` keywords
-// other than INV / ALL_OFF are accepted but the per-event text stream is not
-// produced.
+// Differences a user can see: `--seed=S`, `--gpus=N` / `--devices=a,b,...` and `--scatter-grid=...` are accepted (the
+// reference seeds from the clock, is single-process and has no event histogram); the `--reports` stream is written
+// after the run, grouped by history, where the reference writes its lines as they happen (the engine appends binary
+// records in HBM: include/r3d.h r3d_event); tables are built in HBM unless `--host-tables` is given.
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
