@@ -786,16 +786,11 @@ void refraction_full_rt(Ctx& c, Phonon& p, int face_idx) {
 }
 
 // Phonon::Refraction_Bend, phonons.cpp:311-405
-void refraction_bend(Ctx& c, Phonon& p, int face_idx) {
-  const r3d_model_desc& m = *c.m;
-  const r3d_cell& cell = m.cells[p.cell];
-  const r3d_face& f = cell.faces[face_idx];
+// (the bend on a prepared face: unit normal, the ray's velocity either side; returns true if the ray crosses)
+bool bend_core(Phonon& p, V fnorm, double veli, double velo) {
   V dir = from_angles(p.theta, p.phi);
-  V fnorm = face_normal(m, f, face_idx, p.loc);
   V fpara = in_plane_unit_perp(fnorm, dir);
   V fparash = cross(fnorm, fpara);
-  double veli = velocity_at(m, cell, p.loc, p.type);
-  double velo = velocity_at(m, m.cells[f.neighbor], p.loc, p.type);
   double sini = dot(fpara, dir);
   double sino = (velo / veli) * sini;
   bool transfer;
@@ -816,7 +811,16 @@ void refraction_bend(Ctx& c, Phonon& p, int face_idx) {
   }
   p.theta = theta_of(outdir), p.phi = phi_of(outdir);
   p.pol = polout;
-  if (transfer) p.cell = f.neighbor;
+  return transfer;
+}
+void refraction_bend(Ctx& c, Phonon& p, int face_idx) {
+  const r3d_model_desc& m = *c.m;
+  const r3d_cell& cell = m.cells[p.cell];
+  const r3d_face& f = cell.faces[face_idx];
+  const V fnorm = face_normal(m, f, face_idx, p.loc);
+  const double veli = velocity_at(m, cell, p.loc, p.type);
+  const double velo = velocity_at(m, m.cells[f.neighbor], p.loc, p.type);
+  if (bend_core(p, fnorm, veli, velo)) p.cell = f.neighbor;
 }
 
 // CellFace::VelocityJump, media_cellface.cpp:83-99
@@ -1100,6 +1104,17 @@ void r3d_oracle_rt_event(const double media[6], int has_neighbor, const double n
   const bool crossed = rt_event_core(r, p, u_pol, u_out, &choice, &margin, &pol_margin);
   out[0] = p.type, out[1] = p.theta, out[2] = p.phi, out[3] = p.pol, out[4] = crossed ? 1 : 0, out[5] = choice;
   out[6] = margin, out[7] = pol_margin;
+}
+
+// Known-answer hook for tests: ONE Snell bend without conversion on a bare face (Phonon::Refraction_Bend,
+// phonons.cpp:311-405): the face's outward unit normal, the phonon (theta, phi, polarisation angle, type), the ray's
+// velocity on its own side and beyond the face.   -> out[4] = theta, phi, pol, crossed (0 / 1)
+void r3d_oracle_bend_event(const double normal[3], double theta, double phi, double pol, int type, double veli, double velo,
+                           double out[4]) {
+  Phonon p;
+  p.theta = theta, p.phi = phi, p.pol = pol, p.type = type;
+  const bool crossed = bend_core(p, mk(normal), veli, velo);
+  out[0] = p.theta, out[1] = p.phi, out[2] = p.pol, out[3] = crossed ? 1 : 0;
 }
 
 // Known-answer hooks for tests: one leg of ray geometry in a given cell.

@@ -546,3 +546,76 @@ extern "C" void r3d_emul_rt_weights(const double media[6], double sini, int inty
   rt_weights(f, sini, intype, w, det2);
   w[6] = det2;
 }
+
+// ---- the Snell bend without conversion on random bare faces: bend<FLAT_FACES> (r3d_physics.h) beside the oracle's
+//      restatement of Phonon::Refraction_Bend (oracle/r3d_oracle.cpp r3d_oracle_bend_event).
+// mode: 0 random faces, moderate velocity steps; 1 steps of 1e-5 .. 1e-3 (what the STEP class of a smooth model sees);
+//       2 within 1e-12 .. 1e-2 of total reflection (either side); 3 grazing and near-normal incidence; 4 HORIZONTAL faces
+//       through the layered models' flat-face form, vertical rays included
+// out[0] cases, [1] crossed / reflected differs, [2] of those: outgoing sine further than `margin` from 1, [3] directions
+//       off, [4] polarisations off, [5] crossed, [6] S rays;  dev[0] / dev[1]: largest direction / polarisation x sin(theta) error
+typedef void (*bend_event_fn)(const double normal[3], double theta, double phi, double pol, int type, double veli, double velo,
+                              double out[4]);
+extern "C" void r3d_emul_bend_events(int mode, uint64_t n, uint64_t seed, double tol, double margin, uint64_t* out, double* dev,
+                                     bend_event_fn oracle) {
+  SplitMix g{seed * 0x2545F4914F6CDD1Dull + 7919u * (uint64_t)mode};
+  for (int i = 0; i < 8; i++) out[i] = 0;
+  dev[0] = dev[1] = 0.0;
+  for (uint64_t it = 0; it < n; it++) {
+    const V3 nrm = mode == 4 ? v3(0, 0, g.u() < 0.5 ? 1.0 : -1.0) : rnd_unit(g);
+    const double veli = 1.5 + 7.0 * g.u();
+    double velo = veli * (0.6 + 0.9 * g.u());
+    if (mode == 1) velo = veli * (1.0 + g.logu(1e-5, 1e-3) * (g.u() < 0.5 ? 1.0 : -1.0));
+    double sini = std::sqrt(g.u());
+    if (mode == 2) {
+      velo = veli * (1.05 + g.u());
+      sini = (veli / velo) * (1.0 + g.logu(1e-12, 1e-2) * (g.u() < 0.5 ? 1.0 : -1.0));
+      if (!(sini < 1.0)) sini = veli / velo;
+    }
+    if (mode == 3) sini = g.u() < 0.5 ? std::sqrt(1.0 - std::pow(g.logu(1e-6, 1e-2), 2)) : g.logu(1e-9, 1e-3);
+    if (mode == 4 && g.u() < 0.05) sini = 0.0;
+    V3 tng = cross(nrm, rnd_unit(g));
+    while (mag2(tng) < 1e-6) tng = cross(nrm, rnd_unit(g));
+    tng = (1.0 / std::sqrt(mag2(tng))) * tng;
+    V3 dir = std::sqrt(std::fmax(0.0, 1.0 - sini * sini)) * nrm + sini * tng;
+    if (mode == 4 && sini == 0.0 && nrm.z > 0) dir = nrm;
+    const double theta = std::acos(std::fmax(-1.0, std::fmin(1.0, dir.z))), phi = std::atan2(dir.y, dir.x);
+    dir = v3(std::sin(theta) * std::cos(phi), std::sin(theta) * std::sin(phi), std::cos(theta));
+    if (!(dot(nrm, dir) > 0.0)) {
+      it--;
+      continue;
+    }
+    const int type = g.u() < 0.4 ? RAY_P : RAY_S;
+    const double pol = type == RAY_P ? 0.0 : kPi * g.sym();
+    Phonon p;
+    p.t = p.path = p.recent = p.lamp = 0.0, p.loc = v3(0, 0, 0), p.cell = 0, p.moves = 0;
+    p.dir = dir, p.pc = std::cos(pol), p.ps = std::sin(pol), p.type = type;
+    const bool crossed = mode == 4 ? bend<true>(p, nrm, veli, velo) : bend<false>(p, nrm, veli, velo);
+    double o[4];
+    const double nn[3] = {nrm.x, nrm.y, nrm.z};
+    oracle(nn, theta, phi, pol, type, veli, velo, o);
+    out[0]++, out[5] += crossed ? 1 : 0, out[6] += type == RAY_S ? 1 : 0;
+    const double ci = dot(nrm, dir), si = std::sqrt(mag2(cross(nrm, dir)));
+    const double sino = (velo / veli) * si;
+    // (the reference's cos(i) = sqrt(1 - sin^2) and its unit axis unit(n x d): good to 1e-16 / cos(i), 1e-16 / sin(i))
+    const double lost_dir = 4e-16 / std::fmax(ci, 1e-300) + (sino < 1.0 ? 4e-16 / std::sqrt(std::fmax(1.0 - sino * sino, 1e-300)) : 0.0);
+    const double lost_axis = si > 0 ? 4e-16 / si : 0.0;
+    if ((o[3] != 0.0) != crossed) {
+      out[1]++;
+      if (std::fabs(sino - 1.0) > margin) out[2]++;
+      continue;
+    }
+    const V3 od = v3(std::sin(o[0]) * std::cos(o[1]), std::sin(o[0]) * std::sin(o[1]), std::cos(o[0]));
+    const double dd = std::sqrt(mag2(p.dir - od));
+    if (!(dd <= tol + lost_dir)) out[3]++;
+    if (dd > dev[0]) dev[0] = dd;
+    if (type == RAY_S) {
+      const double dp = std::sqrt((p.pc - std::cos(o[2])) * (p.pc - std::cos(o[2])) + (p.ps - std::sin(o[2])) * (p.ps - std::sin(o[2])));
+      const double st = std::sqrt(od.x * od.x + od.y * od.y);
+      if (st > 1e-6) {
+        if (!(dp <= tol + (lost_dir + lost_axis) / st)) out[4]++;
+        if (dp * st > dev[1]) dev[1] = dp * st;
+      }
+    }
+  }
+}

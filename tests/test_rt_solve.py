@@ -76,3 +76,28 @@ def test_weights_are_the_oracles_probabilities_times_the_determinant():
                 probs = O.rt_probs(*media, float(s), intype)
                 ours = np.array(w[:6]) / w[6]
                 assert np.allclose(ours, probs, rtol=1e-9, atol=1e-12 * max(probs)), (media, intype, s, ours, probs)
+
+
+BEND_MODES = {0: "random faces", 1: "velocity steps of 1e-5 .. 1e-3", 2: "within 1e-12 .. 1e-2 of total reflection",
+              3: "grazing and near-normal incidence", 4: "horizontal faces through the flat-face form"}
+
+
+@pytest.mark.parametrize("mode,n", [(0, 4_000_000), (1, 2_000_000), (2, 2_000_000), (3, 2_000_000), (4, 4_000_000)])
+def test_bend_is_the_oracles_bend(mode, n):
+    """`bend` (csrc/r3d_physics.h: Snell's law on the tangential part of the direction, the particle motion carried in
+    un-normalised axes; on a horizontal face of a layered model the polarisation angle simply carries over) against the
+    oracle's restatement of Phonon::Refraction_Bend (phonons.cpp:311-405: unit axes, SH / SV components, atan2), face by
+    face: crossed or totally reflected alike unless the outgoing sine is within 1e-9 of 1, directions and polarisations to
+    1e-9 (plus what the reference's own cos i and unit axis lose at grazing and near-normal incidence)."""
+    L = E.lib()
+    L.r3d_emul_bend_events.restype = None
+    L.r3d_emul_bend_events.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.POINTER(C.c_uint64),
+                                       C.POINTER(C.c_double), C.c_void_p]
+    out, dev = (C.c_uint64 * 8)(), (C.c_double * 2)()
+    L.r3d_emul_bend_events(mode, n, 20261006 + mode, TOL, MARGIN, out, dev, C.cast(O.lib().r3d_oracle_bend_event, C.c_void_p))
+    r = dict(cases=out[0], side_differs=out[1], side_differs_outside_margin=out[2], direction_off=out[3],
+             polarisation_off=out[4], crossed=out[5], s_rays=out[6], dev_dir=dev[0], dev_pol=dev[1])
+    assert r["cases"] == n
+    assert r["side_differs_outside_margin"] == 0 and r["side_differs"] <= 2, (BEND_MODES[mode], r)
+    assert r["direction_off"] == 0 and r["polarisation_off"] == 0, (BEND_MODES[mode], r)
+    assert r["s_rays"] > 0.4 * n and 0.05 * n < r["crossed"] <= n, (BEND_MODES[mode], r)
