@@ -1117,6 +1117,15 @@ void r3d_oracle_bend_event(const double normal[3], double theta, double phi, dou
   out[0] = p.theta, out[1] = p.phi, out[2] = p.pol, out[3] = crossed ? 1 : 0;
 }
 
+// Known-answer hook for tests: Phonon::Transform (phonons.cpp:116-170; OrthoAxes, geom_r3.cpp:212-340) -- a phonon
+// (theta, phi, pol) rotated by a deflection (theta, phi, pol) given in its own frame.   -> out[3] = theta, phi, pol
+void r3d_oracle_transform(double theta, double phi, double pol, double rth, double rph, double rpol, double out[3]) {
+  Axes AA = make_axes(theta, phi, pol);
+  Axes BB = make_axes(rth, rph, rpol);
+  Axes SS = express(AA, BB);
+  out[0] = SS.theta, out[1] = SS.phi, out[2] = SS.rot;
+}
+
 // Known-answer hooks for tests: one leg of ray geometry in a given cell.
 //   r3d_oracle_advance: move `len` along the ray from (loc, theta, phi)
 //       -> out[8] = new loc(3), new theta, new phi, travel time, attenuation, 0

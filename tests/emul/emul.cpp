@@ -619,3 +619,40 @@ extern "C" void r3d_emul_bend_events(int mode, uint64_t n, uint64_t seed, double
     }
   }
 }
+
+// ---- the scattering's rotation: scatter_transform (r3d_physics.h) beside the oracle's Phonon::Transform
+//      (oracle/r3d_oracle.cpp r3d_oracle_transform), random phonons and deflections; mode 1: deflections within 1e-9 .. 1e-3
+//      of forward and backward, mode 2: phonons within 1e-9 .. 1e-3 of the poles (where theta^, phi^ turn fastest)
+// out[0] cases, [1] directions off, [2] polarisations off;  dev[0] / dev[1] largest direction / polarisation x sin(theta) error
+typedef void (*transform_fn)(double theta, double phi, double pol, double rth, double rph, double rpol, double out[3]);
+extern "C" void r3d_emul_transforms(int mode, uint64_t n, uint64_t seed, double tol, uint64_t* out, double* dev, transform_fn oracle) {
+  SplitMix g{seed * 0x2545F4914F6CDD1Dull + 104729u * (uint64_t)mode};
+  out[0] = out[1] = out[2] = 0;
+  dev[0] = dev[1] = 0.0;
+  for (uint64_t it = 0; it < n; it++) {
+    double theta = std::acos(g.sym()), phi = kPi * g.sym(), pol = kPi * g.sym();
+    double rth = std::acos(g.sym()), rph = kPi * g.sym(), rpol = g.u() < 0.5 ? 0.0 : kPi * g.sym();
+    if (mode == 1) rth = g.u() < 0.5 ? g.logu(1e-9, 1e-3) : kPi - g.logu(1e-9, 1e-3);
+    if (mode == 2) theta = g.u() < 0.5 ? g.logu(1e-9, 1e-3) : kPi - g.logu(1e-9, 1e-3);
+    Phonon p;
+    p.t = p.path = p.recent = p.lamp = 0.0, p.loc = v3(0, 0, 0), p.cell = 0, p.moves = 0, p.type = RAY_S;
+    p.dir = v3(std::sin(theta) * std::cos(phi), std::sin(theta) * std::sin(phi), std::cos(theta));
+    p.pc = std::cos(pol), p.ps = std::sin(pol);
+    const double dirn[4] = {std::cos(rth), std::cos(rph), std::sin(rph), std::sin(rth)};
+    scatter_transform(p, dirn, std::cos(rpol), std::sin(rpol), RAY_S);
+    double o[3];
+    oracle(theta, phi, pol, rth, rph, rpol, o);
+    out[0]++;
+    const V3 od = v3(std::sin(o[0]) * std::cos(o[1]), std::sin(o[0]) * std::sin(o[1]), std::cos(o[0]));
+    const double dd = std::sqrt(mag2(p.dir - od));
+    if (!(dd <= tol)) out[1]++;
+    if (dd > dev[0]) dev[0] = dd;
+    const double dp = std::sqrt((p.pc - std::cos(o[2])) * (p.pc - std::cos(o[2])) + (p.ps - std::sin(o[2])) * (p.ps - std::sin(o[2])));
+    const double st = std::sqrt(od.x * od.x + od.y * od.y);
+    if (st > 1e-6) {
+      // (both sides carry the polarisation as an angle about axes that turn by (direction error) / sin(theta) near a pole)
+      if (!(dp * st <= tol)) out[2]++;
+      if (dp * st > dev[1]) dev[1] = dp * st;
+    }
+  }
+}

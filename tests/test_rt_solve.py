@@ -101,3 +101,19 @@ def test_bend_is_the_oracles_bend(mode, n):
     assert r["side_differs_outside_margin"] == 0 and r["side_differs"] <= 2, (BEND_MODES[mode], r)
     assert r["direction_off"] == 0 and r["polarisation_off"] == 0, (BEND_MODES[mode], r)
     assert r["s_rays"] > 0.4 * n and 0.05 * n < r["crossed"] <= n, (BEND_MODES[mode], r)
+
+
+@pytest.mark.parametrize("mode,n", [(0, 4_000_000), (1, 1_000_000), (2, 1_000_000)])
+def test_scatter_rotation_is_the_oracles_transform(mode, n):
+    """`scatter_transform` (csrc/r3d_physics.h: the deflection's unit vector and S1 axis expressed in the phonon's
+    (S1, S2, direction) frame by algebra) against the oracle's Phonon::Transform (phonons.cpp:116-170, OrthoAxes
+    geom_r3.cpp:212-340: three frames built from angles, acos / atan2 back), case by case: random phonons and
+    deflections, deflections all but forward or backward, phonons all but along a pole."""
+    L = E.lib()
+    L.r3d_emul_transforms.restype = None
+    L.r3d_emul_transforms.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_double),
+                                      C.c_void_p]
+    out, dev = (C.c_uint64 * 3)(), (C.c_double * 2)()
+    L.r3d_emul_transforms(mode, n, 20261007 + mode, TOL, out, dev, C.cast(O.lib().r3d_oracle_transform, C.c_void_p))
+    assert out[0] == n and out[1] == 0 and out[2] == 0, dict(cases=out[0], direction_off=out[1], polarisation_off=out[2],
+                                                               dev_dir=dev[0], dev_pol=dev[1])
